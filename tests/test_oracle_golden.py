@@ -1,0 +1,68 @@
+"""CPU: the numpy oracle against golden vectors produced by the reference's own Numpy backend."""
+import numpy as np
+import pytest
+
+from oracle import sfft_oracle as O
+from _golden import golden_names, load_golden, packet_roles, rms, rel_rms_err
+
+NAMES = golden_names()
+
+
+def _params(meta):
+    return O.SSC(meta["N0"], meta["N1"], meta["KerHW"], meta["DK"], meta["DB"], bool(meta["CPR"]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_linear_system_matches_reference(name):
+    g = load_golden(name)
+    p = _params(g["meta"])
+    I, J, mI, mJ, _ = packet_roles(g)
+    LHMAT, RHb = O.establish_system(mI, mJ, p)
+    # element-wise, relative to the block maximum (<= 1e-11)
+    assert np.max(np.abs(LHMAT - g["LHMAT"])) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
+    assert np.max(np.abs(RHb - g["RHb"])) <= 1e-11 * np.max(np.abs(g["RHb"]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_apply_given_reference_solution(name):
+    """Apply-only gate: DIFF from the reference's Solution, pixel RMS error <= 1e-10 * RMS(J)."""
+    g = load_golden(name)
+    p = _params(g["meta"])
+    I, J, mI, mJ, nm = packet_roles(g)
+    DIFF = O.ESS(I, J, p, SFFTSolution=g["Solution"], Subtract=True)[1]
+    if nm is not None:
+        DIFF[nm] = np.nan
+    if g["meta"]["ForceConv"] == "SCI":
+        DIFF = -DIFF
+    assert rms(DIFF - g["DIFF"]) <= 1e-10 * rms(J)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_end_to_end(name):
+    """End-to-end gate: DIFF pixel-RMS error <= 1e-6 * RMS(DIFF_ref)."""
+    g = load_golden(name)
+    m = g["meta"]
+    Solution, DIFF = O.CP_arrays(g["REF"], g["SCI"], g["mREF"], g["mSCI"], m["ForceConv"], m["KerHW"],
+                                 m["DK"], m["DB"], bool(m["CPR"]))
+    assert np.array_equal(np.isnan(DIFF), np.isnan(g["DIFF"]))
+    assert rel_rms_err(DIFF, g["DIFF"]) <= 1e-6
+    assert Solution.shape == g["Solution"].shape
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if "48x40" in n or "45x35" in n])
+def test_construct_fdiff_literal_equals_matmul_form(name):
+    g = load_golden(name)
+    p = _params(g["meta"])
+    I, J, _, _, _ = packet_roles(g)
+    d1 = O.ESS(I, J, p, SFFTSolution=g["Solution"], Subtract=True, literal=True)[1]
+    d2 = O.ESS(I, J, p, SFFTSolution=g["Solution"], Subtract=True, literal=False)[1]
+    assert rms(d1 - d2) <= 1e-11 * rms(J)
+
+
+def test_param_validation():
+    with pytest.raises(Exception, match="KerPolyOrder should be 0/1/2/3"):
+        O.SSC(64, 64, 2, 4, 0)
+    with pytest.raises(Exception, match="BGPolyOrder should be 0/1/2/3"):
+        O.SSC(64, 64, 2, 0, -1)
+    p = O.SSC(4096, 4096, 8, 2, 2, True)
+    assert (p["NEQ"], p["NEQ_FSfree"], p["Fijab"], p["Fab"]) == (1740, 1735, 1734, 289)
