@@ -1,0 +1,119 @@
+/*
+ * sfft_amd.h -- C ABI of the MI355X-native SFFT subtraction core (libsfft_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of thomasvrussell/sfft behind
+ * sfft.Customized_Packet.CP / sfft.PureCupy_Customized_Packet.PCCP -> sfft.sfftcore.
+ * The reference has no native FFI of its own on this path (its 17 CUDA kernels are C
+ * strings JIT-compiled through cupy.RawModule, sfft/sfftcore/SFFTConfigure.py:106-808),
+ * so each entry point below cites the reference *Python* interface it replaces.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, ints; no torch / hip types in signatures.
+ *   - image pointers are DEVICE pointers to float64, C order, shape [N0][N1], axis 0 = FITS
+ *     NAXIS1 (the packets transpose on read, sfft/CustomizedPacket.py:93); NaN-free.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - the caller allocates every output; the plan owns all workspaces.
+ *   - every function returns SFFT_OK (0) or a negative SFFT_ERR_* code; a human readable
+ *     message for the last failure on the calling thread is returned by sfft_last_error().
+ *   - one plan per (device, N0, N1, KerHW, DK, DB, ConstPhotRatio); a plan may be used by
+ *     one host thread at a time; no global state.
+ */
+#ifndef SFFT_AMD_H
+#define SFFT_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfft_plan sfft_plan;
+
+enum {
+    SFFT_OK = 0,
+    SFFT_ERR_INVALID_ARG = -1,      /* bad DK/DB/size: Python shim raises the reference's 'MeLOn ERROR' texts */
+    SFFT_ERR_UNSUPPORTED_SIZE = -2, /* image side not supported by the on-chip FFT of this build */
+    SFFT_ERR_HIP = -3,              /* a HIP runtime call failed (message has the HIP error string) */
+    SFFT_ERR_SINGULAR = -4,         /* linear system could not be solved (LU hit an exactly zero pivot) */
+    SFFT_ERR_NOMEM = -5
+};
+
+/* fields for sfft_plan_query(); the dict keys callers read from SFFTConfig[0]
+ * (sfft/sfftcore/SFFTConfigure.py:50-75, read at sfft/CustomizedPacket.py:207-217) */
+enum {
+    SFFT_Q_N0 = 0, SFFT_Q_N1, SFFT_Q_W0, SFFT_Q_W1, SFFT_Q_DK, SFFT_Q_DB, SFFT_Q_CONSTPHOTRATIO,
+    SFFT_Q_L0, SFFT_Q_L1, SFFT_Q_FAB, SFFT_Q_FIJ, SFFT_Q_FPQ, SFFT_Q_NEQ, SFFT_Q_FIJAB, SFFT_Q_NEQ_FSFREE,
+    SFFT_Q_FOMG, SFFT_Q_FGAM, SFFT_Q_FTHE, SFFT_Q_FPSI, SFFT_Q_FPHI, SFFT_Q_FDEL,
+    SFFT_Q_WORKSPACE_BYTES,         /* device memory owned by the plan */
+    SFFT_Q_LAST_SOLVER,             /* 1 = Cholesky, 2 = LU fallback, for the most recent solve */
+    SFFT_Q_NUM_GREEK_PAIRS,         /* spectral products actually transformed per solve */
+    SFFT_Q_COUNT
+};
+
+/* stage ids for sfft_stage_ms(); letters follow the reference's VERBOSE_LEVEL=2 printout
+ * (sfft/sfftcore/SFFTSubtract.py:594-597, 763-769, 814-816) */
+enum {
+    SFFT_ST_PRELIM_SOLVE = 0,  /* b+c: spatial polynomial + forward DFTs of the masked pair */
+    SFFT_ST_GREEK_G1,          /* d..h: Hadamard products + pruned column transform */
+    SFFT_ST_GREEK_G2,          /* d..h: pruned row transform -> lag patches */
+    SFFT_ST_FILL,              /* FillLS_* + Remove_LSFStripes */
+    SFFT_ST_SOLVE,             /* i: dense solve + Extend_Solution */
+    SFFT_ST_PRELIM_APPLY,      /* b+c on the full pair */
+    SFFT_ST_CONSTRUCT,         /* j+k: kernel transfer function + Construct_FDIFF */
+    SFFT_ST_INVERSE,           /* k: inverse DFT + DIFF epilogue */
+    SFFT_ST_COUNT
+};
+
+/* SingleSFFTConfigure.SSC (sfft/sfftcore/SFFTConfigure.py:1369-1397): validates arguments, derives the
+ * parameter dictionary (:34-75), builds twiddle / index / polynomial tables and all workspaces on `device`.
+ * Replaces the per-call nvcc / numba JIT of the reference with a cacheable handle. */
+int sfft_plan_create(sfft_plan** plan, int N0, int N1, int KerHW, int KerPolyOrder, int BGPolyOrder,
+                     int ConstPhotRatio, int device);
+
+int sfft_plan_destroy(sfft_plan* plan);
+
+/* read one SFFT_Q_* field */
+int sfft_plan_query(const sfft_plan* plan, int field, long long* value);
+
+/* ElementalSFFTSubtract.ESS(PixA_I, PixA_J, SFFTConfig, SFFTSolution=None, Subtract=False)[0]
+ * (sfft/sfftcore/SFFTSubtract.py:823-837; body :8-412 Cupy, :477-755 Numpy):
+ * establish the normal equations from the (masked) pair and solve them.
+ * d_solution: [NEQ] float64, ordered [a_ijab (ij-major, ab row-major), b_pq]. Synchronises `stream`. */
+int sfft_solve(sfft_plan* plan, const double* d_I, const double* d_J, double* d_solution, void* stream);
+
+/* ElementalSFFTSubtract.ESS(PixA_I, PixA_J, SFFTConfig, SFFTSolution=sol, Subtract=True)[1]
+ * (sfft/sfftcore/SFFTSubtract.py:428-461 Cupy, :773-807 Numpy): DIFF = J - I (*) K - B for a given solution.
+ * d_diff: [N0][N1] float64. Stream-ordered, does not synchronise. */
+int sfft_apply(sfft_plan* plan, const double* d_I, const double* d_J, const double* d_solution,
+               double* d_diff, void* stream);
+
+/* GeneralSFFTSubtract.GSS / GeneralSFFTSubtract_PureCupy.GSS with ContamMask_I=None
+ * (sfft/sfftcore/SFFTSubtract.py:839-904, 1371-1430): solve on (mI, mJ), apply to (I, J). Synchronises. */
+int sfft_subtract(sfft_plan* plan, const double* d_I, const double* d_J, const double* d_mI, const double* d_mJ,
+                  double* d_solution, double* d_diff, void* stream);
+
+/* Parity aid: the linear system of the most recent sfft_solve()/sfft_subtract() on this plan, before
+ * stripe removal, exactly as ESS holds it (LHMAT[NEQ][NEQ], RHb[NEQ]; SFFTSubtract.py:616-617).
+ * Either pointer may be NULL. Synchronises. */
+int sfft_get_system(sfft_plan* plan, double* d_LHMAT, double* d_RHb, void* stream);
+
+/* Parity aid: SCALE * DFT2(I * cx^i * cy^j) in the plan's half-spectrum layout, d_spec: [N0][N1/2+1]
+ * complex128 (interleaved re,im) -- items 3+4 of SURVEY.md 8(a). */
+int sfft_dbg_forward_spectrum(sfft_plan* plan, const double* d_I, int i, int j, double* d_spec, void* stream);
+
+/* enable (1) / disable (0) hipEvent timing of the stages of subsequent calls */
+int sfft_set_timing(sfft_plan* plan, int enable);
+
+/* milliseconds spent in stage `stage` (SFFT_ST_*) during the most recent timed call; synchronises */
+int sfft_stage_ms(sfft_plan* plan, int stage, float* ms);
+
+/* force the LU fallback for every solve (1) or let the plan choose (0, default: Cholesky first) */
+int sfft_set_force_lu(sfft_plan* plan, int enable);
+
+const char* sfft_last_error(void);
+
+/* library version string, e.g. "sfft_amd 0.1 (gfx950)" */
+const char* sfft_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFFT_AMD_H */

@@ -1,0 +1,98 @@
+"""PureCupy_Customized_Packet.PCCP -- mirror of sfft/PureCupyCustomizedPacket.py:38-187 on the HIP backend.
+
+Device arrays in, device arrays out, no file I/O.  "GPU arrays" are torch.float64 CUDA (HIP) tensors (or
+anything exposing __cuda_array_interface__); results are torch tensors on the same device.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .sfftcore.SFFTConfigure import SingleSFFTConfigure
+from .sfftcore.SFFTSubtract import GeneralSFFTSubtract_PureCupy
+
+__all__ = ["PureCupy_Customized_Packet"]
+
+
+def _t(x, dev):
+    if isinstance(x, torch.Tensor):
+        return x
+    return torch.as_tensor(x, device=dev)
+
+
+class PureCupy_Customized_Packet:
+    @staticmethod
+    def PCCP(PixA_REF_GPU, PixA_SCI_GPU, PixA_mREF_GPU, PixA_mSCI_GPU, ForceConv, GKerHW,
+             KerPolyOrder=2, BGPolyOrder=2, ConstPhotRatio=True, CUDA_DEVICE_4SUBTRACT='0', VERBOSE_LEVEL=2):
+        """Same parameters and conventions as the reference:
+        ForceConv='REF' -> DIFF = SCI - Conv(REF);  ForceConv='SCI' -> DIFF = Conv(SCI) - REF
+        (transients on the science image are always positive on DIFF)."""
+        dev = torch.device('cuda', int(CUDA_DEVICE_4SUBTRACT))
+        PixA_REF_GPU, PixA_SCI_GPU = _t(PixA_REF_GPU, dev), _t(PixA_SCI_GPU, dev)
+        PixA_mREF_GPU, PixA_mSCI_GPU = _t(PixA_mREF_GPU, dev), _t(PixA_mSCI_GPU, dev)
+
+        # * assertions (PureCupyCustomizedPacket.py:105-118)
+        assert torch.sum(torch.isnan(PixA_mREF_GPU)) == 0, "The masked reference image contains NaNs!"
+        assert torch.sum(torch.isnan(PixA_mSCI_GPU)) == 0, "The masked science image contains NaNs!"
+        assert PixA_REF_GPU.ndim == 2, "The input PixA_REF_GPU is not two-dimensional!"
+        assert PixA_SCI_GPU.ndim == 2, "The input PixA_SCI_GPU is not two-dimensional!"
+        assert PixA_mREF_GPU.ndim == 2, "The input PixA_mREF_GPU is not two-dimensional!"
+        assert PixA_mSCI_GPU.ndim == 2, "The input PixA_mSCI_GPU is not two-dimensional!"
+        assert PixA_REF_GPU.dtype == torch.float64, "The array does not have dtype cp.float64!"
+        assert PixA_SCI_GPU.dtype == torch.float64, "The array does not have dtype cp.float64!"
+        assert PixA_mREF_GPU.dtype == torch.float64, "The array does not have dtype cp.float64!"
+        assert PixA_mSCI_GPU.dtype == torch.float64, "The array does not have dtype cp.float64!"
+        assert ForceConv in ['REF', 'SCI']
+        ConvdSide = ForceConv
+        KerHW = GKerHW
+        torch.cuda.set_device(dev)
+
+        # * Create the union NaN mask (:125-131)
+        NaNmask_REF_GPU = torch.isnan(PixA_REF_GPU)
+        NaNmask_SCI_GPU = torch.isnan(PixA_SCI_GPU)
+        NaNmask_GPU = None
+        if bool(NaNmask_REF_GPU.any()) or bool(NaNmask_SCI_GPU.any()):
+            NaNmask_GPU = torch.logical_or(NaNmask_REF_GPU, NaNmask_SCI_GPU)
+
+        if VERBOSE_LEVEL in [0, 1, 2]:
+            print('MeLOn CheckPoint: TRIGGER Function Compilations of SFFT-SUBTRACTION!')
+        Tcomp_start = time.time()
+        NX, NY = PixA_REF_GPU.shape
+        SFFTConfig = SingleSFFTConfigure.SSC(NX=NX, NY=NY, KerHW=KerHW, KerPolyOrder=KerPolyOrder,
+                                             BGPolyOrder=BGPolyOrder, ConstPhotRatio=ConstPhotRatio,
+                                             BACKEND_4SUBTRACT="Cupy", VERBOSE_LEVEL=VERBOSE_LEVEL,
+                                             CUDA_DEVICE_4SUBTRACT=dev.index)
+        if VERBOSE_LEVEL in [1, 2]:
+            print('\nMeLOn Report: Function Compilations of SFFT-SUBTRACTION TAKES [%.3f s]' % (time.time() - Tcomp_start))
+
+        # * role swap and NaN fill (:148-162)
+        if ConvdSide == 'REF':
+            PixA_mI_GPU, PixA_mJ_GPU = PixA_mREF_GPU, PixA_mSCI_GPU
+            if NaNmask_GPU is not None:
+                PixA_I_GPU, PixA_J_GPU = PixA_REF_GPU.clone(), PixA_SCI_GPU.clone()
+                PixA_I_GPU[NaNmask_GPU] = PixA_mI_GPU[NaNmask_GPU]
+                PixA_J_GPU[NaNmask_GPU] = PixA_mJ_GPU[NaNmask_GPU]
+            else:
+                PixA_I_GPU, PixA_J_GPU = PixA_REF_GPU, PixA_SCI_GPU
+        if ConvdSide == 'SCI':
+            PixA_mI_GPU, PixA_mJ_GPU = PixA_mSCI_GPU, PixA_mREF_GPU
+            if NaNmask_GPU is not None:
+                PixA_I_GPU, PixA_J_GPU = PixA_SCI_GPU.clone(), PixA_REF_GPU.clone()
+                PixA_I_GPU[NaNmask_GPU] = PixA_mI_GPU[NaNmask_GPU]
+                PixA_J_GPU[NaNmask_GPU] = PixA_mJ_GPU[NaNmask_GPU]
+            else:
+                PixA_I_GPU, PixA_J_GPU = PixA_SCI_GPU, PixA_REF_GPU
+
+        Tsub_start = time.time()
+        Solution_GPU, PixA_DIFF_GPU, _ = GeneralSFFTSubtract_PureCupy.GSS(
+            PixA_I_GPU=PixA_I_GPU, PixA_J_GPU=PixA_J_GPU, PixA_mI_GPU=PixA_mI_GPU, PixA_mJ_GPU=PixA_mJ_GPU,
+            SFFTConfig=SFFTConfig, ContamMask_I_GPU=None, VERBOSE_LEVEL=VERBOSE_LEVEL)
+        if VERBOSE_LEVEL in [1, 2]:
+            print('\nMeLOn Report: SFFT-SUBTRACTION TAKES [%.3f s]' % (time.time() - Tsub_start))
+
+        # * Modifications on the difference image (:170-185)
+        if NaNmask_GPU is not None:
+            PixA_DIFF_GPU[NaNmask_GPU] = np.nan
+        if ConvdSide == 'SCI':
+            PixA_DIFF_GPU *= -1.
+        return Solution_GPU, PixA_DIFF_GPU

@@ -1,0 +1,83 @@
+"""ctypes binding of libsfft_amd.so (the C ABI declared in include/sfft_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing this
+module raises, and so does every operator of the package.
+"""
+import ctypes
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libsfft_amd.so")
+
+# error codes / query fields / stage ids: keep in sync with include/sfft_amd.h
+SFFT_OK = 0
+SFFT_ERR_INVALID_ARG = -1
+SFFT_ERR_UNSUPPORTED_SIZE = -2
+SFFT_ERR_HIP = -3
+SFFT_ERR_SINGULAR = -4
+SFFT_ERR_NOMEM = -5
+
+QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1", "Fab", "Fij", "Fpq", "NEQ", "Fijab",
+                "NEQ_FSfree", "FOMG", "FGAM", "FTHE", "FPSI", "FPHI", "FDEL", "WORKSPACE_BYTES", "LAST_SOLVER",
+                "NUM_GREEK_PAIRS"]
+STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse"]
+
+EXPORTS = ["sfft_plan_create", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
+           "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",
+           "sfft_last_error", "sfft_version"]
+
+
+class SfftLibraryMissing(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SfftLibraryMissing(
+            "sfft_amd: HIP library %s not found. Build it with `python -m sfft_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, dp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int
+    lib.sfft_plan_create.argtypes = [ctypes.POINTER(vp), ip, ip, ip, ip, ip, ip, ip]
+    lib.sfft_plan_destroy.argtypes = [vp]
+    lib.sfft_plan_query.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_longlong)]
+    lib.sfft_solve.argtypes = [vp, dp, dp, dp, vp]
+    lib.sfft_apply.argtypes = [vp, dp, dp, dp, dp, vp]
+    lib.sfft_subtract.argtypes = [vp, dp, dp, dp, dp, dp, dp, vp]
+    lib.sfft_get_system.argtypes = [vp, dp, dp, vp]
+    lib.sfft_dbg_forward_spectrum.argtypes = [vp, dp, ip, ip, dp, vp]
+    lib.sfft_set_timing.argtypes = [vp, ip]
+    lib.sfft_stage_ms.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_float)]
+    lib.sfft_set_force_lu.argtypes = [vp, ip]
+    for name in EXPORTS:
+        getattr(lib, name).restype = ctypes.c_int
+    lib.sfft_last_error.restype = ctypes.c_char_p
+    lib.sfft_last_error.argtypes = []
+    lib.sfft_version.restype = ctypes.c_char_p
+    lib.sfft_version.argtypes = []
+    return lib
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _load()
+    return _LIB
+
+
+def last_error():
+    return lib().sfft_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Turn a non-zero status into the reference's exception convention (Exception('MeLOn ERROR: ...'))."""
+    if rc == SFFT_OK:
+        return
+    msg = last_error()
+    if rc == SFFT_ERR_SINGULAR:
+        import numpy as np
+        raise np.linalg.LinAlgError(msg)      # what numpy.linalg.solve raises in the reference's Numpy backend
+    raise Exception("MeLOn ERROR: %s" % msg)

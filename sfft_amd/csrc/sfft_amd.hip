@@ -1,0 +1,1519 @@
+// sfft_amd.hip -- MI355X (gfx950) native SFFT subtraction core: kernels + C ABI (include/sfft_amd.h).
+//
+// Path covered (reference = thomasvrussell/sfft v1.7.3):
+//   SpatialCoor/SpatialPoly   sfft/sfftcore/SFFTConfigure.py:84-145     fused into rows_r2c (no coordinate planes)
+//   preliminary DFTs          sfft/sfftcore/SFFTSubtract.py:146-168     rows_r2c + cols_c2c (half spectrum, fp64)
+//   HadProd_* + Greek DFTs    SFFTConfigure.py:150-662, SFFTSubtract.py:226-383   greek_g1 + greek_g2 (pruned to the lags FillLS reads)
+//   FillLS_* + stripes        SFFTConfigure.py:198-711                  fill_system
+//   LSSolver                  SFFTSubtract.py:15-23, 398-403            blocked Cholesky (LU with partial pivoting as fallback)
+//   Extend_Solution           SFFTConfigure.py:716-732                  chol_backsolve / lu_backsolve scatter
+//   twiddles + Construct_FDIFF SFFTSubtract.py:433-447, SFFTConfigure.py:737-809   kernel_ctab + construct_fd
+//   inverse DFT               SFFTSubtract.py:460-461                   cols_c2c(inverse) + rows_c2r_diff
+//
+// Layout in HBM: images [N0][N1] f64 row-major; spectra [plane][N0][Nhp] complex128 with Nh = N1/2+1
+// columns kept (the inputs are real, so the other half is the conjugate mirror) and Nhp >= Nh the padded
+// row stride.  All arithmetic is IEEE fp64.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sfft_amd.h"
+
+typedef double2 cplx;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int set_err(int code, const std::string& msg) { g_last_error = msg; return code; }
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof(_b), "%s failed at %s:%d: %s", #call, __FILE__, __LINE__,        \
+                     hipGetErrorString(_e));                                                      \
+            return set_err(SFFT_ERR_HIP, _b);                                                     \
+        }                                                                                         \
+    } while (0)
+
+extern "C" const char* sfft_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double ipow(double x, int e) { double r = 1.0; for (int t = 0; t < e; ++t) r *= x; return r; }
+
+// In-place Stockham autosort FFT (forward, e^{-i}) of `nb` transforms of length M = 2^logM held in LDS at
+// s + f*stride.  Radix-4 stages (one leading radix-2 stage when logM is odd).  Every thread of the block
+// must call; requires nb*M <= 16*blockDim.x so that a thread owns at most 4 radix-4 butterflies per stage.
+// tw[k] = exp(-2*pi*i*k/M), k < M (global memory, cached).
+__device__ __forceinline__ void lds_fft(cplx* s, int M, int logM, int nb, int stride, const cplx* __restrict__ tw)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int p = 1, logp = 0;
+    if (logM & 1) {
+        const int T = M >> 1, logT = logM - 1, total = nb * T;
+        cplx u[8][2];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                const cplx* b = s + f * stride;
+                u[it][0] = b[i];
+                u[it][1] = b[i + T];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                cplx* b = s + f * stride;
+                b[2 * i] = cadd(u[it][0], u[it][1]);
+                b[2 * i + 1] = csub(u[it][0], u[it][1]);
+            }
+        }
+        __syncthreads();
+        p = 2; logp = 1;
+    }
+    const int T = M >> 2, logT = logM - 2, total = nb * T;
+    for (; p < M; p <<= 2, logp += 2) {
+        cplx y[4][4];
+        const int tshift = logM - logp - 2;   // twiddle step M/(4p)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                const int k = i & (p - 1);
+                const cplx* b = s + f * stride;
+                cplx u0 = b[i], u1 = b[i + T], u2 = b[i + 2 * T], u3 = b[i + 3 * T];
+                if (p > 1) {
+                    const int q = k << tshift;
+                    u1 = cmul(u1, tw[q]);
+                    u2 = cmul(u2, tw[2 * q]);
+                    u3 = cmul(u3, tw[3 * q]);
+                }
+                const cplx a02 = cadd(u0, u2), s02 = csub(u0, u2);
+                const cplx a13 = cadd(u1, u3), s13 = csub(u1, u3);
+                y[it][0] = cadd(a02, a13);
+                y[it][2] = csub(a02, a13);
+                // -i*(u1-u3) = (s13.y, -s13.x)
+                y[it][1] = make_double2(s02.x + s13.y, s02.y - s13.x);
+                y[it][3] = make_double2(s02.x - s13.y, s02.y + s13.x);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                const int k = i & (p - 1);
+                cplx* b = s + f * stride + (((i - k) << 2) + k);
+                b[0] = y[it][0];
+                b[p] = y[it][1];
+                b[2 * p] = y[it][2];
+                b[3 * p] = y[it][3];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One 1-D axis: length N transformed either directly (N = M power of two) or by Bluestein's chirp-z
+// (M = power of two >= 2N-1).  All tables live in device memory.
+struct AxisDev {
+    int N, M, logM, blue;
+    const cplx* tw;     // [M]   exp(-2 pi i k / M)
+    const cplx* chirp;  // [N]   exp(-i pi n^2 / N)            (Bluestein only)
+    const cplx* bf;     // [M]   FFT_M(conj-chirp filter) / M  (Bluestein only)
+    const cplx* root;   // [N]   exp(-2 pi i k / N)
+};
+
+// forward length-N DFT of nb sequences already resident in LDS (entries n >= N must be zero when blue).
+// On return entries [0, N) of each sequence hold the DFT.
+__device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int stride)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (!ax.blue) { lds_fft(s, ax.M, ax.logM, nb, stride, ax.tw); return; }
+    const int M = ax.M;
+    for (int e = tid; e < nb * M; e += nt) {           // a[n] = x[n] * chirp[n]
+        const int f = e / M, n = e - f * M;
+        if (n < ax.N) s[f * stride + n] = cmul(s[f * stride + n], ax.chirp[n]);
+    }
+    __syncthreads();
+    lds_fft(s, M, ax.logM, nb, stride, ax.tw);
+    for (int e = tid; e < nb * M; e += nt) {           // conj(A * Bf): second forward FFT then acts as inverse
+        const int f = e / M, k = e - f * M;
+        s[f * stride + k] = cconj(cmul(s[f * stride + k], ax.bf[k]));
+    }
+    __syncthreads();
+    lds_fft(s, M, ax.logM, nb, stride, ax.tw);
+    for (int e = tid; e < nb * M; e += nt) {
+        const int f = e / M, k = e - f * M;
+        if (k < ax.N) s[f * stride + k] = cmul(ax.chirp[k], cconj(s[f * stride + k]));
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward pass 1: rows, real -> half complex, two image rows per complex transform, SpatialPoly fused
+// ------------------------------------------------------------------------------------------------
+#define SFFT_MAX_PLANES 12
+struct RowsArgs {
+    const double* src[SFFT_MAX_PLANES];
+    int ei[SFFT_MAX_PLANES];
+    int ej[SFFT_MAX_PLANES];
+};
+
+__global__ void __launch_bounds__(1024) rows_r2c(RowsArgs a, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
+                                                  AxisDev ax, double scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int plane = blockIdx.y;
+    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const double* __restrict__ src = a.src[plane];
+    const int ei = a.ei[plane], ej = a.ej[plane];
+    const double cx0 = ipow((double(l0) + 1.0) / N0, ei);
+    const double cx1 = ipow((double(l1) + 1.0) / N0, ei);
+    const bool has1 = l1 < N0;
+    for (int n = tid; n < ax.M; n += nt) {
+        cplx z = make_double2(0.0, 0.0);
+        if (n < N1) {
+            const double cyp = ipow((double(n) + 1.0) / N1, ej);
+            z.x = src[(size_t)l0 * N1 + n] * (cx0 * cyp);
+            if (has1) z.y = src[(size_t)l1 * N1 + n] * (cx1 * cyp);
+        }
+        s[n] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, 1, ax.M);
+    cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
+    cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
+    for (int m = tid; m < Nh; m += nt) {
+        const cplx z = s[m];
+        const cplx zc = cconj(s[m == 0 ? 0 : N1 - m]);
+        o0[m] = make_double2(0.5 * scale * (z.x + zc.x), 0.5 * scale * (z.y + zc.y));
+        if (has1) {
+            const double dx = z.x - zc.x, dy = z.y - zc.y;   // (Z - Zc) / (2i) = (dy, -dx)/2
+            o1[m] = make_double2(0.5 * scale * dy, -0.5 * scale * dx);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: columns, complex -> complex in place, TC adjacent columns per workgroup
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) cols_c2c(cplx* __restrict__ data, int N0, int ncols, int Nhp, int TC, int MS,
+                                                  AxisDev ax, int inverse, double scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int c0 = blockIdx.x * TC;
+    cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp;
+    for (int e = tid; e < TC * ax.M; e += nt) {
+        const int l = e / TC, c = e - l * TC;
+        cplx z = make_double2(0.0, 0.0);
+        if (l < N0 && c0 + c < ncols) {
+            z = base[(size_t)l * Nhp + c0 + c];
+            if (inverse) z.y = -z.y;
+        }
+        s[c * MS + l] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, TC, MS);
+    for (int e = tid; e < TC * N0; e += nt) {
+        const int l = e / TC, c = e - l * TC;
+        if (c0 + c < ncols) {
+            cplx z = s[c * MS + l];
+            if (inverse) z.y = -z.y;
+            base[(size_t)l * Nhp + c0 + c] = make_double2(z.x * scale, z.y * scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse pass 2: rows, half complex -> real, two rows per transform, DIFF epilogue fused:
+//   DIFF = J - sum_pq b_pq cx^p cy^q - conv          (SFFTSubtract.py:452-461 with the J and T terms kept in real space)
+// ------------------------------------------------------------------------------------------------
+struct BkgArgs { int npq; int p[10]; int q[10]; };
+
+__global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ FD, const double* __restrict__ J,
+                                                       const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
+                                                       int N0, int N1, int Nh, int Nhp, AxisDev ax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const bool has1 = l1 < N0;
+    const cplx* f0 = FD + (size_t)l0 * Nhp;
+    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * Nhp;
+    const bool even = (N1 & 1) == 0;
+    for (int m = tid; m < ax.M; m += nt) {
+        cplx z = make_double2(0.0, 0.0);
+        if (m < N1) {
+            const bool mir = m >= Nh;
+            const int mm = mir ? N1 - m : m;
+            cplx x0 = f0[mm];
+            cplx x1 = has1 ? f1[mm] : make_double2(0.0, 0.0);
+            if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
+            if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
+            // Z = X0 + i X1, conjugated on input so that the forward transform acts as the inverse
+            z = make_double2(x0.x - x1.y, -(x0.y + x1.x));
+        }
+        s[m] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, 1, ax.M);
+    double b[10];
+    for (int t = 0; t < bk.npq; ++t) b[t] = bpq[t];
+    const double cx0 = (double(l0) + 1.0) / N0, cx1 = (double(l1) + 1.0) / N0;
+    for (int n = tid; n < N1; n += nt) {
+        const cplx z = s[n];                 // conj(result): row0 = z.x, row1 = -z.y
+        const double cy = (double(n) + 1.0) / N1;
+        double B0 = 0.0, B1 = 0.0;
+        for (int t = 0; t < bk.npq; ++t) {
+            const double cyq = ipow(cy, bk.q[t]);
+            B0 += b[t] * (ipow(cx0, bk.p[t]) * cyq);
+            B1 += b[t] * (ipow(cx1, bk.p[t]) * cyq);
+        }
+        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - B0 - z.x;
+        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - B1 + z.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Greek stage 1: for every listed pair (A, B) and column m of the half spectrum
+//      G[r][m] = sum_l A[l][m] * conj(B[l][m]) * W0^(l r),   |r| <= h          (pruned column DFT of the
+// Hadamard product; only these lags are ever read by FillLS_*, SFFTConfigure.py:251-269, 364-371, 621-628).
+// r and -r share their four real products.  B is either a stored plane or the rank-1 spectrum of T_pq.
+// ------------------------------------------------------------------------------------------------
+struct PairDesc {
+    int a_plane;     // plane index into spec
+    int b_plane;     // plane index, or -1: B = scale * Xp[l] * Yq[m]  (DFT of cx^p cy^q)
+    int bp, bq;      // exponents when b_plane < 0
+    int h;           // lag half width
+    int patch_off;   // offset (doubles) of this pair's [(2h+1)][(2h+1)] patch
+    long long gp_off;// offset (cplx) of this pair's [S][2h+1][Nhp] partial buffer
+    double scale;    // patch scale
+};
+
+template <int HB>
+__global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, const PairDesc* __restrict__ pairs, int pair0,
+                                               cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
+                                               int r_base, const cplx* __restrict__ root0,
+                                               const cplx* __restrict__ Xp, const cplx* __restrict__ Yq, double tscale)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    const PairDesc pr = pairs[pair0 + blockIdx.z];
+    const int h = pr.h;
+    const int PH = 2 * h + 1;
+    const int lb = chunk * rows_per_chunk;
+    const int le = min(N0, lb + rows_per_chunk);
+    const bool active = m < Nh;
+    const int mc = active ? m : 0;
+    const size_t plane_sz = (size_t)N0 * Nhp;
+    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz + mc;
+    const bool rank1 = pr.b_plane < 0;
+    const cplx* __restrict__ B = rank1 ? A : spec + (size_t)pr.b_plane * plane_sz + mc;
+    cplx yq = make_double2(0.0, 0.0);
+    const cplx* __restrict__ xp = Xp;
+    if (rank1) {
+        const cplx t = Yq[(size_t)pr.bq * Nhp + mc];
+        yq = make_double2(t.x * tscale, t.y * tscale);
+        xp = Xp + (size_t)pr.bp * N0;
+    }
+    int nact = h - r_base;
+    if (nact > HB) nact = HB;
+    int idx[HB];
+#pragma unroll
+    for (int t = 0; t < HB; ++t) idx[t] = (int)(((long long)lb * (r_base + 1 + t)) % N0);
+    double S1[HB], S2[HB], S3[HB], S4[HB];
+#pragma unroll
+    for (int t = 0; t < HB; ++t) { S1[t] = S2[t] = S3[t] = S4[t] = 0.0; }
+    double g0x = 0.0, g0y = 0.0;
+    for (int l = lb; l < le; ++l) {
+        const cplx av = A[(size_t)l * Nhp];
+        const cplx bv = rank1 ? cmul(xp[l], yq) : B[(size_t)l * Nhp];
+        const cplx H = cmulc(av, bv);
+        g0x += H.x; g0y += H.y;
+#pragma unroll
+        for (int t = 0; t < HB; ++t) {
+            if (t < nact) {
+                const cplx w = root0[idx[t]];
+                S1[t] = fma(H.x, w.x, S1[t]);
+                S2[t] = fma(H.y, w.y, S2[t]);
+                S3[t] = fma(H.x, w.y, S3[t]);
+                S4[t] = fma(H.y, w.x, S4[t]);
+                int ni = idx[t] + (r_base + 1 + t);
+                if (ni >= N0) ni -= N0;
+                idx[t] = ni;
+            }
+        }
+    }
+    if (!active) return;
+    cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp + m;
+    if (r_base == 0) g[(size_t)h * Nhp] = make_double2(g0x, g0y);
+#pragma unroll
+    for (int t = 0; t < HB; ++t) {
+        if (t < nact) {
+            const int r = r_base + 1 + t;
+            g[(size_t)(h + r) * Nhp] = make_double2(S1[t] - S2[t], S3[t] + S4[t]);
+            g[(size_t)(h - r) * Nhp] = make_double2(S1[t] + S2[t], S4[t] - S3[t]);
+        }
+    }
+}
+
+// Greek stage 2: patch[r][e] = scale * sum_{m < Nh} wgt[m] * Re( W1^(m e) * sum_chunks G[r][m] ),  |e| <= h.
+// wgt = 1 for the self-conjugate columns (m = 0, and m = N1/2 when N1 is even), 2 otherwise.
+__global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, const PairDesc* __restrict__ pairs, int pair0,
+                                                double* __restrict__ patches, int Nh, int Nhp, int N1, int S,
+                                                const cplx* __restrict__ root1)
+{
+    const PairDesc pr = pairs[pair0 + blockIdx.y];
+    const int h = pr.h, PH = 2 * h + 1;
+    const int r = blockIdx.x;
+    if (r >= PH) return;
+    const int tid = threadIdx.x;
+    __shared__ double red[2][4][17];
+    const cplx* g = Gp + pr.gp_off + (size_t)r * Nhp;
+    const bool even = (N1 & 1) == 0;
+    double* out = patches + pr.patch_off + (size_t)r * PH + h;
+    for (int e0 = 0; e0 == 0 || e0 < h; e0 += 16) {
+        double U[17], V[17];
+#pragma unroll
+        for (int t = 0; t < 17; ++t) { U[t] = 0.0; V[t] = 0.0; }
+        const int ne = min(16, h - e0);   // lags e0+1 .. e0+ne, plus e0 itself when e0 == 0
+        for (int m = tid; m < Nh; m += 256) {
+            double gx = 0.0, gy = 0.0;
+            for (int c = 0; c < S; ++c) {
+                const cplx v = g[(size_t)c * PH * Nhp + m];
+                gx += v.x; gy += v.y;
+            }
+            const double wgt = (m == 0 || (even && m == N1 / 2)) ? 1.0 : 2.0;
+            gx *= wgt; gy *= wgt;
+            if (e0 == 0) U[0] += gx;
+            int idx = (int)(((long long)m * e0) % N1);
+#pragma unroll
+            for (int t = 1; t <= 16; ++t) {
+                if (t <= ne) {
+                    idx += m; if (idx >= N1) idx -= N1;
+                    const cplx w = root1[idx];
+                    U[t] = fma(gx, w.x, U[t]);
+                    V[t] = fma(gy, w.y, V[t]);
+                }
+            }
+        }
+        // block reduction: wave shuffles then 4 partials through LDS
+#pragma unroll
+        for (int t = 0; t < 17; ++t) {
+            double u = U[t], v = V[t];
+            for (int off = 32; off > 0; off >>= 1) { u += __shfl_down(u, off); v += __shfl_down(v, off); }
+            if ((tid & 63) == 0) { red[0][tid >> 6][t] = u; red[1][tid >> 6][t] = v; }
+        }
+        __syncthreads();
+        if (tid < 17) {
+            const double u = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
+            const double v = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
+            if (tid == 0) { if (e0 == 0) out[0] = pr.scale * u; }
+            else if (tid <= ne) {
+                out[e0 + tid] = pr.scale * (u - v);
+                out[-(e0 + tid)] = pr.scale * (u + v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Delta: rowmom[l][q] = sum_n J[l][n] cy^q  (q <= 3), then delta[pq] = SCALE * sum_l cx^p rowmom[l][q]
+// (= PreDEL[pq][0][0], SFFTSubtract.py:706-729, evaluated in real space: only element [0][0] is ever read).
+__global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J, double* __restrict__ rowmom, int N0, int N1)
+{
+    const int l = blockIdx.x, tid = threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int n = tid; n < N1; n += 256) {
+        const double v = J[(size_t)l * N1 + n];
+        const double cy = (double(n) + 1.0) / N1;
+        acc[0] += v; acc[1] = fma(v, cy, acc[1]); acc[2] = fma(v, cy * cy, acc[2]); acc[3] = fma(v, cy * cy * cy, acc[3]);
+    }
+    __shared__ double red[4][4];
+    for (int q = 0; q < 4; ++q) {
+        double u = acc[q];
+        for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
+        if ((tid & 63) == 0) red[tid >> 6][q] = u;
+    }
+    __syncthreads();
+    if (tid < 4) rowmom[(size_t)l * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ void __launch_bounds__(256) delta_finish(const double* __restrict__ rowmom, double* __restrict__ delta, int N0,
+                                                    BkgArgs bk, double scale)
+{
+    const int pq = blockIdx.x, tid = threadIdx.x;
+    const int p = bk.p[pq], q = bk.q[pq];
+    double acc = 0.0;
+    for (int l = tid; l < N0; l += 256) acc = fma(ipow((double(l) + 1.0) / N0, p), rowmom[(size_t)l * 4 + q], acc);
+    __shared__ double red[4];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) delta[pq] = scale * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FillLS_{OMG,GAM,PSI,PHI,THE,DEL} + Remove_LSFStripes, one thread per matrix element
+// (SFFTConfigure.py:957-1293).  PSI is filled from GAM through Psi[p'q',ij](-rho) == Gam[ij,p'q'](rho), and
+// Omega pairs with i'j' > ij from Omega[ij,i'j'](-rho); both identities are exact.
+// out is [(n+1)][ld]: rows/cols < n hold LHMAT (after the optional index map), row n and column n hold RHb.
+// ------------------------------------------------------------------------------------------------
+struct FillArgs {
+    int Fij, Fpq, Fab, Fijab, L1, w0, w1;
+    int h_omg;            // 2w
+    int h_gam;            // w
+    int omg_off;          // patches offset of Omega pair 0; pair (i'<=i) index = i'*Fij - i'(i'-1)/2 + (i - i')
+    int gam_off;          // Gam pair (ij, pq) at gam_off + (ij*Fpq+pq)*PHg*PHg
+    int the_off;          // Theta pair ij at the_off + ij*PHg*PHg
+};
+
+__device__ __forceinline__ double omg_at(const double* P, const FillArgs& f, int i8, int ij, int r0, int r1)
+{
+    const int PH = 2 * f.h_omg + 1;
+    int lo = i8, hi = ij;
+    if (i8 > ij) { lo = ij; hi = i8; r0 = -r0; r1 = -r1; }
+    const int pidx = lo * f.Fij - (lo * (lo - 1)) / 2 + (hi - lo);
+    return P[f.omg_off + (size_t)pidx * PH * PH + (size_t)(r0 + f.h_omg) * PH + (r1 + f.h_omg)];
+}
+
+__device__ double sys_element(const double* P, const double* phi, const double* delta, const FillArgs& f, int R, int C, int NEQ)
+{
+    const int PHg = 2 * f.h_gam + 1;
+    if (C == NEQ) {   // right hand side
+        if (R < f.Fijab) {
+            const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
+            const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
+            const double* T = P + f.the_off + (size_t)i8 * PHg * PHg;
+            const double t0 = T[(size_t)f.h_gam * PHg + f.h_gam];
+            if (a8 == 0 && b8 == 0) return t0;
+            return T[(size_t)(a8 + f.h_gam) * PHg + (b8 + f.h_gam)] - t0;
+        }
+        return delta[R - f.Fijab];
+    }
+    if (R < f.Fijab && C < f.Fijab) {
+        const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
+        const int ij = C / f.Fab, ab = C - ij * f.Fab;
+        const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
+        const int a = ab / f.L1 - f.w0, b = ab % f.L1 - f.w1;
+        const bool c8 = (a8 == 0 && b8 == 0), c = (a == 0 && b == 0);
+        const double o00 = omg_at(P, f, i8, ij, 0, 0);
+        if (c8 && c) return o00;
+        if (c8) return omg_at(P, f, i8, ij, -a, -b) - o00;
+        if (c) return omg_at(P, f, i8, ij, a8, b8) - o00;
+        return -omg_at(P, f, i8, ij, a8, b8) - omg_at(P, f, i8, ij, -a, -b) + omg_at(P, f, i8, ij, a8 - a, b8 - b) + o00;
+    }
+    if (R < f.Fijab) {          // GAM block
+        const int pq = C - f.Fijab;
+        const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
+        const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
+        const double* G = P + f.gam_off + (size_t)(i8 * f.Fpq + pq) * PHg * PHg;
+        const double g0 = G[(size_t)f.h_gam * PHg + f.h_gam];
+        if (a8 == 0 && b8 == 0) return g0;
+        return G[(size_t)(a8 + f.h_gam) * PHg + (b8 + f.h_gam)] - g0;
+    }
+    if (C < f.Fijab) {          // PSI block = GAM transposed
+        const int pq = R - f.Fijab;
+        const int ij = C / f.Fab, ab = C - ij * f.Fab;
+        const int a = ab / f.L1 - f.w0, b = ab % f.L1 - f.w1;
+        const double* G = P + f.gam_off + (size_t)(ij * f.Fpq + pq) * PHg * PHg;
+        const double g0 = G[(size_t)f.h_gam * PHg + f.h_gam];
+        if (a == 0 && b == 0) return g0;
+        return G[(size_t)(a + f.h_gam) * PHg + (b + f.h_gam)] - g0;
+    }
+    return phi[(R - f.Fijab) * f.Fpq + (C - f.Fijab)];
+}
+
+__global__ void __launch_bounds__(256) fill_system(const double* __restrict__ P, const double* __restrict__ phi,
+                                                   const double* __restrict__ delta, FillArgs f, const int* __restrict__ idx,
+                                                   int n, int NEQ, double* __restrict__ out, int ld,
+                                                   double* __restrict__ rhs_vec)
+{
+    const int Cp = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int Rp = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (Rp > n || Cp > n) return;
+    if (Rp == n && Cp == n) { if (out) out[(size_t)n * ld + n] = 0.0; return; }
+    if (Rp == n) {   // rhs row (and optional separate vector)
+        const int C = idx ? idx[Cp] : Cp;
+        const double v = sys_element(P, phi, delta, f, C, NEQ, NEQ);
+        if (out) out[(size_t)n * ld + Cp] = v;
+        if (rhs_vec) rhs_vec[Cp] = v;
+        return;
+    }
+    if (!out) return;
+    const int R = idx ? idx[Rp] : Rp;
+    if (Cp == n) { out[(size_t)Rp * ld + n] = sys_element(P, phi, delta, f, R, NEQ, NEQ); return; }
+    const int C = idx ? idx[Cp] : Cp;
+    out[(size_t)Rp * ld + Cp] = sys_element(P, phi, delta, f, R, C, NEQ);
+}
+
+// plain LHMAT export for sfft_get_system (no border)
+__global__ void __launch_bounds__(256) fill_plain(const double* __restrict__ P, const double* __restrict__ phi,
+                                                  const double* __restrict__ delta, FillArgs f, int NEQ,
+                                                  double* __restrict__ LH, double* __restrict__ rhs)
+{
+    const int C = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int R = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (R >= NEQ || C >= NEQ) return;
+    if (LH) LH[(size_t)R * NEQ + C] = sys_element(P, phi, delta, f, R, C, NEQ);
+    if (rhs && C == 0) rhs[R] = sys_element(P, phi, delta, f, R, NEQ, NEQ);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense solve.  A is the bordered system [(n+1)][ld] (row n = right hand side), SPD in exact arithmetic
+// (it is a Gram matrix).  Right-looking blocked Cholesky on the lower triangle; the
+// border row rides along so that the forward substitution L y = b is a by-product (y = row n of L).
+// ------------------------------------------------------------------------------------------------
+#define CB 64
+// The diagonal block is read from Dsrc ([CB][CB], written by the previous step's trailing update) rather than
+// from A, because workgroup 0 overwrites A's diagonal block with the factor while the others may still start.
+__global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__ A, int ld, int nb, double* __restrict__ Dst)
+{
+    for (int e = threadIdx.x; e < nb * nb; e += 256) {
+        const int i = e / nb, j = e - i * nb;
+        Dst[i * CB + j] = A[(size_t)i * ld + j];
+    }
+}
+
+__global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
+                                                  int* __restrict__ status)
+{
+    __shared__ double D[CB][CB + 1];
+    __shared__ double Pn[CB][CB + 1];
+    const int tid = threadIdx.x;
+    const int nb = min(CB, n - k);
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int i = e / nb, j = e - i * nb;
+        D[i][j] = Dsrc[i * CB + j];
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        if (tid < nb && tid >= j) {
+            double sacc = D[tid][j];
+            for (int t = 0; t < j; ++t) sacc = fma(-D[tid][t], D[j][t], sacc);
+            D[tid][j] = sacc;
+        }
+        __syncthreads();
+        const double djj = D[j][j];
+        if (!(djj > 0.0) && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
+        const double rj = sqrt(djj);
+        __syncthreads();
+        if (tid < nb && tid >= j) D[tid][j] = (tid == j) ? rj : D[tid][j] / rj;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int i = e / nb, j = e - i * nb;
+            if (j <= i) A[(size_t)(k + i) * ld + k + j] = D[i][j];
+        }
+        return;
+    }
+    // rows below the diagonal block (border row n included): X L^T = A_panel
+    const int r0 = k + nb + (blockIdx.x - 1) * CB;
+    const int nr = min(CB, n + 1 - r0);
+    if (nr <= 0) return;
+    for (int e = tid; e < nr * nb; e += 256) {
+        const int i = e / nb, j = e - i * nb;
+        Pn[i][j] = A[(size_t)(r0 + i) * ld + k + j];
+    }
+    __syncthreads();
+    if (tid < nr) {
+        for (int j = 0; j < nb; ++j) {
+            double sacc = Pn[tid][j];
+            for (int t = 0; t < j; ++t) sacc = fma(-Pn[tid][t], D[j][t], sacc);
+            Pn[tid][j] = sacc / D[j][j];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nr * nb; e += 256) {
+        const int i = e / nb, j = e - i * nb;
+        A[(size_t)(r0 + i) * ld + k + j] = Pn[i][j];
+    }
+}
+
+// trailing update A[i][j] -= sum_t L[i][k+t] L[j][k+t] for i >= j >= k+nb (j < n), 64x64 tiles, 4x4 per thread
+__global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int ld, int n, int k, double* __restrict__ Dnext)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    __shared__ double Li[CB][CB + 1];
+    __shared__ double Lj[CB][CB + 1];
+    const int tid = threadIdx.x;
+    const int nb = min(CB, n - k);
+    const int r0 = k + nb;
+    const int i0 = r0 + ti * CB, j0 = r0 + tj * CB;
+    const int ni = min(CB, n + 1 - i0), nj = min(CB, n - j0);
+    if (ni <= 0 || nj <= 0) return;
+    for (int e = tid; e < CB * nb; e += 256) {
+        const int i = e / nb, t = e - i * nb;
+        Li[i][t] = (i < ni) ? A[(size_t)(i0 + i) * ld + k + t] : 0.0;
+        Lj[i][t] = (i < nj) ? A[(size_t)(j0 + i) * ld + k + t] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    double c[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[r][q] = 0.0;
+    for (int t = 0; t < nb; ++t) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = Li[ty + 16 * r][t];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = Lj[tx + 16 * q][t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[r][q] = fma(av[r], bv[q], c[r][q]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ty + 16 * r;
+        if (i >= ni) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = tx + 16 * q;
+            if (j >= nj) continue;
+            if (j0 + j > i0 + i) continue;   // lower triangle only
+            const double v = A[(size_t)(i0 + i) * ld + j0 + j] - c[r][q];
+            A[(size_t)(i0 + i) * ld + j0 + j] = v;
+            if (ti == 0 && tj == 0) Dnext[i * CB + j] = v;   // next step's diagonal block
+        }
+    }
+}
+
+// back substitution L^T x = y (y = border row n of the factor), then Extend_Solution scatter
+// (SFFTConfigure.py:1299-1311): solution[idx[i]] = x[i], other entries zero.  Single workgroup.
+__global__ void __launch_bounds__(1024) chol_backsolve(const double* __restrict__ A, int ld, int n, const int* __restrict__ idx,
+                                                        double* __restrict__ solution, int NEQ)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* yv = reinterpret_cast<double*>(smem_raw);        // [n]
+    double* D = yv + ((n + 1) & ~1);                         // [CB][CB+1]
+    const int tid = threadIdx.x;
+    for (int c = tid; c < n; c += 1024) yv[c] = A[(size_t)n * ld + c];
+    for (int c = tid; c < NEQ; c += 1024) solution[c] = 0.0;
+    __syncthreads();
+    const int nblk = (n + CB - 1) / CB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int kb = b * CB, nb = min(CB, n - kb);
+        for (int e = tid; e < nb * nb; e += 1024) {
+            const int i = e / nb, j = e - i * nb;
+            D[i * (CB + 1) + j] = A[(size_t)(kb + i) * ld + kb + j];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double yt = (tid < nb) ? yv[kb + tid] : 0.0;
+            for (int j = nb - 1; j >= 0; --j) {
+                const double xj = __shfl(yt, j) / D[j * (CB + 1) + j];
+                if (tid == j) yt = xj;
+                else if (tid < j) yt = fma(-D[j * (CB + 1) + tid], xj, yt);
+            }
+            if (tid < nb) yv[kb + tid] = yt;
+        }
+        __syncthreads();
+        for (int c = tid; c < kb; c += 1024) {
+            double sacc = 0.0;
+            for (int t = 0; t < nb; ++t) sacc = fma(A[(size_t)(kb + t) * ld + c], yv[kb + t], sacc);
+            yv[c] -= sacc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) solution[idx ? idx[i] : i] = yv[i];
+}
+
+// ---- LU with partial pivoting (fallback; matches the reference's getrf/gesv semantics) --------------------
+// A is [(n+1)][ld]; rows < n, columns <= n (column n = rhs).  Unblocked right-looking elimination.
+__global__ void __launch_bounds__(1024) lu_pivot(double* __restrict__ A, int ld, int n, int k, int* __restrict__ status)
+{
+    __shared__ double bestv[16];
+    __shared__ int besti[16];
+    __shared__ int piv;
+    const int tid = threadIdx.x;
+    double bv = -1.0; int bi = k;
+    for (int i = k + tid; i < n; i += 1024) {
+        const double v = fabs(A[(size_t)i * ld + k]);
+        if (v > bv) { bv = v; bi = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(bv, off); const int oi = __shfl_down(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
+        piv = bi;
+        if (!(bv > 0.0)) atomicOr(status, 2);
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k) {
+        for (int c = tid; c <= n; c += 1024) {
+            const double t = A[(size_t)k * ld + c];
+            A[(size_t)k * ld + c] = A[(size_t)p * ld + c];
+            A[(size_t)p * ld + c] = t;
+        }
+    }
+    __syncthreads();
+    const double d = A[(size_t)k * ld + k];
+    for (int i = k + 1 + tid; i < n; i += 1024) A[(size_t)i * ld + k] /= d;
+}
+
+__global__ void __launch_bounds__(256) lu_rank1(double* __restrict__ A, int ld, int n, int k)
+{
+    const int j = k + 1 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ib = k + 1 + blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (j > n) return;
+    const double u = A[(size_t)k * ld + j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ib + r;
+        if (i < n) A[(size_t)i * ld + j] = fma(-A[(size_t)i * ld + k], u, A[(size_t)i * ld + j]);
+    }
+}
+
+__global__ void __launch_bounds__(1024) lu_backsolve(const double* __restrict__ A, int ld, int n, const int* __restrict__ idx,
+                                                      double* __restrict__ solution, int NEQ)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* yv = reinterpret_cast<double*>(smem_raw);
+    const int tid = threadIdx.x;
+    for (int c = tid; c < n; c += 1024) yv[c] = A[(size_t)c * ld + n];
+    for (int c = tid; c < NEQ; c += 1024) solution[c] = 0.0;
+    __syncthreads();
+    for (int i = n - 1; i >= 0; --i) {
+        if (tid == 0) yv[i] = yv[i] / A[(size_t)i * ld + i];
+        __syncthreads();
+        const double xi = yv[i];
+        for (int c = tid; c < i; c += 1024) yv[c] = fma(-A[(size_t)c * ld + i], xi, yv[c]);
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) solution[idx ? idx[i] : i] = yv[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Subtraction: kernel transfer function tables + Construct_FDIFF (SFFTConfigure.py:737-809)
+//   Ctab[ij][a][m] = sum_b a_ijab W1^(m b);   Soff[ij] = sum_{ab != centre} a_ijab
+//   FD[l][m] = sum_ij FI_ij[l][m] * SCALE * ( sum_a W0^(l a) Ctab[ij][a][m] - Soff[ij] )
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kernel_ctab(const double* __restrict__ sol, cplx* __restrict__ Ctab, double* __restrict__ Soff,
+                                                   int Fij, int L0, int L1, int w1, int Nh, int Nhp, int N1,
+                                                   const cplx* __restrict__ root1)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int ija = blockIdx.y;                   // ij*L0 + a
+    const int Fab = L0 * L1;
+    if (m == 0 && (ija % L0) == 0) {              // one thread per ij
+        const int ij = ija / L0;
+        double sacc = 0.0;
+        const int cen = (L0 / 2) * L1 + w1;
+        for (int ab = 0; ab < Fab; ++ab) if (ab != cen) sacc += sol[ij * Fab + ab];
+        Soff[ij] = sacc;
+    }
+    if (m >= Nh) return;
+    const double* arow = sol + (size_t)ija * L1;  // ij*Fab + a*L1
+    double cxr = 0.0, cyi = 0.0;
+    for (int bb = 0; bb < L1; ++bb) {
+        const int b = bb - w1;
+        long long q = ((long long)m * b) % N1; if (q < 0) q += N1;
+        const cplx w = root1[q];
+        cxr = fma(arow[bb], w.x, cxr);
+        cyi = fma(arow[bb], w.y, cyi);
+    }
+    Ctab[(size_t)ija * Nhp + m] = make_double2(cxr, cyi);
+}
+
+#define CRL 8
+__global__ void __launch_bounds__(256) construct_fd(const cplx* __restrict__ FI, cplx* __restrict__ FD, const cplx* __restrict__ Ctab,
+                                                    const double* __restrict__ Soff, const cplx* __restrict__ root0,
+                                                    int N0, int Nh, int Nhp, int Fij, int L0, int w0, double scale)
+{
+    __shared__ cplx wl[CRL][72];
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x * 256 + tid;
+    const int lbase = blockIdx.y * CRL;
+    for (int e = tid; e < CRL * L0; e += 256) {
+        const int r = e / L0, aa = e - r * L0;
+        const int l = lbase + r;
+        long long q = ((long long)l * (aa - w0)) % N0; if (q < 0) q += N0;
+        wl[r][aa] = root0[q];
+    }
+    __syncthreads();
+    if (m >= Nh) return;
+    cplx acc[CRL];
+#pragma unroll
+    for (int r = 0; r < CRL; ++r) acc[r] = make_double2(0.0, 0.0);
+    const size_t plane_sz = (size_t)N0 * Nhp;
+    for (int ij = 0; ij < Fij; ++ij) {
+        cplx kk[CRL];
+#pragma unroll
+        for (int r = 0; r < CRL; ++r) kk[r] = make_double2(0.0, 0.0);
+        for (int aa = 0; aa < L0; ++aa) {
+            const cplx c = Ctab[((size_t)ij * L0 + aa) * Nhp + m];
+#pragma unroll
+            for (int r = 0; r < CRL; ++r) {
+                const cplx w = wl[r][aa];
+                kk[r].x = fma(w.x, c.x, fma(-w.y, c.y, kk[r].x));
+                kk[r].y = fma(w.x, c.y, fma(w.y, c.x, kk[r].y));
+            }
+        }
+        const double so = Soff[ij];
+#pragma unroll
+        for (int r = 0; r < CRL; ++r) {
+            const int l = lbase + r;
+            if (l < N0) {
+                const cplx fi = FI[(size_t)ij * plane_sz + (size_t)l * Nhp + m];
+                const cplx kf = make_double2(scale * (kk[r].x - so), scale * kk[r].y);
+                acc[r] = cadd(acc[r], cmul(fi, kf));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CRL; ++r) {
+        const int l = lbase + r;
+        if (l < N0) FD[(size_t)l * Nhp + m] = acc[r];
+    }
+}
+
+// debug: copy a padded half-spectrum plane to a dense [N0][Nh] array
+__global__ void copy_spectrum(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, int Nhp)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (m < Nh) dst[(size_t)l * Nh + m] = src[(size_t)l * Nhp + m];
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct AxisHost {
+    int N = 0, M = 0, logM = 0, blue = 0;
+    cplx *tw = nullptr, *chirp = nullptr, *bf = nullptr, *root = nullptr;
+    bool root_is_tw = false;
+};
+
+struct sfft_plan {
+    int dev = 0;
+    int N0 = 0, N1 = 0, w = 0, DK = 0, DB = 0, cpr = 0;
+    int L = 0, Fab = 0, Fij = 0, Fpq = 0, Fijab = 0, NEQ = 0, NEQfs = 0;
+    int Nh = 0, Nhp = 0;
+    double scale = 0.0;
+    AxisHost ax0, ax1;
+    int TC = 1, MS = 0;                 // column pass tiling
+    int nt_rows = 64, nt_cols = 64;
+    size_t lds_rows = 0, lds_cols = 0;
+    int ref_ij[10][2], ref_pq[10][2];
+    BkgArgs bk;
+    // device tables
+    int* d_idx = nullptr;               // [NEQfs] (only when cpr)
+    double* d_phi = nullptr;            // [Fpq*Fpq]
+    cplx* d_Xp = nullptr;               // [4][N0]
+    cplx* d_Yq = nullptr;               // [4][Nhp]
+    PairDesc* d_pairs = nullptr;
+    std::vector<PairDesc> pairs;
+    int n_omg = 0, n_gam = 0, n_the = 0;
+    int S = 1, rows_per_chunk = 0;
+    FillArgs fa;
+    // workspaces
+    cplx* d_spec = nullptr;             // [Fij+1][N0][Nhp]   (plane Fij: J in solve, FD in apply)
+    cplx* d_gp = nullptr;
+    double* d_patches = nullptr; size_t n_patches = 0;
+    double* d_A = nullptr; int ld = 0;
+    double* d_dbuf = nullptr;           // [2][CB][CB] diagonal blocks handed from chol_update to chol_panel
+    double* d_sol = nullptr;            // [NEQ] internal solution copy
+    cplx* d_ctab = nullptr; double* d_soff = nullptr;
+    double* d_rowmom = nullptr; double* d_delta = nullptr;
+    int* d_status = nullptr;
+    size_t ws_bytes = 0;
+    int last_solver = 0, force_lu = 0;
+    int timing = 0;
+    hipEvent_t ev[SFFT_ST_COUNT][2];
+    bool ev_valid[SFFT_ST_COUNT];
+    bool have_system = false;
+};
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <typename T>
+static int dev_alloc(sfft_plan* p, T** ptr, size_t count)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+    if (e != hipSuccess) return set_err(SFFT_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    *ptr = reinterpret_cast<T*>(q);
+    p->ws_bytes += count * sizeof(T);
+    return SFFT_OK;
+}
+
+static void host_fft_pow2(std::vector<long double>& re, std::vector<long double>& im)
+{
+    const int n = (int)re.size();
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    const long double PI = acosl(-1.0L);
+    for (int len = 2; len <= n; len <<= 1) {
+        for (int i = 0; i < n; i += len) {
+            for (int k = 0; k < len / 2; ++k) {
+                const long double ang = -2.0L * PI * k / len;
+                const long double wr = cosl(ang), wi = sinl(ang);
+                const int a = i + k, b = i + k + len / 2;
+                const long double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+        }
+    }
+}
+
+static int build_axis(sfft_plan* p, AxisHost& ax, int N)
+{
+    const long double PI = acosl(-1.0L);
+    ax.N = N;
+    if (is_pow2(N)) { ax.M = N; ax.blue = 0; }
+    else { int M = 1; while (M < 2 * N - 1) M <<= 1; ax.M = M; ax.blue = 1; }
+    ax.logM = ilog2(ax.M);
+    int rc;
+    std::vector<cplx> h(ax.M);
+    for (int k = 0; k < ax.M; ++k) {
+        const long double ang = -2.0L * PI * k / ax.M;
+        h[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    if ((rc = dev_alloc(p, &ax.tw, ax.M))) return rc;
+    HIPCHK(hipMemcpy(ax.tw, h.data(), ax.M * sizeof(cplx), hipMemcpyHostToDevice));
+    if (!ax.blue) { ax.root = ax.tw; ax.root_is_tw = true; return SFFT_OK; }
+    std::vector<cplx> r(N), c(N);
+    for (int k = 0; k < N; ++k) {
+        const long double ang = -2.0L * PI * k / N;
+        r[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+        const long long q = ((long long)k * k) % (2LL * N);
+        const long double a2 = -PI * q / N;
+        c[k] = make_double2((double)cosl(a2), (double)sinl(a2));
+    }
+    if ((rc = dev_alloc(p, &ax.root, N))) return rc;
+    HIPCHK(hipMemcpy(ax.root, r.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(p, &ax.chirp, N))) return rc;
+    HIPCHK(hipMemcpy(ax.chirp, c.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
+    std::vector<long double> fr(ax.M, 0.0L), fi(ax.M, 0.0L);
+    for (int k = 0; k < N; ++k) {
+        const long long q = ((long long)k * k) % (2LL * N);
+        const long double a2 = PI * q / N;      // conj(chirp)
+        fr[k] = cosl(a2); fi[k] = sinl(a2);
+        if (k > 0) { fr[ax.M - k] = fr[k]; fi[ax.M - k] = fi[k]; }
+    }
+    host_fft_pow2(fr, fi);
+    std::vector<cplx> bf(ax.M);
+    for (int k = 0; k < ax.M; ++k) bf[k] = make_double2((double)(fr[k] / ax.M), (double)(fi[k] / ax.M));
+    if ((rc = dev_alloc(p, &ax.bf, ax.M))) return rc;
+    HIPCHK(hipMemcpy(ax.bf, bf.data(), ax.M * sizeof(cplx), hipMemcpyHostToDevice));
+    return SFFT_OK;
+}
+
+static AxisDev axis_dev(const AxisHost& a)
+{
+    AxisDev d; d.N = a.N; d.M = a.M; d.logM = a.logM; d.blue = a.blue; d.tw = a.tw; d.chirp = a.chirp; d.bf = a.bf; d.root = a.root;
+    return d;
+}
+
+// DFT of the polynomial factor v[x] = ((x+1)/N)^e over one axis, e = 0..3, direct O(N^2) in extended precision
+static void poly_axis_dft(int N, int e, int nout, std::vector<cplx>& out)
+{
+    const long double PI = acosl(-1.0L);
+    std::vector<long double> v(N), cr(N), ci(N);
+    for (int x = 0; x < N; ++x) {
+        long double c = ((long double)x + 1.0L) / N, r = 1.0L;
+        for (int t = 0; t < e; ++t) r *= c;
+        v[x] = (long double)(double)r;   // the device computes the factor in double
+        const long double ang = -2.0L * PI * x / N;
+        cr[x] = cosl(ang); ci[x] = sinl(ang);
+    }
+    out.resize(nout);
+    for (int k = 0; k < nout; ++k) {
+        long double sr = 0.0L, si = 0.0L;
+        long long q = 0;
+        for (int x = 0; x < N; ++x) {
+            sr += v[x] * cr[q]; si += v[x] * ci[q];
+            q += k; if (q >= N) q -= N;
+        }
+        out[k] = make_double2((double)sr, (double)si);
+    }
+}
+
+static const size_t LDS_MAX_ELEMS = 8192;   // longest on-chip transform: 128 KiB of complex128 (160 KiB LDS per CU on gfx950)
+static const size_t LDS_COL_ELEMS = 9216;   // column tile budget (144 KiB): two padded 4096-point columns fit
+
+extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int DK, int DB, int cpr, int device)
+{
+    if (!out) return set_err(SFFT_ERR_INVALID_ARG, "plan pointer is NULL");
+    *out = nullptr;
+    if (DK < 0 || DK > 3) return set_err(SFFT_ERR_INVALID_ARG, "Input KerPolyOrder should be 0/1/2/3!");
+    if (DB < 0 || DB > 3) return set_err(SFFT_ERR_INVALID_ARG, "Input BGPolyOrder should be 0/1/2/3!");
+    if (N0 < 8 || N1 < 8) return set_err(SFFT_ERR_INVALID_ARG, "Input Image has dramatically small size!");
+    if (KerHW < 0 || KerHW > 32) return set_err(SFFT_ERR_INVALID_ARG, "KerHW must be in [0, 32]");
+    HIPCHK(hipSetDevice(device));
+    sfft_plan* p = new sfft_plan();
+    p->dev = device;
+    p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->cpr = cpr ? 1 : 0;
+    p->L = 2 * KerHW + 1; p->Fab = p->L * p->L;
+    p->Fij = (DK + 1) * (DK + 2) / 2; p->Fpq = (DB + 1) * (DB + 2) / 2;
+    p->Fijab = p->Fij * p->Fab; p->NEQ = p->Fijab + p->Fpq;
+    p->NEQfs = p->cpr ? p->NEQ - (p->Fij - 1) : p->NEQ;
+    p->scale = 1.0 / ((double)N0 * (double)N1);
+    p->Nh = N1 / 2 + 1;
+    p->Nhp = (p->Nh + 3) & ~3;
+    if (((p->Nhp / 4) & 1) == 0) p->Nhp += 4;     // row stride an odd multiple of 64 B: no power-of-two column stride
+    for (int s = 0; s < SFFT_ST_COUNT; ++s) p->ev_valid[s] = false;
+    int rc;
+#define PLAN_TRY(x) do { rc = (x); if (rc) { sfft_plan_destroy(p); return rc; } } while (0)
+#define PLAN_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { set_err(SFFT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); sfft_plan_destroy(p); return SFFT_ERR_HIP; } } while (0)
+    for (int s = 0; s < SFFT_ST_COUNT; ++s) { PLAN_HIP(hipEventCreate(&p->ev[s][0])); PLAN_HIP(hipEventCreate(&p->ev[s][1])); }
+    {
+        int n = 0;
+        for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { p->ref_ij[n][0] = i; p->ref_ij[n][1] = j; ++n; }
+        n = 0;
+        for (int a = 0; a <= DB; ++a) for (int b = 0; b <= DB - a; ++b) { p->ref_pq[n][0] = a; p->ref_pq[n][1] = b; ++n; }
+        p->bk.npq = p->Fpq;
+        for (int t = 0; t < p->Fpq; ++t) { p->bk.p[t] = p->ref_pq[t][0]; p->bk.q[t] = p->ref_pq[t][1]; }
+    }
+    PLAN_TRY(build_axis(p, p->ax0, N0));
+    PLAN_TRY(build_axis(p, p->ax1, N1));
+    if ((size_t)p->ax0.M > LDS_MAX_ELEMS || (size_t)p->ax1.M > LDS_MAX_ELEMS) {
+        sfft_plan_destroy(p);
+        return set_err(SFFT_ERR_UNSUPPORTED_SIZE,
+                       "image side not supported by this build: power-of-two sides up to 8192, other sides up to 4096");
+    }
+    // launch geometry of the FFT kernels
+    p->nt_rows = std::min(1024, std::max(64, p->ax1.M / 16));
+    p->lds_rows = (size_t)p->ax1.M * sizeof(cplx);
+    p->MS = p->ax0.M + 1;
+    p->TC = 1;
+    while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS) p->TC *= 2;
+    p->nt_cols = std::min(1024, std::max(64, p->TC * p->ax0.M / 16));
+    p->lds_cols = (size_t)p->TC * p->MS * sizeof(cplx);
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)chol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)lu_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if ((size_t)(p->NEQfs + 2) * 8 + (size_t)CB * (CB + 1) * 8 > 150 * 1024) {
+        sfft_plan_destroy(p);
+        return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "linear system too large for the on-chip back substitution of this build");
+    }
+
+    // index map of Remove_LSFStripes (SFFTSubtract.py:83-90)
+    if (p->cpr) {
+        std::vector<int> idx;
+        std::vector<char> forb(p->NEQ, 0);
+        const int ij00_first = KerHW * p->L + KerHW;
+        for (int ij = 1; ij < p->Fij; ++ij) forb[ij00_first + ij * p->Fab] = 1;
+        for (int r = 0; r < p->NEQ; ++r) if (!forb[r]) idx.push_back(r);
+        PLAN_TRY(dev_alloc(p, &p->d_idx, idx.size()));
+        PLAN_HIP(hipMemcpy(p->d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // PHI block: PrePHI[p'q',pq][0][0] = SCALE * sum_x T_p'q' T_pq  (SFFTSubtract.py:680-694), separable closed form
+    {
+        long double Sx[7], Sy[7];
+        for (int e = 0; e < 7; ++e) {
+            long double ax = 0.0L, ay = 0.0L;
+            for (int x = 0; x < N0; ++x) { long double c = ((long double)x + 1.0L) / N0, r = 1.0L; for (int t = 0; t < e; ++t) r *= c; ax += r; }
+            for (int y = 0; y < N1; ++y) { long double c = ((long double)y + 1.0L) / N1, r = 1.0L; for (int t = 0; t < e; ++t) r *= c; ay += r; }
+            Sx[e] = ax; Sy[e] = ay;
+        }
+        std::vector<double> phi(p->Fpq * p->Fpq);
+        for (int a = 0; a < p->Fpq; ++a) for (int b = 0; b < p->Fpq; ++b)
+            phi[a * p->Fpq + b] = (double)((long double)p->scale * Sx[p->ref_pq[a][0] + p->ref_pq[b][0]] * Sy[p->ref_pq[a][1] + p->ref_pq[b][1]]);
+        PLAN_TRY(dev_alloc(p, &p->d_phi, phi.size()));
+        PLAN_HIP(hipMemcpy(p->d_phi, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // rank-1 spectra of T_pq: FT_pq[l][m] = SCALE * Xp[l] * Yq[m]
+    {
+        PLAN_TRY(dev_alloc(p, &p->d_Xp, (size_t)4 * N0));
+        PLAN_TRY(dev_alloc(p, &p->d_Yq, (size_t)4 * p->Nhp));
+        PLAN_HIP(hipMemset(p->d_Yq, 0, (size_t)4 * p->Nhp * sizeof(cplx)));
+        for (int e = 0; e <= DB; ++e) {
+            std::vector<cplx> v;
+            poly_axis_dft(N0, e, N0, v);
+            PLAN_HIP(hipMemcpy(p->d_Xp + (size_t)e * N0, v.data(), (size_t)N0 * sizeof(cplx), hipMemcpyHostToDevice));
+            poly_axis_dft(N1, e, p->Nh, v);
+            PLAN_HIP(hipMemcpy(p->d_Yq + (size_t)e * p->Nhp, v.data(), (size_t)p->Nh * sizeof(cplx), hipMemcpyHostToDevice));
+        }
+    }
+    // Greek pair list: Omega (i'j' <= ij), Gamma (i'j', pq), Theta (i'j')
+    {
+        const int hO = 2 * KerHW, hG = KerHW;
+        const int PHo = 2 * hO + 1, PHg = 2 * hG + 1;
+        // row chunks: enough workgroups to fill 256 CUs several times over
+        int S = 1;
+        const int colblocks = (p->Nh + 63) / 64;
+        const int npairs_est = p->Fij * (p->Fij + 1) / 2 + p->Fij * p->Fpq + p->Fij;
+        while (S < 16 && (long long)colblocks * S * npairs_est < 8192 && N0 / (2 * S) >= 64) S *= 2;
+        p->S = S;
+        p->rows_per_chunk = (N0 + S - 1) / S;
+        int poff = 0; long long goff = 0;
+        p->fa.omg_off = 0;
+        for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) {
+            PairDesc d; d.a_plane = a; d.b_plane = b; d.bp = d.bq = 0; d.h = hO; d.patch_off = poff; d.gp_off = goff;
+            d.scale = p->scale * p->scale;      // PreOMG = SCALE * Re[SCALE * DFT]  (SFFTSubtract.py:233-240)
+            p->pairs.push_back(d); poff += PHo * PHo; goff += (long long)S * PHo * p->Nhp;
+        }
+        p->n_omg = (int)p->pairs.size();
+        p->fa.gam_off = poff;
+        for (int a = 0; a < p->Fij; ++a) for (int q = 0; q < p->Fpq; ++q) {
+            PairDesc d; d.a_plane = a; d.b_plane = -1; d.bp = p->ref_pq[q][0]; d.bq = p->ref_pq[q][1]; d.h = hG;
+            d.patch_off = poff; d.gp_off = goff; d.scale = p->scale;   // PreGAM = Re[SCALE * DFT]  (:262-268)
+            p->pairs.push_back(d); poff += PHg * PHg; goff += (long long)S * PHg * p->Nhp;
+        }
+        p->n_gam = p->Fij * p->Fpq;
+        p->fa.the_off = poff;
+        for (int a = 0; a < p->Fij; ++a) {
+            PairDesc d; d.a_plane = a; d.b_plane = p->Fij; d.bp = d.bq = 0; d.h = hG; d.patch_off = poff; d.gp_off = goff;
+            d.scale = p->scale;                 // PreTHE = Re[SCALE * DFT]  (:353-362)
+            p->pairs.push_back(d); poff += PHg * PHg; goff += (long long)S * PHg * p->Nhp;
+        }
+        p->n_the = p->Fij;
+        p->n_patches = poff;
+        PLAN_TRY(dev_alloc(p, &p->d_pairs, p->pairs.size()));
+        PLAN_HIP(hipMemcpy(p->d_pairs, p->pairs.data(), p->pairs.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+        PLAN_TRY(dev_alloc(p, &p->d_gp, (size_t)goff));
+        PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
+        p->fa.Fij = p->Fij; p->fa.Fpq = p->Fpq; p->fa.Fab = p->Fab; p->fa.Fijab = p->Fijab; p->fa.L1 = p->L;
+        p->fa.w0 = KerHW; p->fa.w1 = KerHW; p->fa.h_omg = hO; p->fa.h_gam = hG;
+    }
+    PLAN_TRY(dev_alloc(p, &p->d_spec, (size_t)(p->Fij + 1) * N0 * p->Nhp));
+    p->ld = (p->NEQfs + 1 + 3) & ~3;
+    PLAN_TRY(dev_alloc(p, &p->d_A, (size_t)(p->NEQfs + 1) * p->ld));
+    PLAN_TRY(dev_alloc(p, &p->d_dbuf, (size_t)2 * CB * CB));
+    PLAN_TRY(dev_alloc(p, &p->d_sol, (size_t)p->NEQ));
+    PLAN_TRY(dev_alloc(p, &p->d_ctab, (size_t)p->Fij * p->L * p->Nhp));
+    PLAN_TRY(dev_alloc(p, &p->d_soff, (size_t)p->Fij));
+    PLAN_TRY(dev_alloc(p, &p->d_rowmom, (size_t)N0 * 4));
+    PLAN_TRY(dev_alloc(p, &p->d_delta, (size_t)p->Fpq));
+    PLAN_TRY(dev_alloc(p, &p->d_status, (size_t)1));
+    PLAN_HIP(hipMemset(p->d_status, 0, sizeof(int)));
+    PLAN_HIP(hipDeviceSynchronize());
+#undef PLAN_TRY
+#undef PLAN_HIP
+    *out = p;
+    return SFFT_OK;
+}
+
+static void free_axis(AxisHost& a)
+{
+    if (a.tw) hipFree(a.tw);
+    if (a.root && !a.root_is_tw) hipFree(a.root);
+    if (a.chirp) hipFree(a.chirp);
+    if (a.bf) hipFree(a.bf);
+    a.tw = a.root = a.chirp = a.bf = nullptr;
+}
+
+extern "C" int sfft_plan_destroy(sfft_plan* p)
+{
+    if (!p) return SFFT_OK;
+    hipSetDevice(p->dev);
+    free_axis(p->ax0); free_axis(p->ax1);
+    void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_pairs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
+                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf};
+    for (void* q : ptrs) if (q) hipFree(q);
+    for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
+    delete p;
+    return SFFT_OK;
+}
+
+extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
+{
+    if (!p || !v) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    switch (field) {
+        case SFFT_Q_N0: *v = p->N0; break;
+        case SFFT_Q_N1: *v = p->N1; break;
+        case SFFT_Q_W0: case SFFT_Q_W1: *v = p->w; break;
+        case SFFT_Q_DK: *v = p->DK; break;
+        case SFFT_Q_DB: *v = p->DB; break;
+        case SFFT_Q_CONSTPHOTRATIO: *v = p->cpr; break;
+        case SFFT_Q_L0: case SFFT_Q_L1: *v = p->L; break;
+        case SFFT_Q_FAB: *v = p->Fab; break;
+        case SFFT_Q_FIJ: *v = p->Fij; break;
+        case SFFT_Q_FPQ: *v = p->Fpq; break;
+        case SFFT_Q_NEQ: *v = p->NEQ; break;
+        case SFFT_Q_FIJAB: *v = p->Fijab; break;
+        case SFFT_Q_NEQ_FSFREE: *v = p->NEQ - (p->Fij - 1); break;
+        case SFFT_Q_FOMG: *v = p->Fij * p->Fij; break;
+        case SFFT_Q_FGAM: case SFFT_Q_FPSI: *v = p->Fij * p->Fpq; break;
+        case SFFT_Q_FTHE: *v = p->Fij; break;
+        case SFFT_Q_FPHI: *v = p->Fpq * p->Fpq; break;
+        case SFFT_Q_FDEL: *v = p->Fpq; break;
+        case SFFT_Q_WORKSPACE_BYTES: *v = (long long)p->ws_bytes; break;
+        case SFFT_Q_LAST_SOLVER: *v = p->last_solver; break;
+        case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)p->pairs.size(); break;
+        default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
+    }
+    return SFFT_OK;
+}
+
+extern "C" int sfft_set_timing(sfft_plan* p, int enable) { if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan"); p->timing = enable; return SFFT_OK; }
+extern "C" int sfft_set_force_lu(sfft_plan* p, int enable) { if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan"); p->force_lu = enable; return SFFT_OK; }
+
+extern "C" int sfft_stage_ms(sfft_plan* p, int stage, float* ms)
+{
+    if (!p || !ms || stage < 0 || stage >= SFFT_ST_COUNT) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    *ms = 0.0f;
+    if (!p->ev_valid[stage]) return SFFT_OK;
+    HIPCHK(hipEventSynchronize(p->ev[stage][1]));
+    HIPCHK(hipEventElapsedTime(ms, p->ev[stage][0], p->ev[stage][1]));
+    return SFFT_OK;
+}
+
+struct StageTimer {
+    sfft_plan* p; int st; hipStream_t s;
+    StageTimer(sfft_plan* p_, int st_, hipStream_t s_) : p(p_), st(st_), s(s_) { if (p->timing) { hipEventRecord(p->ev[st][0], s); } }
+    ~StageTimer() { if (p->timing) { hipEventRecord(p->ev[st][1], s); p->ev_valid[st] = true; } }
+};
+
+#define LAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+// forward transforms of `nplanes` polynomial-weighted planes into spec planes [0, nplanes)
+static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, hipStream_t s)
+{
+    dim3 g1((p->N0 + 1) / 2, nplanes);
+    hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, p->d_spec, p->N0, p->N1, p->Nh, p->Nhp,
+                       axis_dev(p->ax1), p->scale);
+    LAUNCH_CHECK();
+    dim3 g2((p->Nh + p->TC - 1) / p->TC, nplanes);
+    hipLaunchKernelGGL(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, p->d_spec, p->N0, p->Nh, p->Nhp, p->TC, p->MS,
+                       axis_dev(p->ax0), 0, 1.0);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+template <int HB>
+static void launch_g1(sfft_plan* p, int pair0, int npairs, int h, hipStream_t s)
+{
+    dim3 g((p->Nh + 63) / 64, p->S, npairs);
+    for (int rb = 0; rb < h || rb == 0; rb += HB) {
+        hipLaunchKernelGGL(greek_g1<HB>, g, dim3(64), 0, s, p->d_spec, p->d_pairs, pair0, p->d_gp, p->N0, p->Nh, p->Nhp,
+                           p->rows_per_chunk, rb, p->ax0.root, p->d_Xp, p->d_Yq, p->scale);
+        if (h == 0) break;
+    }
+}
+
+static int greek_g1_group(sfft_plan* p, int pair0, int npairs, int h, hipStream_t s)
+{
+    if (npairs <= 0) return SFFT_OK;
+    if (h <= 4) launch_g1<4>(p, pair0, npairs, h, s);
+    else if (h <= 8) launch_g1<8>(p, pair0, npairs, h, s);
+    else if (h <= 16) launch_g1<16>(p, pair0, npairs, h, s);
+    else launch_g1<32>(p, pair0, npairs, h, s);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+static int run_fill(sfft_plan* p, hipStream_t s)
+{
+    const int n = p->NEQfs;
+    dim3 g((n + 1 + 15) / 16, (n + 1 + 15) / 16);
+    hipLaunchKernelGGL(fill_system, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->d_idx, n, p->NEQ,
+                       p->d_A, p->ld, (double*)nullptr);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
+{
+    const int n = p->NEQfs;
+    hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
+    int step = 0;
+    for (int k = 0; k < n; k += CB, ++step) {
+        const int nb = std::min(CB, n - k);
+        const int rows_below = n + 1 - (k + nb);
+        const int nblk = 1 + (rows_below + CB - 1) / CB;
+        double* Dcur = p->d_dbuf + (size_t)(step & 1) * CB * CB;
+        double* Dnxt = p->d_dbuf + (size_t)((step + 1) & 1) * CB * CB;
+        hipLaunchKernelGGL(chol_panel, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, k, Dcur, p->d_status);
+        const int ntile = (rows_below + CB - 1) / CB;
+        if (ntile > 0 && k + nb < n)
+            hipLaunchKernelGGL(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k, Dnxt);
+    }
+    LAUNCH_CHECK();
+    const size_t lds = (size_t)((n + 1) & ~1) * 8 + (size_t)CB * (CB + 1) * 8;
+    hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_idx, d_solution, p->NEQ);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+static int run_lu(sfft_plan* p, double* d_solution, hipStream_t s)
+{
+    const int n = p->NEQfs;
+    for (int k = 0; k < n; ++k) {
+        hipLaunchKernelGGL(lu_pivot, dim3(1), dim3(1024), 0, s, p->d_A, p->ld, n, k, p->d_status);
+        const int rem = n - k - 1;
+        if (rem > 0)
+            hipLaunchKernelGGL(lu_rank1, dim3((rem + 1 + 63) / 64, (rem + 15) / 16), dim3(256), 0, s, p->d_A, p->ld, n, k);
+    }
+    LAUNCH_CHECK();
+    const size_t lds = (size_t)(n + 2) * 8;
+    hipLaunchKernelGGL(lu_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_idx, d_solution, p->NEQ);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, double* d_solution, void* stream)
+{
+    if (!p || !d_I || !d_J || !d_solution) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    int rc;
+    {
+        StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
+        RowsArgs ra;
+        for (int k = 0; k < p->Fij; ++k) { ra.src[k] = d_I; ra.ei[k] = p->ref_ij[k][0]; ra.ej[k] = p->ref_ij[k][1]; }
+        ra.src[p->Fij] = d_J; ra.ei[p->Fij] = 0; ra.ej[p->Fij] = 0;
+        for (int k = p->Fij + 1; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
+        if ((rc = forward_planes(p, ra, p->Fij + 1, s))) return rc;
+        hipLaunchKernelGGL(row_moments, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1);
+        hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
+        LAUNCH_CHECK();
+    }
+    {
+        StageTimer t(p, SFFT_ST_GREEK_G1, s);
+        if ((rc = greek_g1_group(p, 0, p->n_omg, 2 * p->w, s))) return rc;
+        if ((rc = greek_g1_group(p, p->n_omg, p->n_gam + p->n_the, p->w, s))) return rc;
+    }
+    {
+        StageTimer t(p, SFFT_ST_GREEK_G2, s);
+        hipLaunchKernelGGL(greek_g2, dim3(4 * p->w + 1, p->n_omg), dim3(256), 0, s, p->d_gp, p->d_pairs, 0, p->d_patches,
+                           p->Nh, p->Nhp, p->N1, p->S, p->ax1.root);
+        hipLaunchKernelGGL(greek_g2, dim3(2 * p->w + 1, p->n_gam + p->n_the), dim3(256), 0, s, p->d_gp, p->d_pairs, p->n_omg,
+                           p->d_patches, p->Nh, p->Nhp, p->N1, p->S, p->ax1.root);
+        LAUNCH_CHECK();
+    }
+    p->have_system = true;
+    int status = 0;
+    bool use_lu = p->force_lu != 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        {
+            StageTimer t(p, SFFT_ST_FILL, s);
+            HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), s));
+            if ((rc = run_fill(p, s))) return rc;
+        }
+        {
+            StageTimer t(p, SFFT_ST_SOLVE, s);
+            if (use_lu) { if ((rc = run_lu(p, p->d_sol, s))) return rc; }
+            else { if ((rc = run_cholesky(p, p->d_sol, s))) return rc; }
+        }
+        HIPCHK(hipMemcpyAsync(&status, p->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        p->last_solver = use_lu ? 2 : 1;
+        if (status == 0) break;
+        if (use_lu) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+        use_lu = true;   // Cholesky met a non-positive pivot: redo with pivoted LU like the reference's gesv
+    }
+    HIPCHK(hipMemcpyAsync(d_solution, p->d_sol, (size_t)p->NEQ * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return SFFT_OK;
+}
+
+extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, const double* d_solution, double* d_diff,
+                          void* stream)
+{
+    if (!p || !d_I || !d_J || !d_solution || !d_diff) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    int rc;
+    {
+        StageTimer t(p, SFFT_ST_PRELIM_APPLY, s);
+        RowsArgs ra;
+        for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
+        for (int k = 0; k < p->Fij; ++k) { ra.src[k] = d_I; ra.ei[k] = p->ref_ij[k][0]; ra.ej[k] = p->ref_ij[k][1]; }
+        if ((rc = forward_planes(p, ra, p->Fij, s))) return rc;
+    }
+    cplx* FD = p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp;
+    {
+        StageTimer t(p, SFFT_ST_CONSTRUCT, s);
+        hipLaunchKernelGGL(kernel_ctab, dim3((p->Nh + 255) / 256, p->Fij * p->L), dim3(256), 0, s, d_solution, p->d_ctab, p->d_soff,
+                           p->Fij, p->L, p->L, p->w, p->Nh, p->Nhp, p->N1, p->ax1.root);
+        hipLaunchKernelGGL(construct_fd, dim3((p->Nh + 255) / 256, (p->N0 + CRL - 1) / CRL), dim3(256), 0, s, p->d_spec, FD, p->d_ctab,
+                           p->d_soff, p->ax0.root, p->N0, p->Nh, p->Nhp, p->Fij, p->L, p->w, p->scale);
+        LAUNCH_CHECK();
+    }
+    {
+        StageTimer t(p, SFFT_ST_INVERSE, s);
+        dim3 g2((p->Nh + p->TC - 1) / p->TC, 1);
+        hipLaunchKernelGGL(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, FD, p->N0, p->Nh, p->Nhp, p->TC, p->MS,
+                           axis_dev(p->ax0), 1, 1.0);
+        hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
+                           d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, axis_dev(p->ax1));
+        LAUNCH_CHECK();
+    }
+    return SFFT_OK;
+}
+
+extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J, const double* d_mI, const double* d_mJ,
+                             double* d_solution, double* d_diff, void* stream)
+{
+    int rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream);
+    if (rc) return rc;
+    rc = sfft_apply(p, d_I, d_J, d_solution, d_diff, stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return SFFT_OK;
+}
+
+extern "C" int sfft_get_system(sfft_plan* p, double* d_LHMAT, double* d_RHb, void* stream)
+{
+    if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan");
+    if (!p->have_system) return set_err(SFFT_ERR_INVALID_ARG, "no linear system yet: call sfft_solve first");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    dim3 g((p->NEQ + 15) / 16, (p->NEQ + 15) / 16);
+    hipLaunchKernelGGL(fill_plain, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->NEQ, d_LHMAT, d_RHb);
+    LAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(s));
+    return SFFT_OK;
+}
+
+extern "C" int sfft_dbg_forward_spectrum(sfft_plan* p, const double* d_I, int i, int j, double* d_spec_out, void* stream)
+{
+    if (!p || !d_I || !d_spec_out) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    if (i < 0 || j < 0 || i > 3 || j > 3) return set_err(SFFT_ERR_INVALID_ARG, "exponents must be in [0,3]");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    RowsArgs ra;
+    for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
+    ra.src[0] = d_I; ra.ei[0] = i; ra.ej[0] = j;
+    int rc = forward_planes(p, ra, 1, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(copy_spectrum, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec_out, p->N0, p->Nh, p->Nhp);
+    LAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(s));
+    return SFFT_OK;
+}

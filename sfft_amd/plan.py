@@ -1,0 +1,129 @@
+"""Plan handle: Python owner of one `sfft_plan` (the cacheable replacement of SingleSFFTConfigure's JIT step)."""
+import collections
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Plan:
+    def __init__(self, N0, N1, KerHW, DK, DB, ConstPhotRatio, device=0):
+        self._h = ctypes.c_void_p()
+        self.device = int(device)
+        self.key = (int(device), int(N0), int(N1), int(KerHW), int(DK), int(DB), bool(ConstPhotRatio))
+        rc = _lib.lib().sfft_plan_create(ctypes.byref(self._h), int(N0), int(N1), int(KerHW), int(DK), int(DB),
+                                         1 if ConstPhotRatio else 0, int(device))
+        _lib.check(rc)
+        self.N0, self.N1 = int(N0), int(N1)
+        self.NEQ = self.query("NEQ")
+        self.Fijab = self.query("Fijab")
+        self.Fpq = self.query("Fpq")
+
+    def query(self, name):
+        v = ctypes.c_longlong()
+        _lib.check(_lib.lib().sfft_plan_query(self._h, _lib.QUERY_FIELDS.index(name), ctypes.byref(v)))
+        return int(v.value)
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _dev(self):
+        return torch.device("cuda", self.device)
+
+    @staticmethod
+    def _stream_ptr(device):
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def _check_img(self, t, name):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+                and tuple(t.shape) == (self.N0, self.N1) and t.device.index == self.device):
+            raise Exception("MeLOn ERROR: %s must be a contiguous float64 tensor of shape [%d, %d] on cuda:%d"
+                            % (name, self.N0, self.N1, self.device))
+
+    # -- C ABI calls ---------------------------------------------------------------------------
+    def solve(self, I, J):
+        self._check_img(I, "PixA_I"); self._check_img(J, "PixA_J")
+        sol = torch.empty(self.NEQ, dtype=torch.float64, device=self._dev())
+        _lib.check(_lib.lib().sfft_solve(self._h, I.data_ptr(), J.data_ptr(), sol.data_ptr(), self._stream_ptr(self._dev())))
+        return sol
+
+    def apply(self, I, J, solution):
+        self._check_img(I, "PixA_I"); self._check_img(J, "PixA_J")
+        sol = solution.to(device=self._dev(), dtype=torch.float64).contiguous()
+        if sol.numel() != self.NEQ:
+            raise Exception("MeLOn ERROR: SFFTSolution must have %d entries" % self.NEQ)
+        diff = torch.empty((self.N0, self.N1), dtype=torch.float64, device=self._dev())
+        _lib.check(_lib.lib().sfft_apply(self._h, I.data_ptr(), J.data_ptr(), sol.data_ptr(), diff.data_ptr(),
+                                         self._stream_ptr(self._dev())))
+        return diff
+
+    def subtract(self, I, J, mI, mJ, out_solution=None, out_diff=None):
+        for t, n in ((I, "PixA_I"), (J, "PixA_J"), (mI, "PixA_mI"), (mJ, "PixA_mJ")):
+            self._check_img(t, n)
+        sol = out_solution if out_solution is not None else torch.empty(self.NEQ, dtype=torch.float64, device=self._dev())
+        diff = out_diff if out_diff is not None else torch.empty((self.N0, self.N1), dtype=torch.float64, device=self._dev())
+        _lib.check(_lib.lib().sfft_subtract(self._h, I.data_ptr(), J.data_ptr(), mI.data_ptr(), mJ.data_ptr(),
+                                            sol.data_ptr(), diff.data_ptr(), self._stream_ptr(self._dev())))
+        return sol, diff
+
+    def get_system(self):
+        LH = torch.empty((self.NEQ, self.NEQ), dtype=torch.float64, device=self._dev())
+        rhs = torch.empty(self.NEQ, dtype=torch.float64, device=self._dev())
+        _lib.check(_lib.lib().sfft_get_system(self._h, LH.data_ptr(), rhs.data_ptr(), self._stream_ptr(self._dev())))
+        return LH, rhs
+
+    def forward_spectrum(self, I, i, j):
+        self._check_img(I, "PixA_I")
+        out = torch.empty((self.N0, self.N1 // 2 + 1), dtype=torch.complex128, device=self._dev())
+        _lib.check(_lib.lib().sfft_dbg_forward_spectrum(self._h, I.data_ptr(), int(i), int(j), out.data_ptr(),
+                                                        self._stream_ptr(self._dev())))
+        return out
+
+    def set_timing(self, enable=True):
+        _lib.check(_lib.lib().sfft_set_timing(self._h, 1 if enable else 0))
+
+    def set_force_lu(self, enable=True):
+        _lib.check(_lib.lib().sfft_set_force_lu(self._h, 1 if enable else 0))
+
+    def stage_ms(self):
+        out = {}
+        for k, name in enumerate(_lib.STAGES):
+            v = ctypes.c_float()
+            _lib.check(_lib.lib().sfft_stage_ms(self._h, k, ctypes.byref(v)))
+            out[name] = float(v.value)
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().sfft_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_CACHE = collections.OrderedDict()
+_CACHE_MAX = 4
+
+
+def get_plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device=0):
+    """Plans are cached per (device, shape, KerHW, DK, DB, ConstPhotRatio): the reference re-JITs on every
+    SSC call (sfft/PureCupyCustomizedPacket.py:139-141, 7.6 s); here repeated packets reuse tables and workspaces."""
+    key = (int(device), int(N0), int(N1), int(KerHW), int(DK), int(DB), bool(ConstPhotRatio))
+    p = _CACHE.get(key)
+    if p is not None:
+        _CACHE.move_to_end(key)
+        return p
+    p = Plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device)
+    _CACHE[key] = p
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)      # freed when the last SFFTConfig holding it goes away
+    return p
+
+
+def clear_plan_cache():
+    while _CACHE:
+        _, old = _CACHE.popitem()
+        old.close()

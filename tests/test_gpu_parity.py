@@ -1,0 +1,315 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI against
+  (a) golden vectors produced by the reference's own Numpy backend (tests/golden/*.npz),
+  (b) the CPU oracle on seeded inputs at sizes it finishes in seconds,
+  (c) size-independent properties at the BASELINE size (4096 x 4096, KerHW 8, orders 2/2).
+
+Tolerances (fp64; SURVEY.md 8c, restated in DESIGN.md):
+  forward spectra            max |err| <= 1e-12 * max|spectrum|
+  LHMAT / RHb                element-wise <= 1e-11 * max|block|
+  apply-only DIFF            pixel RMS error <= 1e-10 * RMS(J)
+  end-to-end DIFF            pixel RMS error <= 1e-6  * RMS(DIFF_ref)
+"""
+import numpy as np
+import pytest
+
+from _golden import golden_names, load_golden, packet_roles, rms, rel_rms_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from sfft_amd import _lib
+    _lib.lib()          # fail loudly if the HIP library is missing
+    return torch.device("cuda", 0)
+
+
+def _to(dev, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+
+def _plan(meta, dev):
+    from sfft_amd.plan import get_plan
+    return get_plan(meta["N0"], meta["N1"], meta["KerHW"], meta["DK"], meta["DB"], bool(meta["CPR"]), dev.index)
+
+
+NAMES = golden_names()
+
+
+# ------------------------------------------------------------------------------------------------
+# (0) building blocks
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(8, 8), (64, 64), (128, 32), (48, 40), (45, 35), (100, 96), (512, 256), (300, 500),
+                                   (1024, 2048)])
+@pytest.mark.parametrize("ij", [(0, 0), (2, 1)])
+def test_forward_spectrum_matches_numpy_fft2(dev, shape, ij):
+    from sfft_amd.plan import get_plan
+    N0, N1 = shape
+    rng = np.random.default_rng(N0 * 7 + N1)
+    img = rng.normal(size=shape) * 50 + 10
+    plan = get_plan(N0, N1, 1, 0, 0, True, dev.index)
+    F = plan.forward_spectrum(_to(dev, img), ij[0], ij[1]).cpu().numpy()
+    cx = ((np.arange(N0) + 1.0) / N0)[:, None]
+    cy = ((np.arange(N1) + 1.0) / N1)[None, :]
+    ref = (np.fft.fft2(img * (cx ** ij[0] * cy ** ij[1])) / (N0 * N1))[:, :N1 // 2 + 1]
+    assert np.max(np.abs(F - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+# ------------------------------------------------------------------------------------------------
+# (a) golden vectors from the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", NAMES)
+def test_linear_system_matches_reference(dev, name):
+    g = load_golden(name)
+    plan = _plan(g["meta"], dev)
+    I, J, mI, mJ, _ = packet_roles(g)
+    plan.solve(_to(dev, mI), _to(dev, mJ))
+    LH, rhs = plan.get_system()
+    LH, rhs = LH.cpu().numpy(), rhs.cpu().numpy()
+    assert np.max(np.abs(LH - g["LHMAT"])) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
+    assert np.max(np.abs(rhs - g["RHb"])) <= 1e-11 * np.max(np.abs(g["RHb"]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_apply_given_reference_solution(dev, name):
+    g = load_golden(name)
+    plan = _plan(g["meta"], dev)
+    I, J, mI, mJ, nm = packet_roles(g)
+    DIFF = plan.apply(_to(dev, I), _to(dev, J), _to(dev, g["Solution"])).cpu().numpy()
+    if nm is not None:
+        DIFF[nm] = np.nan
+    if g["meta"]["ForceConv"] == "SCI":
+        DIFF = -DIFF
+    assert rms(DIFF - g["DIFF"]) <= 1e-10 * rms(J)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_pccp_end_to_end_matches_reference(dev, name):
+    from sfft_amd import PureCupy_Customized_Packet
+    g = load_golden(name)
+    m = g["meta"]
+    sol, diff = PureCupy_Customized_Packet.PCCP(_to(dev, g["REF"]), _to(dev, g["SCI"]), _to(dev, g["mREF"]),
+                                                _to(dev, g["mSCI"]), m["ForceConv"], m["KerHW"], KerPolyOrder=m["DK"],
+                                                BGPolyOrder=m["DB"], ConstPhotRatio=bool(m["CPR"]),
+                                                CUDA_DEVICE_4SUBTRACT=str(dev.index), VERBOSE_LEVEL=0)
+    DIFF = diff.cpu().numpy()
+    assert np.array_equal(np.isnan(DIFF), np.isnan(g["DIFF"]))
+    assert rel_rms_err(DIFF, g["DIFF"]) <= 1e-6
+    sol = sol.cpu().numpy()
+    assert sol.shape == g["Solution"].shape
+    if bool(m["CPR"]) and m["DK"] > 0:      # forbidden stripes stay exactly zero (Extend_Solution)
+        Fab = (2 * m["KerHW"] + 1) ** 2
+        cen = m["KerHW"] * (2 * m["KerHW"] + 1) + m["KerHW"]
+        Fij = (m["DK"] + 1) * (m["DK"] + 2) // 2
+        assert all(sol[ij * Fab + cen] == 0.0 for ij in range(1, Fij))
+
+
+@pytest.mark.parametrize("name", ["c64x64_w2_k2b2_cpr", "c45x35_w2_k1b2_free", "c96x80_w3_k2b2_cpr_nan"])
+def test_lu_fallback_matches_reference(dev, name):
+    g = load_golden(name)
+    plan = _plan(g["meta"], dev)
+    I, J, mI, mJ, nm = packet_roles(g)
+    plan.set_force_lu(True)
+    try:
+        sol, diff = plan.subtract(_to(dev, I), _to(dev, J), _to(dev, mI), _to(dev, mJ))
+        assert plan.query("LAST_SOLVER") == 2
+    finally:
+        plan.set_force_lu(False)
+    DIFF = diff.cpu().numpy()
+    if nm is not None:
+        DIFF[nm] = np.nan
+    if g["meta"]["ForceConv"] == "SCI":
+        DIFF = -DIFF
+    assert rel_rms_err(DIFF, g["DIFF"]) <= 1e-6
+
+
+def test_customized_packet_fits_files(dev, tmp_path):
+    """File-based operator (Customized_Packet.CP) on FITS written with the minimal FITS module."""
+    from sfft_amd import Customized_Packet
+    from sfft_amd.utils import minifits
+    g = load_golden("c64x32_w3_k2b0_cpr")
+    m = g["meta"]
+    paths = {}
+    for k in ("REF", "SCI", "mREF", "mSCI"):
+        paths[k] = str(tmp_path / (k + ".fits"))
+        minifits.writeto(paths[k], np.ascontiguousarray(g[k].T))     # FITS axes are transposed (CustomizedPacket.py:93)
+    fdiff, fsol = str(tmp_path / "diff.fits"), str(tmp_path / "sol.fits")
+    sol, diff = Customized_Packet.CP(paths["REF"], paths["SCI"], paths["mREF"], paths["mSCI"], m["ForceConv"], m["KerHW"],
+                                     FITS_DIFF=fdiff, FITS_Solution=fsol, KerPolyOrder=m["DK"], BGPolyOrder=m["DB"],
+                                     ConstPhotRatio=bool(m["CPR"]), BACKEND_4SUBTRACT="Cupy",
+                                     CUDA_DEVICE_4SUBTRACT=str(dev.index), VERBOSE_LEVEL=0)
+    assert isinstance(sol, np.ndarray) and isinstance(diff, np.ndarray)
+    assert rel_rms_err(diff, g["DIFF"]) <= 1e-6
+    d2, cards = minifits.getdata(fdiff)
+    h = minifits.header_dict(cards)
+    assert h["KERHW"] == m["KerHW"] and h["CONVD"] == m["ForceConv"] and h["KERORDER"] == m["DK"]
+    assert np.allclose(d2.T, diff, rtol=0, atol=0)
+    s2, c2 = minifits.getdata(fsol)
+    assert s2.shape == (1, sol.size) and np.array_equal(s2[0], sol)
+    assert minifits.header_dict(c2)["FIJAB"] == (2 * m["KerHW"] + 1) ** 2 * 6
+
+
+# ------------------------------------------------------------------------------------------------
+# (b) oracle on seeded inputs
+# ------------------------------------------------------------------------------------------------
+ORACLE_CASES = [
+    # N0, N1, w, DK, DB, CPR, ForceConv, mask
+    (256, 256, 4, 2, 2, True, "REF", True),
+    (384, 200, 3, 1, 3, True, "SCI", False),
+    (200, 333, 2, 3, 0, False, "REF", True),
+    (512, 512, 8, 2, 2, True, "REF", True),     # BASELINE kernel geometry at a size the oracle finishes in seconds
+    (128, 128, 0, 2, 1, True, "REF", False),    # degenerate 1x1 kernel
+    (64, 48, 9, 0, 0, True, "REF", False),      # 4w+1 > N1/2: lags wrap around the image
+]
+
+
+@pytest.mark.parametrize("case", ORACLE_CASES)
+def test_gss_matches_oracle(dev, case):
+    from oracle import sfft_oracle as O
+    from sfft_amd import PureCupy_Customized_Packet
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1, w, DK, DB, CPR, FC, mask = case
+    pair = make_pair(N0, N1, seed=N0 + 3 * N1 + w, mask=mask, sky=0.0 if mask else 100.0, bkg_scale=0.05 if mask else 1.0)
+    sol_o, diff_o = O.CP_arrays(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], FC, w, DK, DB, CPR, workers=8)
+    sol, diff = PureCupy_Customized_Packet.PCCP(*[_to(dev, pair[k]) for k in ("REF", "SCI", "mREF", "mSCI")], FC, w,
+                                                KerPolyOrder=DK, BGPolyOrder=DB, ConstPhotRatio=CPR,
+                                                CUDA_DEVICE_4SUBTRACT=str(dev.index), VERBOSE_LEVEL=0)
+    assert rel_rms_err(diff.cpu().numpy(), diff_o) <= 1e-6
+    # apply-only with the oracle's solution: tight gate
+    from sfft_amd.plan import get_plan
+    plan = get_plan(N0, N1, w, DK, DB, CPR, dev.index)
+    if FC == "REF":
+        I, J = pair["REF"], pair["SCI"]
+    else:
+        I, J = pair["SCI"], pair["REF"]
+    d2 = plan.apply(_to(dev, I), _to(dev, J), _to(dev, sol_o)).cpu().numpy()
+    p = O.SSC(N0, N1, w, DK, DB, CPR)
+    d2_o = O.ESS(I, J, p, SFFTSolution=sol_o, Subtract=True, workers=8)[1]
+    assert rms(d2 - d2_o) <= 1e-10 * rms(J)
+
+
+def test_contamination_mask_matches_oracle(dev):
+    from oracle import sfft_oracle as O
+    from sfft_amd.sfftcore import SingleSFFTConfigure, GeneralSFFTSubtract
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1, w = 128, 96, 3
+    pair = make_pair(N0, N1, seed=99, mask=False)
+    cm = np.zeros((N0, N1), dtype=bool)
+    cm[40:44, 50:53] = True
+    cm[100, 10] = True
+    cfg = SingleSFFTConfigure.SSC(N0, N1, w, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+    sol, diff, cmask = GeneralSFFTSubtract.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], cfg,
+                                               ContamMask_I=cm, VERBOSE_LEVEL=0)
+    p = O.SSC(N0, N1, w, 1, 1, True)
+    sol_o, diff_o, cmask_o = O.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], p, ContamMask_I=cm)
+    assert rel_rms_err(diff, diff_o) <= 1e-6
+    assert cmask.dtype == bool and cmask.shape == (N0, N1)
+    assert np.mean(cmask != cmask_o) <= 1e-3      # threshold crossings may differ on a handful of pixels
+    assert cmask[41, 51] and cmask[100, 10]
+
+
+def test_error_behaviour(dev):
+    from sfft_amd.sfftcore import SingleSFFTConfigure, ElementalSFFTSubtract, GeneralSFFTSubtract
+    from sfft_amd import PureCupy_Customized_Packet
+    cfg = SingleSFFTConfigure.SSC(64, 64, 2, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+    assert cfg[0]["NEQ"] == 3 * 25 + 3 and cfg[0]["NEQ_FSfree"] == 3 * 25 + 3 - 2 and cfg[0]["Fijab"] == 75
+    a = np.zeros((64, 32))
+    with pytest.raises(Exception, match=r"INCONSISTENT shape of input images I & J, \[64, 64\] required!"):
+        ElementalSFFTSubtract.ESS(a, a, cfg, VERBOSE_LEVEL=0)
+    b = np.zeros((64, 64))
+    with pytest.raises(Exception, match="Input images should have same size!"):
+        GeneralSFFTSubtract.GSS(b, b, a, a, cfg, VERBOSE_LEVEL=0)
+    bad = np.ones((64, 64)); bad[3, 3] = np.nan
+    t = lambda x: _to(dev, x)
+    with pytest.raises(AssertionError, match="masked reference image contains NaNs"):
+        PureCupy_Customized_Packet.PCCP(t(b), t(b), t(bad), t(b), "REF", 2, VERBOSE_LEVEL=0)
+    with pytest.raises(AssertionError):
+        PureCupy_Customized_Packet.PCCP(t(b), t(b), t(b), t(b), "BOTH", 2, VERBOSE_LEVEL=0)
+    with pytest.raises(AssertionError, match="dtype"):
+        PureCupy_Customized_Packet.PCCP(t(b).float(), t(b), t(b), t(b), "REF", 2, VERBOSE_LEVEL=0)
+    # exactly singular system (all-zero masked pair): Cholesky fails, LU meets a zero pivot -> LinAlgError like numpy
+    with pytest.raises(np.linalg.LinAlgError):
+        ElementalSFFTSubtract.ESS(b, b, cfg, VERBOSE_LEVEL=0)
+    # unsupported size is reported, not mis-computed
+    with pytest.raises(Exception, match="not supported by this build"):
+        SingleSFFTConfigure.SSC(6144, 64, 2, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+
+
+# ------------------------------------------------------------------------------------------------
+# (c) BASELINE size: properties that need no oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big(dev):
+    from sfft_amd.plan import get_plan
+    from sfft_amd.utils.synthetic import make_pair
+    N = 4096
+    pair = make_pair(N, N, seed=1234, mask=True, sky=0.0, bkg_scale=0.05)
+    plan = get_plan(N, N, 8, 2, 2, True, dev.index)
+    g = {k: _to(dev, v) for k, v in pair.items()}
+    return plan, pair, g
+
+
+def test_baseline_size_identity_kernel_and_background(dev, big):
+    """Solution = unit delta kernel (a_00,centre = N0*N1, SFFTSolutionReader.py:63-64) + background b_pq:
+    DIFF must equal J - I - sum_pq b_pq cx^p cy^q to rounding."""
+    plan, pair, g = big
+    N = plan.N0
+    sol = np.zeros(plan.NEQ)
+    Fab, cen = 17 * 17, 8 * 17 + 8
+    sol[cen] = float(N * N)
+    b = np.array([3.0, -1.0, 0.5, 2.0, 0.25, -0.75])        # (0,0),(0,1),(0,2),(1,0),(1,1),(2,0)
+    sol[plan.Fijab:] = b
+    D = plan.apply(g["REF"], g["SCI"], _to(dev, sol)).cpu().numpy()
+    cx = ((np.arange(N) + 1.0) / N)[:, None]
+    cy = ((np.arange(N) + 1.0) / N)[None, :]
+    B = b[0] + b[1] * cy + b[2] * cy ** 2 + b[3] * cx + b[4] * cx * cy + b[5] * cx ** 2
+    expect = pair["SCI"] - pair["REF"] - B
+    assert rms(D - expect) <= 1e-10 * rms(pair["SCI"])
+
+
+def test_baseline_size_shift_kernel_and_linearity(dev, big):
+    """A pure shift kernel (delta at (a,b)) reproduces a circularly shifted I; apply is linear in the solution."""
+    plan, pair, g = big
+    N = plan.N0
+    Fab, L, w = 289, 17, 8
+    a, b = 3, -5
+    sol1 = np.zeros(plan.NEQ)
+    ab = (a + w) * L + (b + w)
+    sol1[ab] = float(N * N)          # modified delta basis: K_ab = delta(a,b) - delta(0,0); centre coefficient = kernel sum
+    sol1[w * L + w] = float(N * N)
+    D1 = plan.apply(g["REF"], g["SCI"], _to(dev, sol1)).cpu().numpy()
+    shifted = np.roll(pair["REF"], shift=(a, b), axis=(0, 1))
+    assert rms(D1 - (pair["SCI"] - shifted)) <= 1e-10 * rms(pair["SCI"])
+    rng = np.random.default_rng(0)
+    sol2 = rng.normal(size=plan.NEQ) * 1e5
+    D2 = plan.apply(g["REF"], g["SCI"], _to(dev, sol2)).cpu().numpy()
+    D12 = plan.apply(g["REF"], g["SCI"], _to(dev, sol1 + sol2)).cpu().numpy()
+    J = pair["SCI"]
+    # J - D is linear in the solution
+    assert rms((J - D12) - ((J - D1) + (J - D2))) <= 1e-10 * rms(J - D2)
+
+
+def test_baseline_size_system_is_symmetric_gram_and_solution_is_stationary(dev, big):
+    plan, pair, g = big
+    sol, diff = plan.subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"])
+    assert plan.query("LAST_SOLVER") in (1, 2)
+    LH, rhs = plan.get_system()
+    asym = float((LH - LH.T).abs().max() / LH.abs().max())
+    assert asym <= 1e-13
+    # residual of the normal equations on the stripe-free system
+    idx = np.ones(plan.NEQ, dtype=bool)
+    idx[[ij * 289 + 8 * 17 + 8 for ij in range(1, 6)]] = False
+    idx_t = torch.from_numpy(np.where(idx)[0]).to(dev)
+    A = LH[idx_t][:, idx_t]
+    r = A @ sol[idx_t] - rhs[idx_t]
+    assert float(r.abs().max()) <= 1e-7 * float(rhs.abs().max())
+    d = diff.cpu().numpy()
+    assert np.isfinite(d).all()
+    # the fit removes the stars: residual RMS is of the order of the noise (3 in REF, blurred + 3 in SCI)
+    assert rms(d) < 8.0
+    # recovered photometric ratio: kernel sum = a_00,centre / (N0*N1) (SFFTSolutionReader.py:173-181) ~ 1.3
+    ksum = float(sol[8 * 17 + 8].item()) / (4096.0 * 4096.0)
+    assert abs(ksum - 1.3) < 0.02
