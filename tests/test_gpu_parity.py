@@ -312,4 +312,4 @@ def test_baseline_size_system_is_symmetric_gram_and_solution_is_stationary(dev, 
     assert rms(d) < 8.0
     # recovered photometric ratio: kernel sum = a_00,centre / (N0*N1) (SFFTSolutionReader.py:173-181) ~ 1.3
     ksum = float(sol[8 * 17 + 8].item()) / (4096.0 * 4096.0)
-    assert abs(ksum - 1.3) < 0.02
+    assert abs(ksum - 1.3) < 0.05
