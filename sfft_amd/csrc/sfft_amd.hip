@@ -6,7 +6,7 @@
 //   HadProd_* + Greek DFTs    SFFTConfigure.py:150-662, SFFTSubtract.py:226-383   greek_g1 + greek_g2 (pruned to the lags FillLS reads)
 //   FillLS_* + stripes        SFFTConfigure.py:198-711                  fill_system
 //   LSSolver                  SFFTSubtract.py:15-23, 398-403            blocked Cholesky (LU with partial pivoting as fallback)
-//   Extend_Solution           SFFTConfigure.py:716-732                  chol_backsolve / lu_backsolve scatter
+//   Extend_Solution           SFFTConfigure.py:716-732                  scatter_solution / lu_backsolve
 //   twiddles + Construct_FDIFF SFFTSubtract.py:433-447, SFFTConfigure.py:737-809   kernel_ctab + construct_fd
 //   inverse DFT               SFFTSubtract.py:460-461                   cols_c2c(inverse) + rows_c2r_diff
 //
@@ -301,30 +301,40 @@ __global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ F
 }
 
 // ------------------------------------------------------------------------------------------------
-// Greek stage 1: for every listed pair (A, B) and column m of the half spectrum
+// Greek stage 1: for every listed pass (A, B) and column m of the half spectrum
 //      G[r][m] = sum_l A[l][m] * conj(B[l][m]) * W0^(l r),   |r| <= h          (pruned column DFT of the
 // Hadamard product; only these lags are ever read by FillLS_*, SFFTConfigure.py:251-269, 364-371, 621-628).
-// r and -r share their four real products.  B is either a stored plane or the rank-1 spectrum of T_pq.
+// r and -r share their four real products.  B is a stored plane (Omega, Theta) or, for Gamma, the column
+// factor Xp[l] = DFT(cx^p)[l] of the rank-1 spectrum FT_pq = SCALE * Xp (x) Yq -- the row factor Yq[m] does not
+// depend on l and is applied in stage 2, so one pass serves every q.
+// One wave per 64 columns; RS waves of a workgroup split the lags; rows are loaded U at a time ahead of use.
 // ------------------------------------------------------------------------------------------------
-struct PairDesc {
-    int a_plane;     // plane index into spec
-    int b_plane;     // plane index, or -1: B = scale * Xp[l] * Yq[m]  (DFT of cx^p cy^q)
-    int bp, bq;      // exponents when b_plane < 0
-    int h;           // lag half width
-    int patch_off;   // offset (doubles) of this pair's [(2h+1)][(2h+1)] patch
-    long long gp_off;// offset (cplx) of this pair's [S][2h+1][Nhp] partial buffer
-    double scale;    // patch scale
+struct G1Pass {
+    int a_plane;      // plane index into spec
+    int b_plane;      // plane index, or -1: B[l][m] = Xp[bp][l]
+    int bp;
+    int h;            // lag half width
+    long long gp_off; // offset (cplx) of this pass's [S][2h+1][Nhp] partial buffer
 };
 
-template <int HB>
-__global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, const PairDesc* __restrict__ pairs, int pair0,
-                                               cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
-                                               int r_base, const cplx* __restrict__ root0,
-                                               const cplx* __restrict__ Xp, const cplx* __restrict__ Yq, double tscale)
+struct PatchJob {
+    int pass;         // G1 pass that produced G
+    int yq;           // -1, or q: G[r][m] is multiplied by conj(tscale * Yq[q][m])
+    int h;
+    int patch_off;    // offset (doubles) of this job's [(2h+1)][(2h+1)] patch
+    double scale;
+};
+
+template <int HBW, int RS>
+__global__ void __launch_bounds__(64 * RS) greek_g1(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+                                                    cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
+                                                    int r_base, const cplx* __restrict__ W0tab, int HM, const cplx* __restrict__ Xp)
 {
-    const int m = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x * 64 + lane;
     const int chunk = blockIdx.y;
-    const PairDesc pr = pairs[pair0 + blockIdx.z];
+    const G1Pass pr = passes[pass0 + blockIdx.z];
     const int h = pr.h;
     const int PH = 2 * h + 1;
     const int lb = chunk * rows_per_chunk;
@@ -333,81 +343,106 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
     const int mc = active ? m : 0;
     const size_t plane_sz = (size_t)N0 * Nhp;
     const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz + mc;
-    const bool rank1 = pr.b_plane < 0;
-    const cplx* __restrict__ B = rank1 ? A : spec + (size_t)pr.b_plane * plane_sz + mc;
-    cplx yq = make_double2(0.0, 0.0);
-    const cplx* __restrict__ xp = Xp;
-    if (rank1) {
-        const cplx t = Yq[(size_t)pr.bq * Nhp + mc];
-        yq = make_double2(t.x * tscale, t.y * tscale);
-        xp = Xp + (size_t)pr.bp * N0;
-    }
-    int nact = h - r_base;
-    if (nact > HB) nact = HB;
-    int idx[HB];
+    const bool colfac = pr.b_plane < 0;
+    const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz + mc;
+    const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
+    const int rfirst = r_base + 1 + wv * HBW;       // this wave's lags: rfirst .. rfirst + HBW - 1 (wave-uniform)
+    int nact = h - (rfirst - 1);
+    if (nact > HBW) nact = HBW;
+    if (nact < 0) nact = 0;
+    double S1[HBW], S2[HBW], S3[HBW], S4[HBW];
 #pragma unroll
-    for (int t = 0; t < HB; ++t) idx[t] = (int)(((long long)lb * (r_base + 1 + t)) % N0);
-    double S1[HB], S2[HB], S3[HB], S4[HB];
-#pragma unroll
-    for (int t = 0; t < HB; ++t) { S1[t] = S2[t] = S3[t] = S4[t] = 0.0; }
+    for (int t = 0; t < HBW; ++t) { S1[t] = S2[t] = S3[t] = S4[t] = 0.0; }
     double g0x = 0.0, g0y = 0.0;
-    for (int l = lb; l < le; ++l) {
+    const bool do_g0 = (r_base == 0 && wv == 0);
+    // W0tab[l][r-1] = W0^(l r), r = 1..HM: one contiguous, wave-uniform row of twiddles per image row (scalar loads)
+    const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + (rfirst - 1);
+    for (int l = lb; l < le; ++l, trow += HM) {
         const cplx av = A[(size_t)l * Nhp];
-        const cplx bv = rank1 ? cmul(xp[l], yq) : B[(size_t)l * Nhp];
+        const cplx bv = colfac ? xp[l] : B[(size_t)l * Nhp];
         const cplx H = cmulc(av, bv);
-        g0x += H.x; g0y += H.y;
+        if (do_g0) { g0x += H.x; g0y += H.y; }
 #pragma unroll
-        for (int t = 0; t < HB; ++t) {
+        for (int t = 0; t < HBW; ++t) {
             if (t < nact) {
-                const cplx w = root0[idx[t]];
+                const cplx w = trow[t];
                 S1[t] = fma(H.x, w.x, S1[t]);
                 S2[t] = fma(H.y, w.y, S2[t]);
                 S3[t] = fma(H.x, w.y, S3[t]);
                 S4[t] = fma(H.y, w.x, S4[t]);
-                int ni = idx[t] + (r_base + 1 + t);
-                if (ni >= N0) ni -= N0;
-                idx[t] = ni;
             }
         }
     }
     if (!active) return;
     cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp + m;
-    if (r_base == 0) g[(size_t)h * Nhp] = make_double2(g0x, g0y);
+    if (do_g0) g[(size_t)h * Nhp] = make_double2(g0x, g0y);
 #pragma unroll
-    for (int t = 0; t < HB; ++t) {
+    for (int t = 0; t < HBW; ++t) {
         if (t < nact) {
-            const int r = r_base + 1 + t;
+            const int r = rfirst + t;
             g[(size_t)(h + r) * Nhp] = make_double2(S1[t] - S2[t], S3[t] + S4[t]);
             g[(size_t)(h - r) * Nhp] = make_double2(S1[t] + S2[t], S4[t] - S3[t]);
         }
     }
 }
 
-// Greek stage 2: patch[r][e] = scale * sum_{m < Nh} wgt[m] * Re( W1^(m e) * sum_chunks G[r][m] ),  |e| <= h.
-// wgt = 1 for the self-conjugate columns (m = 0, and m = N1/2 when N1 is even), 2 otherwise.
-__global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, const PairDesc* __restrict__ pairs, int pair0,
-                                                double* __restrict__ patches, int Nh, int Nhp, int N1, int S,
-                                                const cplx* __restrict__ root1)
+// W0tab[l][r-1] = root0[(l r) mod N0]
+__global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
 {
-    const PairDesc pr = pairs[pair0 + blockIdx.y];
-    const int h = pr.h, PH = 2 * h + 1;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N0 * HM) return;
+    const int l = e / HM, r = e - l * HM + 1;
+    W0tab[e] = root0[(int)(((long long)l * r) % N0)];
+}
+
+// Gamma passes with p = 0: Xp = N0 * delta[l], so G[r][m] = N0 * A[0][m] for every lag (chunk 0; other chunks zero)
+__global__ void __launch_bounds__(256) greek_g1_row0(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+                                                     cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int S)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= Nh) return;
+    const G1Pass pr = passes[pass0 + blockIdx.y];
+    const int PH = 2 * pr.h + 1;
+    const cplx a0 = spec[(size_t)pr.a_plane * N0 * Nhp + m];
+    const cplx v = make_double2(a0.x * (double)N0, a0.y * (double)N0);
+    cplx* g = Gp + pr.gp_off + m;
+    for (int c = 0; c < S; ++c)
+        for (int r = 0; r < PH; ++r) g[((size_t)c * PH + r) * Nhp] = (c == 0) ? v : make_double2(0.0, 0.0);
+}
+
+// Greek stage 2: patch[r][e] = scale * sum_{m < Nh} wgt[m] * Re( W1^(m e) * y[m] * sum_chunks G[r][m] ),  |e| <= h.
+// wgt = 1 for the self-conjugate columns (m = 0, and m = N1/2 when N1 is even), 2 otherwise;
+// y[m] = conj(tscale * Yq[q][m]) for Gamma jobs, 1 otherwise.
+__global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, const G1Pass* __restrict__ passes,
+                                                const PatchJob* __restrict__ jobs, int job0,
+                                                double* __restrict__ patches, int Nh, int Nhp, int N1, int S,
+                                                const cplx* __restrict__ root1, const cplx* __restrict__ Yq, double tscale)
+{
+    const PatchJob jb = jobs[job0 + blockIdx.y];
+    const int h = jb.h, PH = 2 * h + 1;
     const int r = blockIdx.x;
     if (r >= PH) return;
     const int tid = threadIdx.x;
     __shared__ double red[2][4][17];
-    const cplx* g = Gp + pr.gp_off + (size_t)r * Nhp;
+    const cplx* g = Gp + passes[jb.pass].gp_off + (size_t)r * Nhp;
+    const cplx* yq = jb.yq >= 0 ? Yq + (size_t)jb.yq * Nhp : nullptr;
     const bool even = (N1 & 1) == 0;
-    double* out = patches + pr.patch_off + (size_t)r * PH + h;
+    double* out = patches + jb.patch_off + (size_t)r * PH + h;
     for (int e0 = 0; e0 == 0 || e0 < h; e0 += 16) {
         double U[17], V[17];
 #pragma unroll
         for (int t = 0; t < 17; ++t) { U[t] = 0.0; V[t] = 0.0; }
-        const int ne = min(16, h - e0);   // lags e0+1 .. e0+ne, plus e0 itself when e0 == 0
+        const int ne = min(16, h - e0);   // lags e0+1 .. e0+ne, plus lag 0 when e0 == 0
         for (int m = tid; m < Nh; m += 256) {
             double gx = 0.0, gy = 0.0;
             for (int c = 0; c < S; ++c) {
                 const cplx v = g[(size_t)c * PH * Nhp + m];
                 gx += v.x; gy += v.y;
+            }
+            if (yq) {
+                const cplx y = yq[m];
+                const cplx t = cmulc(make_double2(gx, gy), make_double2(y.x * tscale, y.y * tscale));
+                gx = t.x; gy = t.y;
             }
             const double wgt = (m == 0 || (even && m == N1 / 2)) ? 1.0 : 2.0;
             gx *= wgt; gy *= wgt;
@@ -423,7 +458,6 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
                 }
             }
         }
-        // block reduction: wave shuffles then 4 partials through LDS
 #pragma unroll
         for (int t = 0; t < 17; ++t) {
             double u = U[t], v = V[t];
@@ -434,10 +468,10 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
         if (tid < 17) {
             const double u = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
             const double v = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
-            if (tid == 0) { if (e0 == 0) out[0] = pr.scale * u; }
+            if (tid == 0) { if (e0 == 0) out[0] = jb.scale * u; }
             else if (tid <= ne) {
-                out[e0 + tid] = pr.scale * (u - v);
-                out[-(e0 + tid)] = pr.scale * (u + v);
+                out[e0 + tid] = jb.scale * (u - v);
+                out[-(e0 + tid)] = jb.scale * (u + v);
             }
         }
         __syncthreads();
@@ -591,6 +625,7 @@ __global__ void __launch_bounds__(256) fill_plain(const double* __restrict__ P, 
 // border row rides along so that the forward substitution L y = b is a by-product (y = row n of L).
 // ------------------------------------------------------------------------------------------------
 #define CB 64
+#define BACK_SLICES 64
 // The diagonal block is read from Dsrc ([CB][CB], written by the previous step's trailing update) rather than
 // from A, because workgroup 0 overwrites A's diagonal block with the factor while the others may still start.
 __global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__ A, int ld, int nb, double* __restrict__ Dst)
@@ -601,59 +636,92 @@ __global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__
     }
 }
 
+// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no IEEE division / sqrt sequences on the
+// critical path of the factorisation)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * fma(-0.5 * d, r * r, 1.5);
+    r = r * fma(-0.5 * d, r * r, 1.5);
+    return r;
+}
+
+// One panel step.  Every workgroup factors the 64x64 diagonal block (right-looking; thread (i, cg) owns elements
+// (i, cg + 4q), q < 16, in registers; one barrier per column; the column loop is fully unrolled so that all
+// register indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
+// b >= 1 then solve X L^T = A_panel for 64 rows below it (border row n included) the same way.
 __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
                                                   int* __restrict__ status)
 {
-    __shared__ double D[CB][CB + 1];
-    __shared__ double Pn[CB][CB + 1];
+    __shared__ double Dl[CB][CB + 1];     // factor of the diagonal block
+    __shared__ double rdiag[CB];          // 1 / L[j][j]
+    __shared__ double col[2][CB];         // published column (double buffered)
     const int tid = threadIdx.x;
     const int nb = min(CB, n - k);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        D[i][j] = Dsrc[i * CB + j];
+    const int i = tid >> 2, cg = tid & 3;
+    double a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int buf = j & 1, jq = j >> 2, jr = j & 3;
+        if (cg == jr) col[buf][i] = a[jq];
+        __syncthreads();
+        const double d = col[buf][j];
+        if (j < nb && !(d > 0.0) && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
+        const double rs = rsqrt_nr(d);
+        const double xi = col[buf][i];
+        const double nx = -xi * (rs * rs);
+        if (cg == jr) { a[jq] = xi * rs; if (i == j) rdiag[j] = rs; }            // final L[i][j] (rows < j: unused)
+#pragma unroll
+        for (int q = jq; q < 16; ++q) {                                         // columns c > j (upper part: harmless garbage)
+            const double cv = col[buf][cg + 4 * q];
+            if (q > jq) a[q] = fma(nx, cv, a[q]);
+            else a[q] = (cg > jr) ? fma(nx, cv, a[q]) : a[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        Dl[i][c] = (c <= i) ? a[q] : 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        if (tid < nb && tid >= j) {
-            double sacc = D[tid][j];
-            for (int t = 0; t < j; ++t) sacc = fma(-D[tid][t], D[j][t], sacc);
-            D[tid][j] = sacc;
-        }
-        __syncthreads();
-        const double djj = D[j][j];
-        if (!(djj > 0.0) && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
-        const double rj = sqrt(djj);
-        __syncthreads();
-        if (tid < nb && tid >= j) D[tid][j] = (tid == j) ? rj : D[tid][j] / rj;
-        __syncthreads();
-    }
     if (blockIdx.x == 0) {
         for (int e = tid; e < nb * nb; e += 256) {
-            const int i = e / nb, j = e - i * nb;
-            if (j <= i) A[(size_t)(k + i) * ld + k + j] = D[i][j];
+            const int r = e / nb, c = e - r * nb;
+            if (c <= r) A[(size_t)(k + r) * ld + k + c] = Dl[r][c];
         }
         return;
     }
-    // rows below the diagonal block (border row n included): X L^T = A_panel
     const int r0 = k + nb + (blockIdx.x - 1) * CB;
     const int nr = min(CB, n + 1 - r0);
     if (nr <= 0) return;
-    for (int e = tid; e < nr * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        Pn[i][j] = A[(size_t)(r0 + i) * ld + k + j];
+    double p[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
     }
-    __syncthreads();
-    if (tid < nr) {
-        for (int j = 0; j < nb; ++j) {
-            double sacc = Pn[tid][j];
-            for (int t = 0; t < j; ++t) sacc = fma(-Pn[tid][t], D[j][t], sacc);
-            Pn[tid][j] = sacc / D[j][j];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int buf = j & 1, jq = j >> 2, jr = j & 3;
+        if (cg == jr) { p[jq] *= rdiag[j]; col[buf][i] = p[jq]; }
+        __syncthreads();
+        const double xi = col[buf][i];
+#pragma unroll
+        for (int q = jq; q < 16; ++q) {
+            const double lv = Dl[cg + 4 * q][j];                                // zero for padded columns c >= nb
+            if (q > jq) p[q] = fma(-xi, lv, p[q]);
+            else p[q] = (cg > jr) ? fma(-xi, lv, p[q]) : p[q];
         }
     }
-    __syncthreads();
-    for (int e = tid; e < nr * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        A[(size_t)(r0 + i) * ld + k + j] = Pn[i][j];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        if (i < nr && c < nb) A[(size_t)(r0 + i) * ld + k + c] = p[q];
     }
 }
 
@@ -709,44 +777,70 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
     }
 }
 
-// back substitution L^T x = y (y = border row n of the factor), then Extend_Solution scatter
-// (SFFTConfigure.py:1299-1311): solution[idx[i]] = x[i], other entries zero.  Single workgroup.
-__global__ void __launch_bounds__(1024) chol_backsolve(const double* __restrict__ A, int ld, int n, const int* __restrict__ idx,
+// Back substitution L^T x = y (y = border row n of the factor), one launch per 64-row block, last block first.
+// x_b = L_bb^-T ( y_b - sum_{rows below} L[row][b]^T x[row] ).  The strip product is spread over gridDim.x
+// workgroups (64 rows each); the last one to arrive (device-scope counter) reduces the partials and solves the
+// 64x64 triangle.  xv is [n] (stripe-free ordering).
+__global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__ A, int ld, int n, int kb, double* __restrict__ xv,
+                                                      double* __restrict__ partial, unsigned int* __restrict__ counter)
+{
+    __shared__ double red[4][CB];
+    __shared__ double D[CB][CB + 1];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int nb = min(CB, n - kb);
+    const int c = tid & 63, rg = tid >> 6;
+    const int rows_below = n - (kb + nb);
+    const int nslice = gridDim.x;
+    if (rows_below > 0) {
+        const int per = (rows_below + nslice - 1) / nslice;
+        const int rb = kb + nb + blockIdx.x * per;
+        const int re = min(n, rb + per);
+        double acc = 0.0;
+        if (c < nb)
+            for (int row = rb + rg; row < re; row += 4) acc = fma(A[(size_t)row * ld + kb + c], xv[row], acc);
+        red[rg][c] = acc;
+        __syncthreads();
+        if (tid < CB) partial[(size_t)blockIdx.x * CB + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int prev = atomicAdd(counter, 1u);
+            is_last = (prev == (unsigned int)(nslice - 1));
+        }
+        __syncthreads();
+        if (!is_last) return;
+        __threadfence();
+    } else if (blockIdx.x != 0) return;
+    // last arriver: y_b - strip product, then the triangle
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e / nb, q = e - r * nb;
+        D[r][q] = A[(size_t)(kb + r) * ld + kb + q];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double yt = 0.0;
+        if (tid < nb) {
+            yt = A[(size_t)n * ld + kb + tid];
+            if (rows_below > 0)
+                for (int g = 0; g < nslice; ++g) yt -= __hip_atomic_load(&partial[(size_t)g * CB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int j = nb - 1; j >= 0; --j) {
+            const double xj = __shfl(yt, j) / D[j][j];
+            if (tid == j) yt = xj;
+            else if (tid < j) yt = fma(-D[j][tid], xj, yt);
+        }
+        if (tid < nb) xv[kb + tid] = yt;
+        if (tid == 0) *counter = 0u;
+    }
+}
+
+// Extend_Solution scatter (SFFTConfigure.py:1299-1311): solution[idx[i]] = x[i], forbidden entries stay zero
+__global__ void __launch_bounds__(256) scatter_solution(const double* __restrict__ xv, int n, const int* __restrict__ idx,
                                                         double* __restrict__ solution, int NEQ)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* yv = reinterpret_cast<double*>(smem_raw);        // [n]
-    double* D = yv + ((n + 1) & ~1);                         // [CB][CB+1]
-    const int tid = threadIdx.x;
-    for (int c = tid; c < n; c += 1024) yv[c] = A[(size_t)n * ld + c];
-    for (int c = tid; c < NEQ; c += 1024) solution[c] = 0.0;
-    __syncthreads();
-    const int nblk = (n + CB - 1) / CB;
-    for (int b = nblk - 1; b >= 0; --b) {
-        const int kb = b * CB, nb = min(CB, n - kb);
-        for (int e = tid; e < nb * nb; e += 1024) {
-            const int i = e / nb, j = e - i * nb;
-            D[i * (CB + 1) + j] = A[(size_t)(kb + i) * ld + kb + j];
-        }
-        __syncthreads();
-        if (tid < 64) {
-            double yt = (tid < nb) ? yv[kb + tid] : 0.0;
-            for (int j = nb - 1; j >= 0; --j) {
-                const double xj = __shfl(yt, j) / D[j * (CB + 1) + j];
-                if (tid == j) yt = xj;
-                else if (tid < j) yt = fma(-D[j * (CB + 1) + tid], xj, yt);
-            }
-            if (tid < nb) yv[kb + tid] = yt;
-        }
-        __syncthreads();
-        for (int c = tid; c < kb; c += 1024) {
-            double sacc = 0.0;
-            for (int t = 0; t < nb; ++t) sacc = fma(A[(size_t)(kb + t) * ld + c], yv[kb + t], sacc);
-            yv[c] -= sacc;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 1024) solution[idx ? idx[i] : i] = yv[i];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) solution[idx ? idx[t] : t] = xv[t];
 }
 
 // ---- LU with partial pivoting (fallback; matches the reference's getrf/gesv semantics) --------------------
@@ -936,9 +1030,12 @@ struct sfft_plan {
     double* d_phi = nullptr;            // [Fpq*Fpq]
     cplx* d_Xp = nullptr;               // [4][N0]
     cplx* d_Yq = nullptr;               // [4][Nhp]
-    PairDesc* d_pairs = nullptr;
-    std::vector<PairDesc> pairs;
-    int n_omg = 0, n_gam = 0, n_the = 0;
+    cplx* d_w0tab = nullptr; int hm = 1;   // [N0][hm] twiddle rows of the pruned column transform
+    G1Pass* d_passes = nullptr;
+    PatchJob* d_jobs = nullptr;
+    std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
+    std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
+    int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
     int S = 1, rows_per_chunk = 0;
     FillArgs fa;
     // workspaces
@@ -947,12 +1044,16 @@ struct sfft_plan {
     double* d_patches = nullptr; size_t n_patches = 0;
     double* d_A = nullptr; int ld = 0;
     double* d_dbuf = nullptr;           // [2][CB][CB] diagonal blocks handed from chol_update to chol_panel
+    double* d_xv = nullptr;             // [NEQfs] solution in stripe-free ordering
+    double* d_partial = nullptr;        // [BACK_SLICES][CB] strip-product partials of the back substitution
+    unsigned int* d_counter = nullptr;
     double* d_sol = nullptr;            // [NEQ] internal solution copy
     cplx* d_ctab = nullptr; double* d_soff = nullptr;
     double* d_rowmom = nullptr; double* d_delta = nullptr;
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
+    int g1_variant = 0;                 // tuning knob (env SFFT_G1_VARIANT): how the lags of a Greek pass are split over waves
     int timing = 0;
     hipEvent_t ev[SFFT_ST_COUNT][2];
     bool ev_valid[SFFT_ST_COUNT];
@@ -1084,6 +1185,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
     HIPCHK(hipSetDevice(device));
     sfft_plan* p = new sfft_plan();
     p->dev = device;
+    if (const char* ev = getenv("SFFT_G1_VARIANT")) p->g1_variant = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->cpr = cpr ? 1 : 0;
     p->L = 2 * KerHW + 1; p->Fab = p->L * p->L;
     p->Fij = (DK + 1) * (DK + 2) / 2; p->Fpq = (DB + 1) * (DB + 2) / 2;
@@ -1124,7 +1226,6 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PLAN_HIP(hipFuncSetAttribute((const void*)chol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)lu_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if ((size_t)(p->NEQfs + 2) * 8 + (size_t)CB * (CB + 1) * 8 > 150 * 1024) {
         sfft_plan_destroy(p);
@@ -1163,49 +1264,64 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         PLAN_HIP(hipMemset(p->d_Yq, 0, (size_t)4 * p->Nhp * sizeof(cplx)));
         for (int e = 0; e <= DB; ++e) {
             std::vector<cplx> v;
+            // e = 0: the factor is the constant 1, whose DFT is exactly N * delta (what an FFT of T_00 returns)
             poly_axis_dft(N0, e, N0, v);
+            if (e == 0) { for (int k = 0; k < N0; ++k) v[k] = make_double2(k == 0 ? (double)N0 : 0.0, 0.0); }
             PLAN_HIP(hipMemcpy(p->d_Xp + (size_t)e * N0, v.data(), (size_t)N0 * sizeof(cplx), hipMemcpyHostToDevice));
             poly_axis_dft(N1, e, p->Nh, v);
+            if (e == 0) { for (int k = 0; k < p->Nh; ++k) v[k] = make_double2(k == 0 ? (double)N1 : 0.0, 0.0); }
             PLAN_HIP(hipMemcpy(p->d_Yq + (size_t)e * p->Nhp, v.data(), (size_t)p->Nh * sizeof(cplx), hipMemcpyHostToDevice));
         }
     }
-    // Greek pair list: Omega (i'j' <= ij), Gamma (i'j', pq), Theta (i'j')
+    // Greek work lists.  G1 passes: Omega (i'j' <= ij), Theta (i'j'), Gamma column-factor passes (i'j', p).
+    // Patch jobs (one lag patch each): Omega, Gamma (i'j', pq), Theta.
     {
         const int hO = 2 * KerHW, hG = KerHW;
         const int PHo = 2 * hO + 1, PHg = 2 * hG + 1;
-        // row chunks: enough workgroups to fill 256 CUs several times over
         int S = 1;
         const int colblocks = (p->Nh + 63) / 64;
-        const int npairs_est = p->Fij * (p->Fij + 1) / 2 + p->Fij * p->Fpq + p->Fij;
-        while (S < 16 && (long long)colblocks * S * npairs_est < 8192 && N0 / (2 * S) >= 64) S *= 2;
+        const int npass_est = p->Fij * (p->Fij + 1) / 2 + p->Fij * DB + p->Fij;
+        while (S < 16 && (long long)colblocks * S * npass_est < 6144 && N0 / (2 * S) >= 64) S *= 2;
         p->S = S;
         p->rows_per_chunk = (N0 + S - 1) / S;
-        int poff = 0; long long goff = 0;
-        p->fa.omg_off = 0;
-        for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) {
-            PairDesc d; d.a_plane = a; d.b_plane = b; d.bp = d.bq = 0; d.h = hO; d.patch_off = poff; d.gp_off = goff;
-            d.scale = p->scale * p->scale;      // PreOMG = SCALE * Re[SCALE * DFT]  (SFFTSubtract.py:233-240)
-            p->pairs.push_back(d); poff += PHo * PHo; goff += (long long)S * PHo * p->Nhp;
-        }
-        p->n_omg = (int)p->pairs.size();
+        long long goff = 0;
+        auto add_pass = [&](int a, int b, int bp, int h) {
+            G1Pass d; d.a_plane = a; d.b_plane = b; d.bp = bp; d.h = h; d.gp_off = goff;
+            p->passes.push_back(d); goff += (long long)S * (2 * h + 1) * p->Nhp;
+            return (int)p->passes.size() - 1;
+        };
+        std::vector<int> omg_pass, the_pass, gam_pass(p->Fij * (DB + 1));
+        for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) omg_pass.push_back(add_pass(a, b, 0, hO));
+        p->n_omg = (int)omg_pass.size();
+        for (int a = 0; a < p->Fij; ++a) the_pass.push_back(add_pass(a, p->Fij, 0, hG));
+        p->n_the = p->Fij;
+        for (int a = 0; a < p->Fij; ++a) for (int e = 1; e <= DB; ++e) gam_pass[a * (DB + 1) + e] = add_pass(a, -1, e, hG);
+        p->n_gamp = p->Fij * DB;
+        for (int a = 0; a < p->Fij; ++a) gam_pass[a * (DB + 1) + 0] = add_pass(a, -1, 0, hG);
+        p->n_gam0 = p->Fij;
+        int poff = 0;
+        auto add_job = [&](int pass, int yq, int h, double scale) {
+            PatchJob j; j.pass = pass; j.yq = yq; j.h = h; j.patch_off = poff; j.scale = scale;
+            p->jobs.push_back(j); poff += (2 * h + 1) * (2 * h + 1);
+        };
+        p->fa.omg_off = poff;
+        for (int k = 0; k < p->n_omg; ++k) add_job(omg_pass[k], -1, hO, p->scale * p->scale);   // PreOMG = SCALE*Re[SCALE*DFT] (SFFTSubtract.py:233-240)
         p->fa.gam_off = poff;
-        for (int a = 0; a < p->Fij; ++a) for (int q = 0; q < p->Fpq; ++q) {
-            PairDesc d; d.a_plane = a; d.b_plane = -1; d.bp = p->ref_pq[q][0]; d.bq = p->ref_pq[q][1]; d.h = hG;
-            d.patch_off = poff; d.gp_off = goff; d.scale = p->scale;   // PreGAM = Re[SCALE * DFT]  (:262-268)
-            p->pairs.push_back(d); poff += PHg * PHg; goff += (long long)S * PHg * p->Nhp;
-        }
+        for (int a = 0; a < p->Fij; ++a) for (int q = 0; q < p->Fpq; ++q)
+            add_job(gam_pass[a * (DB + 1) + p->ref_pq[q][0]], p->ref_pq[q][1], hG, p->scale);     // PreGAM = Re[SCALE*DFT] (:262-268)
         p->n_gam = p->Fij * p->Fpq;
         p->fa.the_off = poff;
-        for (int a = 0; a < p->Fij; ++a) {
-            PairDesc d; d.a_plane = a; d.b_plane = p->Fij; d.bp = d.bq = 0; d.h = hG; d.patch_off = poff; d.gp_off = goff;
-            d.scale = p->scale;                 // PreTHE = Re[SCALE * DFT]  (:353-362)
-            p->pairs.push_back(d); poff += PHg * PHg; goff += (long long)S * PHg * p->Nhp;
-        }
-        p->n_the = p->Fij;
+        for (int a = 0; a < p->Fij; ++a) add_job(the_pass[a], -1, hG, p->scale);                  // PreTHE = Re[SCALE*DFT] (:353-362)
         p->n_patches = poff;
-        PLAN_TRY(dev_alloc(p, &p->d_pairs, p->pairs.size()));
-        PLAN_HIP(hipMemcpy(p->d_pairs, p->pairs.data(), p->pairs.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+        (void)PHo; (void)PHg;
+        PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
+        PLAN_HIP(hipMemcpy(p->d_passes, p->passes.data(), p->passes.size() * sizeof(G1Pass), hipMemcpyHostToDevice));
+        PLAN_TRY(dev_alloc(p, &p->d_jobs, p->jobs.size()));
+        PLAN_HIP(hipMemcpy(p->d_jobs, p->jobs.data(), p->jobs.size() * sizeof(PatchJob), hipMemcpyHostToDevice));
         PLAN_TRY(dev_alloc(p, &p->d_gp, (size_t)goff));
+        p->hm = std::max(1, hO);
+        PLAN_TRY(dev_alloc(p, &p->d_w0tab, (size_t)N0 * p->hm));
+        hipLaunchKernelGGL(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
         p->fa.Fij = p->Fij; p->fa.Fpq = p->Fpq; p->fa.Fab = p->Fab; p->fa.Fijab = p->Fijab; p->fa.L1 = p->L;
         p->fa.w0 = KerHW; p->fa.w1 = KerHW; p->fa.h_omg = hO; p->fa.h_gam = hG;
@@ -1214,6 +1330,10 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
     p->ld = (p->NEQfs + 1 + 3) & ~3;
     PLAN_TRY(dev_alloc(p, &p->d_A, (size_t)(p->NEQfs + 1) * p->ld));
     PLAN_TRY(dev_alloc(p, &p->d_dbuf, (size_t)2 * CB * CB));
+    PLAN_TRY(dev_alloc(p, &p->d_xv, (size_t)p->NEQfs));
+    PLAN_TRY(dev_alloc(p, &p->d_partial, (size_t)BACK_SLICES * CB));
+    PLAN_TRY(dev_alloc(p, &p->d_counter, (size_t)1));
+    PLAN_HIP(hipMemset(p->d_counter, 0, sizeof(unsigned int)));
     PLAN_TRY(dev_alloc(p, &p->d_sol, (size_t)p->NEQ));
     PLAN_TRY(dev_alloc(p, &p->d_ctab, (size_t)p->Fij * p->L * p->Nhp));
     PLAN_TRY(dev_alloc(p, &p->d_soff, (size_t)p->Fij));
@@ -1242,8 +1362,8 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     if (!p) return SFFT_OK;
     hipSetDevice(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
-    void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_pairs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf};
+    void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
+                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     delete p;
@@ -1274,7 +1394,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_FDEL: *v = p->Fpq; break;
         case SFFT_Q_WORKSPACE_BYTES: *v = (long long)p->ws_bytes; break;
         case SFFT_Q_LAST_SOLVER: *v = p->last_solver; break;
-        case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)p->pairs.size(); break;
+        case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_the + p->n_gamp); break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
     return SFFT_OK;
@@ -1315,24 +1435,31 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, hipStre
     return SFFT_OK;
 }
 
-template <int HB>
-static void launch_g1(sfft_plan* p, int pair0, int npairs, int h, hipStream_t s)
+template <int HBW, int RS>
+static void launch_g1(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
 {
-    dim3 g((p->Nh + 63) / 64, p->S, npairs);
-    for (int rb = 0; rb < h || rb == 0; rb += HB) {
-        hipLaunchKernelGGL(greek_g1<HB>, g, dim3(64), 0, s, p->d_spec, p->d_pairs, pair0, p->d_gp, p->N0, p->Nh, p->Nhp,
-                           p->rows_per_chunk, rb, p->ax0.root, p->d_Xp, p->d_Yq, p->scale);
+    dim3 g((p->Nh + 63) / 64, p->S, npass);
+    const int per_launch = HBW * RS;
+    for (int rb = 0; rb < h || rb == 0; rb += per_launch) {
+        hipLaunchKernelGGL((greek_g1<HBW, RS>), g, dim3(64 * RS), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
+                           p->Nhp, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp);
         if (h == 0) break;
     }
 }
 
-static int greek_g1_group(sfft_plan* p, int pair0, int npairs, int h, hipStream_t s)
+static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
 {
-    if (npairs <= 0) return SFFT_OK;
-    if (h <= 4) launch_g1<4>(p, pair0, npairs, h, s);
-    else if (h <= 8) launch_g1<8>(p, pair0, npairs, h, s);
-    else if (h <= 16) launch_g1<16>(p, pair0, npairs, h, s);
-    else launch_g1<32>(p, pair0, npairs, h, s);
+    if (npass <= 0) return SFFT_OK;
+    if (h <= 4) launch_g1<4, 1>(p, pass0, npass, h, s);
+    else if (h <= 8) launch_g1<8, 1>(p, pass0, npass, h, s);
+    else if (h <= 16) {
+        if (p->g1_variant == 1) launch_g1<8, 2>(p, pass0, npass, h, s);
+        else if (p->g1_variant == 2) launch_g1<4, 4>(p, pass0, npass, h, s);
+        else launch_g1<16, 1>(p, pass0, npass, h, s);
+    } else {
+        if (p->g1_variant == 2) launch_g1<4, 4>(p, pass0, npass, h, s);
+        else launch_g1<8, 2>(p, pass0, npass, h, s);
+    }
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -1364,8 +1491,15 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
             hipLaunchKernelGGL(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k, Dnxt);
     }
     LAUNCH_CHECK();
-    const size_t lds = (size_t)((n + 1) & ~1) * 8 + (size_t)CB * (CB + 1) * 8;
-    hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_idx, d_solution, p->NEQ);
+    HIPCHK(hipMemsetAsync(d_solution, 0, (size_t)p->NEQ * sizeof(double), s));
+    const int nblk = (n + CB - 1) / CB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int kb = b * CB, nb = std::min(CB, n - kb);
+        const int rows_below = n - (kb + nb);
+        const int nslice = rows_below > 0 ? std::min(BACK_SLICES, (rows_below + CB - 1) / CB) : 1;
+        hipLaunchKernelGGL(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter);
+    }
+    hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -1406,14 +1540,19 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     {
         StageTimer t(p, SFFT_ST_GREEK_G1, s);
         if ((rc = greek_g1_group(p, 0, p->n_omg, 2 * p->w, s))) return rc;
-        if ((rc = greek_g1_group(p, p->n_omg, p->n_gam + p->n_the, p->w, s))) return rc;
+        if ((rc = greek_g1_group(p, p->n_omg, p->n_the + p->n_gamp, p->w, s))) return rc;
+        if (p->n_gam0 > 0) {
+            hipLaunchKernelGGL(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_gam0), dim3(256), 0, s, p->d_spec, p->d_passes,
+                               p->n_omg + p->n_the + p->n_gamp, p->d_gp, p->N0, p->Nh, p->Nhp, p->S);
+            LAUNCH_CHECK();
+        }
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G2, s);
-        hipLaunchKernelGGL(greek_g2, dim3(4 * p->w + 1, p->n_omg), dim3(256), 0, s, p->d_gp, p->d_pairs, 0, p->d_patches,
-                           p->Nh, p->Nhp, p->N1, p->S, p->ax1.root);
-        hipLaunchKernelGGL(greek_g2, dim3(2 * p->w + 1, p->n_gam + p->n_the), dim3(256), 0, s, p->d_gp, p->d_pairs, p->n_omg,
-                           p->d_patches, p->Nh, p->Nhp, p->N1, p->S, p->ax1.root);
+        hipLaunchKernelGGL(greek_g2, dim3(4 * p->w + 1, p->n_omg), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
+                           p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
+        hipLaunchKernelGGL(greek_g2, dim3(2 * p->w + 1, p->n_gam + p->n_the), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs,
+                           p->n_omg, p->d_patches, p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
         LAUNCH_CHECK();
     }
     p->have_system = true;
