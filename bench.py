@@ -5,11 +5,14 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one GSS-equivalent pass (solve on the masked pair + apply to the full pair, the body of
-sfft.PureCupy_Customized_Packet.PCCP) over one synthetic 4096 x 4096 image pair, KerHW 8, KerPolyOrder 2,
-BGPolyOrder 2, ConstPhotRatio, fp64 -- BASELINE.json configs[1].  Inputs are resident in HBM when the timed
-region starts; the plan (tables + workspaces) is created before it.  With N ranks every rank runs its own pair
-per step (weak scaling, independent pairs, no data-path collective); the only collective is the gather of
-per-pair records at the end (sfft_amd/sharding.py).
+sfft.PureCupy_Customized_Packet.PCCP) over one batch of synthetic 4096 x 4096 image pairs, KerHW 8,
+KerPolyOrder 2, BGPolyOrder 2, ConstPhotRatio, fp64 -- BASELINE.json configs[1].  The batch is `--streams` pairs
+per GPU (default 3), each on its own plan, HIP stream and host thread: the dense solve of one pair is latency
+bound and leaves most CUs idle, so independent pairs are pipelined on one GPU exactly as the reference's
+multi-task packet pipelines them with one thread per device queue.  Inputs are resident in HBM when the timed
+region starts; plans (tables + workspaces) are created before it.  With N ranks every rank runs its own batch
+per step (weak scaling, no data-path collective); the only collective is the gather of per-pair records at the
+end (sfft_amd/sharding.py).
 
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
   roofline     -- the dominant stage (by HIP-event time measured inside the timed region, on the stream the
@@ -43,9 +46,11 @@ def alg_bytes(N0, N1, w, DK, DB):
     spec = c * N0 * Nh                                  # one half-spectrum plane
     fwd_plane = r * P + spec + 2 * spec                 # rows: read image, write spectrum; columns: read + write
     n_omg, n_gam, n_the = Fij * (Fij + 1) // 2, Fij * Fpq, Fij
+    n_gamp = Fij * DB                                   # dense Gamma column-factor passes (p >= 1); they read A only
     out = {
         "prelim_solve": (Fij + 1) * fwd_plane + r * P,  # + row moments of J
-        "greek_g1": (n_omg + n_the) * 2 * spec + n_gam * spec,   # operands A and B (B generated on the fly for Gamma)
+        "greek_g1": n_omg * 2 * spec,                   # Omega passes: operands A and B, every pass streams both
+        "greek_g1b": n_the * 2 * spec + n_gamp * spec,  # Theta passes (A, FJ) + Gamma passes (A; B is a column factor)
         "prelim_apply": Fij * fwd_plane,
         "construct": Fij * spec + spec,
         "inverse": 2 * spec + spec + r * P + r * P,      # columns r+w, rows read, J read, DIFF write
@@ -85,9 +90,12 @@ def main():
     ap.add_argument("--kerhw", type=int, default=8)
     ap.add_argument("--dk", type=int, default=2)
     ap.add_argument("--db", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent pairs in flight per GPU (one plan + stream + host thread each); a step = this many pairs")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="side of the CPU-baseline sample image (0 = skip)")
     args = ap.parse_args()
 
+    import threading
     import torch
     import torch.distributed as dist
     from sfft_amd.plan import get_plan
@@ -105,23 +113,38 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    N = args.size
+    N, S = args.size, max(1, args.streams)
     t0 = time.perf_counter()
-    plan = get_plan(N, N, args.kerhw, args.dk, args.db, True, local_rank)
+    plans = [get_plan(N, N, args.kerhw, args.dk, args.db, True, local_rank, slot=i) for i in range(S)]
     torch.cuda.synchronize(dev)
-    plan_s = time.perf_counter() - t0
-    pair = make_pair(N, N, seed=1234 + rank, mask=True, sky=0.0, bkg_scale=0.05)
-    g = {k: torch.from_numpy(v).to(dev) for k, v in pair.items()}
-    sol = torch.empty(plan.NEQ, dtype=torch.float64, device=dev)
-    diff = torch.empty((N, N), dtype=torch.float64, device=dev)
-
-    def step():
-        plan.subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"], out_solution=sol, out_diff=diff)
-
-    for _ in range(args.warmup):
-        step()
-    plan.set_timing(True)
+    plan_s = (time.perf_counter() - t0) / S
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    # one synthetic pair per stream (pair id = rank * S + i), resident in HBM before the timed region
+    pairs = [make_pair(N, N, seed=1234 + rank * S + i, mask=True, sky=0.0, bkg_scale=0.05) for i in range(S)]
+    g = [{k: torch.from_numpy(v).to(dev) for k, v in pr.items()} for pr in pairs]
+    sols = [torch.empty(plans[0].NEQ, dtype=torch.float64, device=dev) for _ in range(S)]
+    diffs = [torch.empty((N, N), dtype=torch.float64, device=dev) for _ in range(S)]
     stage_acc = {}
+
+    def run(i, n, timed):
+        torch.cuda.set_device(local_rank)
+        with torch.cuda.stream(streams[i]):
+            for _ in range(n):
+                plans[i].subtract(g[i]["REF"], g[i]["SCI"], g[i]["mREF"], g[i]["mSCI"], out_solution=sols[i], out_diff=diffs[i])
+                if timed and i == 0:
+                    for k, v in plans[0].stage_ms().items():
+                        stage_acc[k] = stage_acc.get(k, 0.0) + v
+
+    def run_all(n, timed):
+        if S == 1:
+            run(0, n, timed)
+            return
+        th = [threading.Thread(target=run, args=(i, n, timed)) for i in range(S)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+
+    run_all(args.warmup, False)
+    plans[0].set_timing(True)
 
     def barrier():
         if world > 1:
@@ -129,48 +152,74 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k, v in plan.stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    run_all(args.steps, True)
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t_start
-    plan.set_timing(False)
+
+    # isolated pass (one pair in flight) for per-kernel roofline numbers that are not inflated by the other streams
+    iso_acc = {}
+    n_iso = min(5, max(2, args.steps))
+    with torch.cuda.stream(streams[0]):
+        t_iso = time.perf_counter()
+        for _ in range(n_iso):
+            plans[0].subtract(g[0]["REF"], g[0]["SCI"], g[0]["mREF"], g[0]["mSCI"], out_solution=sols[0], out_diff=diffs[0])
+            for k, v in plans[0].stage_ms().items():
+                iso_acc[k] = iso_acc.get(k, 0.0) + v
+        torch.cuda.synchronize(dev)
+        iso_ms = (time.perf_counter() - t_iso) * 1e3 / n_iso
+    plans[0].set_timing(False)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # gather one record per pair (pair id = rank): the only collective of the data path
-    rec = pack_record(rank, 0, elapsed * 1e3 / max(args.steps, 1), sol)
-    table = gather_records([rec], world, plan.NEQ, dev)
+    # gather one record per pair: the only collective of the data path
+    recs = [pack_record(rank * S + i, 0, elapsed * 1e3 / max(args.steps, 1), sols[i]) for i in range(S)]
+    table = gather_records(recs, world * S, plans[0].NEQ, dev)
 
     if rank == 0:
-        pairs = world * args.steps
-        value = pairs / elapsed
+        npairs = world * S * args.steps
+        value = npairs / elapsed
         ms_step = elapsed * 1e3 / args.steps
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+        iso_stage = {k: v / n_iso for k, v in iso_acc.items()}
         ab = alg_bytes(N, N, args.kerhw, args.dk, args.db)
-        timed = {k: v for k, v in stage_ms.items() if k in ab}
-        dom = max(timed, key=timed.get)
-        ach = ab[dom] / (timed[dom] * 1e-3) / 1e9
+
+        pmc = {}
+        try:   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json; see profiles/README.md)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pass
+
+        def roof(stages):
+            timed = {k: v for k, v in stages.items() if k in ab}
+            dom = max(timed, key=timed.get)
+            ach = ab[dom] / (timed[dom] * 1e-3) / 1e9
+            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if (N, args.kerhw, args.dk, args.db) == (4096, 8, 2, 2) else None
+            return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": timed[dom]}
         out = {
             "metric": "image-pairs/sec, %dx%d, KerHW=%d polyOrd=%d" % (N, N, args.kerhw, args.dk),
             "value": value, "unit": "image-pairs/s", "mpix_per_s": value * N * N / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: one %dx%d pair per step per GPU, KerHW %d, KerPolyOrder %d, "
-                                   "BGPolyOrder %d, ConstPhotRatio, fp64; GSS = solve(masked pair) + apply(full pair)"
-                                   % (N, N, args.kerhw, args.dk, args.db),
-                       "pairs_per_step": world, "plan_create_s": plan_s, "solver": {1: "cholesky", 2: "lu"}.get(plan.query("LAST_SOLVER"), "?")},
+            "config": {"workload": "BASELINE configs[1]: %dx%d pairs, KerHW %d, KerPolyOrder %d, BGPolyOrder %d, "
+                                   "ConstPhotRatio, fp64; GSS = solve(masked pair) + apply(full pair); "
+                                   "%d independent pairs in flight per GPU (one plan + stream each), a step = %d pairs"
+                                   % (N, N, args.kerhw, args.dk, args.db, S, world * S),
+                       "pairs_per_step": world * S, "pairs_in_flight_per_gpu": S, "plan_create_s": plan_s,
+                       "solver": {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")},
             "stage_ms": stage_ms,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "alg_bytes_per_launch": ab[dom], "avg_ms": timed[dom]},
+            "roofline": dict(roof(iso_stage), measured="HIP events on the launch stream around the kernel, %d launches with one "
+                             "pair in flight right after the timed region (same process, same buffers)" % n_iso),
+            "roofline_timed_region": dict(roof(stage_ms), measured="same events on stream 0 inside the timed region; durations "
+                                          "include time sliced to the other %d streams' kernels" % (S - 1)),
+            "single_pair": {"ms": iso_ms, "pairs_per_s": 1e3 / iso_ms, "stage_ms": iso_stage,
+                            "note": "one pair in flight: latency of one GSS and per-stage times without interleaving"},
             "pair_effective": {"B_alg_reference_bytes": ab["B_alg_reference"], "n_fft_reference": ab["n_fft_reference"],
-                               "effective_GBs": ab["B_alg_reference"] / (ms_step * 1e-3 / world) / 1e9 / world,
-                               "note": "reference-algorithm bytes (SURVEY 8d) / measured pair time; the build moves fewer bytes"},
+                               "effective_GBs_per_gpu": ab["B_alg_reference"] * (value / world) / 1e9,
+                               "note": "reference-algorithm bytes (SURVEY 8d) x pairs/s per GPU; the build moves ~10x fewer bytes"},
             "gathered_pairs": int(table.shape[0]),
         }
         if world == 1 and args.cpu_sample > 0:

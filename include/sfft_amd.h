@@ -52,13 +52,14 @@ enum {
  * (sfft/sfftcore/SFFTSubtract.py:594-597, 763-769, 814-816) */
 enum {
     SFFT_ST_PRELIM_SOLVE = 0,  /* b+c: spatial polynomial + forward DFTs of the masked pair */
-    SFFT_ST_GREEK_G1,          /* d..h: Hadamard products + pruned column transform */
+    SFFT_ST_GREEK_G1,          /* d: Omega passes -- Hadamard products + pruned column transform (kernel greek_g1, 2w lags) */
     SFFT_ST_GREEK_G2,          /* d..h: pruned row transform -> lag patches */
     SFFT_ST_FILL,              /* FillLS_* + Remove_LSFStripes */
     SFFT_ST_SOLVE,             /* i: dense solve + Extend_Solution */
     SFFT_ST_PRELIM_APPLY,      /* b+c on the full pair */
     SFFT_ST_CONSTRUCT,         /* j+k: kernel transfer function + Construct_FDIFF */
     SFFT_ST_INVERSE,           /* k: inverse DFT + DIFF epilogue */
+    SFFT_ST_GREEK_G1B,         /* e..h: Theta and Gamma passes (kernel greek_g1, w lags) */
     SFFT_ST_COUNT
 };
 

@@ -20,7 +20,7 @@ SFFT_ERR_NOMEM = -5
 QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1", "Fab", "Fij", "Fpq", "NEQ", "Fijab",
                 "NEQ_FSfree", "FOMG", "FGAM", "FTHE", "FPSI", "FPHI", "FDEL", "WORKSPACE_BYTES", "LAST_SOLVER",
                 "NUM_GREEK_PAIRS"]
-STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse"]
+STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b"]
 
 EXPORTS = ["sfft_plan_create", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
            "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",

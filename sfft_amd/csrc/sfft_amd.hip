@@ -558,8 +558,8 @@ __global__ void __launch_bounds__(64 * RS) greek_g1(const cplx* __restrict__ spe
     for (int t = 0; t < HBW; ++t) { S1[t] = S2[t] = S3[t] = S4[t] = 0.0; }
     double g0x = 0.0, g0y = 0.0;
     const bool do_g0 = (r_base == 0 && wv == 0);
-    // W0tab[l][r-1] = W0^(l r), r = 1..HM: one contiguous, wave-uniform row of twiddles per image row (scalar loads)
-    const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + (rfirst - 1);
+    // W0tab[l][r] = W0^(l r), r = 0..HM-1: one contiguous, wave-uniform row of twiddles per image row (scalar loads)
+    const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + rfirst;
     for (int l = lb; l < le; ++l, trow += HM) {
         const cplx av = A[(size_t)l * Nhp];
         const cplx bv = colfac ? xp[l] : B[(size_t)l * Nhp];
@@ -589,12 +589,12 @@ __global__ void __launch_bounds__(64 * RS) greek_g1(const cplx* __restrict__ spe
     }
 }
 
-// W0tab[l][r-1] = root0[(l r) mod N0]
+// W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)
 __global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= N0 * HM) return;
-    const int l = e / HM, r = e - l * HM + 1;
+    const int l = e / HM, r = e - l * HM;
     W0tab[e] = root0[(int)(((long long)l * r) % N0)];
 }
 
@@ -854,7 +854,7 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 // register indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
 // b >= 1 then solve X L^T = A_panel for 64 rows below it (border row n included) the same way.
 __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
-                                                  int* __restrict__ status)
+                                                  int* __restrict__ status, double* __restrict__ rd)
 {
     __shared__ double Dl[CB][CB + 1];     // factor of the diagonal block
     __shared__ double rdiag[CB];          // 1 / L[j][j]
@@ -897,6 +897,7 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
             const int r = e / nb, c = e - r * nb;
             if (c <= r) A[(size_t)(k + r) * ld + k + c] = Dl[r][c];
         }
+        if (tid < nb) rd[k + tid] = rdiag[tid];
         return;
     }
     const int r0 = k + nb + (blockIdx.x - 1) * CB;
@@ -941,10 +942,12 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
     const int i0 = r0 + ti * CB, j0 = r0 + tj * CB;
     const int ni = min(CB, n + 1 - i0), nj = min(CB, n - j0);
     if (ni <= 0 || nj <= 0) return;
-    for (int e = tid; e < CB * nb; e += 256) {
-        const int i = e / nb, t = e - i * nb;
-        Li[i][t] = (i < ni) ? A[(size_t)(i0 + i) * ld + k + t] : 0.0;
-        Lj[i][t] = (i < nj) ? A[(size_t)(j0 + i) * ld + k + t] : 0.0;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {                 // 32 independent loads in flight per thread
+        const int e = tid + 256 * it;
+        const int i = e >> 6, t = e & 63;
+        Li[i][t] = (i < ni && t < nb) ? A[(size_t)(i0 + i) * ld + k + t] : 0.0;
+        Lj[i][t] = (i < nj && t < nb) ? A[(size_t)(j0 + i) * ld + k + t] : 0.0;
     }
     __syncthreads();
     const int tx = tid & 15, ty = tid >> 4;
@@ -953,7 +956,8 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) c[r][q] = 0.0;
-    for (int t = 0; t < nb; ++t) {
+#pragma unroll 8
+    for (int t = 0; t < CB; ++t) {                    // columns t >= nb are zero padded
         double av[4], bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) av[r] = Li[ty + 16 * r][t];
@@ -964,20 +968,28 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
 #pragma unroll
             for (int q = 0; q < 4; ++q) c[r][q] = fma(av[r], bv[q], c[r][q]);
     }
+    // epilogue: all 16 loads first (independent), then the stores
+    double old[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = ty + 16 * r;
-        if (i >= ni) continue;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int j = tx + 16 * q;
-            if (j >= nj) continue;
-            if (j0 + j > i0 + i) continue;   // lower triangle only
-            const double v = A[(size_t)(i0 + i) * ld + j0 + j] - c[r][q];
-            A[(size_t)(i0 + i) * ld + j0 + j] = v;
-            if (ti == 0 && tj == 0) Dnext[i * CB + j] = v;   // next step's diagonal block
+            const int i = ty + 16 * r, j = tx + 16 * q;
+            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
+            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
         }
-    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * r, j = tx + 16 * q;
+            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);   // lower triangle only
+            if (ok) {
+                const double v = old[r][q] - c[r][q];
+                A[(size_t)(i0 + i) * ld + j0 + j] = v;
+                if (ti == 0 && tj == 0) Dnext[i * CB + j] = v;          // next step's diagonal block
+            }
+        }
 }
 
 // Back substitution L^T x = y (y = border row n of the factor), one launch per 64-row block, last block first.
@@ -985,7 +997,8 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
 // workgroups (64 rows each); the last one to arrive (device-scope counter) reduces the partials and solves the
 // 64x64 triangle.  xv is [n] (stripe-free ordering).
 __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__ A, int ld, int n, int kb, double* __restrict__ xv,
-                                                      double* __restrict__ partial, unsigned int* __restrict__ counter)
+                                                      double* __restrict__ partial, unsigned int* __restrict__ counter,
+                                                      const double* __restrict__ rd)
 {
     __shared__ double red[4][CB];
     __shared__ double D[CB][CB + 1];
@@ -1000,36 +1013,43 @@ __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__
         const int rb = kb + nb + blockIdx.x * per;
         const int re = min(n, rb + per);
         double acc = 0.0;
-        if (c < nb)
+        if (c < nb) {
+#pragma unroll 8
             for (int row = rb + rg; row < re; row += 4) acc = fma(A[(size_t)row * ld + kb + c], xv[row], acc);
+        }
         red[rg][c] = acc;
         __syncthreads();
         if (tid < CB) partial[(size_t)blockIdx.x * CB + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        __threadfence();
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0) {                                   // one lane releases for the workgroup
+            __threadfence();
             const unsigned int prev = atomicAdd(counter, 1u);
             is_last = (prev == (unsigned int)(nslice - 1));
+            if (is_last) __threadfence();                 // ... and acquires for the last arriver
         }
         __syncthreads();
         if (!is_last) return;
-        __threadfence();
     } else if (blockIdx.x != 0) return;
     // last arriver: y_b - strip product, then the triangle
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e / nb, q = e - r * nb;
-        D[r][q] = A[(size_t)(kb + r) * ld + kb + q];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it;
+        const int r = e >> 6, q = e & 63;
+        D[r][q] = (r < nb && q < nb) ? A[(size_t)(kb + r) * ld + kb + q] : 0.0;
     }
+    double ps = 0.0;
+    if (rows_below > 0 && c < nb)
+        for (int g = rg; g < nslice; g += 4) ps += __hip_atomic_load(&partial[(size_t)g * CB + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[rg][c] = ps;
     __syncthreads();
     if (tid < 64) {
-        double yt = 0.0;
+        double yt = 0.0, rdj = 1.0;
         if (tid < nb) {
-            yt = A[(size_t)n * ld + kb + tid];
-            if (rows_below > 0)
-                for (int g = 0; g < nslice; ++g) yt -= __hip_atomic_load(&partial[(size_t)g * CB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            yt = A[(size_t)n * ld + kb + tid] - (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+            rdj = rd[kb + tid];
         }
         for (int j = nb - 1; j >= 0; --j) {
-            const double xj = __shfl(yt, j) / D[j][j];
+            const double xj = __shfl(yt, j) * __shfl(rdj, j);
             if (tid == j) yt = xj;
             else if (tid < j) yt = fma(-D[j][tid], xj, yt);
         }
@@ -1239,15 +1259,20 @@ struct sfft_plan {
     std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
     std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
+
     int S = 1, rows_per_chunk = 0;
     FillArgs fa;
     // workspaces
     cplx* d_spec = nullptr;             // [Fij+1][N0][Nhp]   (plane Fij: J in solve, FD in apply)
+    cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
+    hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr; int no_overlap = 0;
+    const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
     cplx* d_gp = nullptr;
     double* d_patches = nullptr; size_t n_patches = 0;
     double* d_A = nullptr; int ld = 0;
     double* d_dbuf = nullptr;           // [2][CB][CB] diagonal blocks handed from chol_update to chol_panel
     double* d_xv = nullptr;             // [NEQfs] solution in stripe-free ordering
+    double* d_rd = nullptr;             // [NEQfs] reciprocal diagonal of the Cholesky factor
     double* d_partial = nullptr;        // [BACK_SLICES][CB] strip-product partials of the back substitution
     unsigned int* d_counter = nullptr;
     double* d_sol = nullptr;            // [NEQ] internal solution copy
@@ -1391,6 +1416,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
     p->dev = device;
     if (const char* ev = getenv("SFFT_G1_VARIANT")) p->g1_variant = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
+    if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->cpr = cpr ? 1 : 0;
     p->L = 2 * KerHW + 1; p->Fab = p->L * p->L;
     p->Fij = (DK + 1) * (DK + 2) / 2; p->Fpq = (DB + 1) * (DB + 2) / 2;
@@ -1405,6 +1431,25 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
 #define PLAN_TRY(x) do { rc = (x); if (rc) { sfft_plan_destroy(p); return rc; } } while (0)
 #define PLAN_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { set_err(SFFT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); sfft_plan_destroy(p); return SFFT_ERR_HIP; } } while (0)
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { PLAN_HIP(hipEventCreate(&p->ev[s][0])); PLAN_HIP(hipEventCreate(&p->ev[s][1])); }
+    {
+        int lo = 0, hi = 0;
+        PLAN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));     // lo = least urgent
+        // the second stream runs the apply pass's forward transforms beside the dense solve: keep it off a
+        // subset of the CUs when SFFT_S2_CUMASK is set (bit pattern per 32 CUs) so that the solver's small,
+        // latency-bound launches always find free CUs; fall back to a low-priority stream if masking fails
+        uint32_t pat = 0u;      // CU masking measured slower than a plain low-priority stream on MI355X; off by default
+        if (const char* ev = getenv("SFFT_S2_CUMASK")) pat = (uint32_t)strtoul(ev, nullptr, 0);
+        hipDeviceProp_t prop;
+        PLAN_HIP(hipGetDeviceProperties(&prop, device));
+        const int nwords = (prop.multiProcessorCount + 31) / 32;
+        std::vector<uint32_t> mask(nwords, pat);
+        if (pat == 0 || hipExtStreamCreateWithCUMask(&p->s2, (uint32_t)nwords, mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            PLAN_HIP(hipStreamCreateWithPriority(&p->s2, hipStreamNonBlocking, lo));
+        }
+        PLAN_HIP(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
+        PLAN_HIP(hipEventCreateWithFlags(&p->ev_pre, hipEventDisableTiming));
+    }
     {
         int n = 0;
         for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { p->ref_ij[n][0] = i; p->ref_ij[n][1] = j; ++n; }
@@ -1527,7 +1572,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         PLAN_TRY(dev_alloc(p, &p->d_jobs, p->jobs.size()));
         PLAN_HIP(hipMemcpy(p->d_jobs, p->jobs.data(), p->jobs.size() * sizeof(PatchJob), hipMemcpyHostToDevice));
         PLAN_TRY(dev_alloc(p, &p->d_gp, (size_t)goff));
-        p->hm = std::max(1, hO);
+        p->hm = hO + 1;
         PLAN_TRY(dev_alloc(p, &p->d_w0tab, (size_t)N0 * p->hm));
         hipLaunchKernelGGL(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
@@ -1539,6 +1584,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
     PLAN_TRY(dev_alloc(p, &p->d_A, (size_t)(p->NEQfs + 1) * p->ld));
     PLAN_TRY(dev_alloc(p, &p->d_dbuf, (size_t)2 * CB * CB));
     PLAN_TRY(dev_alloc(p, &p->d_xv, (size_t)p->NEQfs));
+    PLAN_TRY(dev_alloc(p, &p->d_rd, (size_t)p->NEQfs));
     PLAN_TRY(dev_alloc(p, &p->d_partial, (size_t)BACK_SLICES * CB));
     PLAN_TRY(dev_alloc(p, &p->d_counter, (size_t)1));
     PLAN_HIP(hipMemset(p->d_counter, 0, sizeof(unsigned int)));
@@ -1571,9 +1617,12 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     hipSetDevice(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab};
+                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
+    if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
+    if (p->ev_in) hipEventDestroy(p->ev_in);
+    if (p->ev_pre) hipEventDestroy(p->ev_pre);
     delete p;
     return SFFT_OK;
 }
@@ -1646,16 +1695,16 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
     }
 }
 
-static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, hipStream_t s)
+static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* dst, hipStream_t s)
 {
     dim3 g1((p->N0 + 1) / 2, nplanes);
     if (fast_axis(p->ax1) && !p->no_fast_fft)
-        hipLaunchKernelGGL(rows_r2c_4096, g1, dim3(256), F4K_LDS * sizeof(cplx), s, ra, p->d_spec, p->N0, p->Nhp, p->ax1.tw, p->scale);
+        hipLaunchKernelGGL(rows_r2c_4096, g1, dim3(256), F4K_LDS * sizeof(cplx), s, ra, dst, p->N0, p->Nhp, p->ax1.tw, p->scale);
     else
-        hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, p->d_spec, p->N0, p->N1, p->Nh, p->Nhp,
+        hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
                            axis_dev(p->ax1), p->scale);
     LAUNCH_CHECK();
-    launch_cols(p, p->d_spec, nplanes, 0, s);
+    launch_cols(p, dst, nplanes, 0, s);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -1710,7 +1759,7 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
         const int nblk = 1 + (rows_below + CB - 1) / CB;
         double* Dcur = p->d_dbuf + (size_t)(step & 1) * CB * CB;
         double* Dnxt = p->d_dbuf + (size_t)((step + 1) & 1) * CB * CB;
-        hipLaunchKernelGGL(chol_panel, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, k, Dcur, p->d_status);
+        hipLaunchKernelGGL(chol_panel, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, k, Dcur, p->d_status, p->d_rd);
         const int ntile = (rows_below + CB - 1) / CB;
         if (ntile > 0 && k + nb < n)
             hipLaunchKernelGGL(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k, Dnxt);
@@ -1722,7 +1771,7 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
         const int kb = b * CB, nb = std::min(CB, n - kb);
         const int rows_below = n - (kb + nb);
         const int nslice = rows_below > 0 ? std::min(BACK_SLICES, (rows_below + CB - 1) / CB) : 1;
-        hipLaunchKernelGGL(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter);
+        hipLaunchKernelGGL(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter, p->d_rd);
     }
     hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ);
     LAUNCH_CHECK();
@@ -1745,6 +1794,8 @@ static int run_lu(sfft_plan* p, double* d_solution, hipStream_t s)
     return SFFT_OK;
 }
 
+static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t s);
+
 extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, double* d_solution, void* stream)
 {
     if (!p || !d_I || !d_J || !d_solution) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
@@ -1757,7 +1808,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
         for (int k = 0; k < p->Fij; ++k) { ra.src[k] = d_I; ra.ei[k] = p->ref_ij[k][0]; ra.ej[k] = p->ref_ij[k][1]; }
         ra.src[p->Fij] = d_J; ra.ei[p->Fij] = 0; ra.ej[p->Fij] = 0;
         for (int k = p->Fij + 1; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
-        if ((rc = forward_planes(p, ra, p->Fij + 1, s))) return rc;
+        if ((rc = forward_planes(p, ra, p->Fij + 1, p->d_spec, s))) return rc;
         hipLaunchKernelGGL(row_moments, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
@@ -1765,6 +1816,9 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     {
         StageTimer t(p, SFFT_ST_GREEK_G1, s);
         if ((rc = greek_g1_group(p, 0, p->n_omg, 2 * p->w, s))) return rc;
+    }
+    {
+        StageTimer t(p, SFFT_ST_GREEK_G1B, s);
         if ((rc = greek_g1_group(p, p->n_omg, p->n_the + p->n_gamp, p->w, s))) return rc;
         if (p->n_gam0 > 0) {
             hipLaunchKernelGGL(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_gam0), dim3(256), 0, s, p->d_spec, p->d_passes,
@@ -1781,6 +1835,14 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
         LAUNCH_CHECK();
     }
     p->have_system = true;
+    if (p->overlap_I) {      // sfft_subtract: start the full pair's forward transforms now, beside the dense solve
+        const double* dI = p->overlap_I;
+        p->overlap_I = nullptr;
+        HIPCHK(hipEventRecord(p->ev_in, s));
+        HIPCHK(hipStreamWaitEvent(p->s2, p->ev_in, 0));
+        if ((rc = apply_prelim(p, dI, p->d_spec2, p->s2))) return rc;
+        HIPCHK(hipEventRecord(p->ev_pre, p->s2));
+    }
     int status = 0;
     bool use_lu = p->force_lu != 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1806,26 +1868,25 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     return SFFT_OK;
 }
 
-extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, const double* d_solution, double* d_diff,
-                          void* stream)
+// forward spectra of the polynomial-weighted planes of I for the apply pass, into `dst` ([Fij][N0][Nhp])
+static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t s)
 {
-    if (!p || !d_I || !d_J || !d_solution || !d_diff) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
-    hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(p->dev));
-    int rc;
-    {
-        StageTimer t(p, SFFT_ST_PRELIM_APPLY, s);
-        RowsArgs ra;
-        for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
-        for (int k = 0; k < p->Fij; ++k) { ra.src[k] = d_I; ra.ei[k] = p->ref_ij[k][0]; ra.ej[k] = p->ref_ij[k][1]; }
-        if ((rc = forward_planes(p, ra, p->Fij, s))) return rc;
-    }
-    cplx* FD = p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp;
+    StageTimer t(p, SFFT_ST_PRELIM_APPLY, s);
+    RowsArgs ra;
+    for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
+    for (int k = 0; k < p->Fij; ++k) { ra.src[k] = d_I; ra.ei[k] = p->ref_ij[k][0]; ra.ej[k] = p->ref_ij[k][1]; }
+    return forward_planes(p, ra, p->Fij, dst, s);
+}
+
+// Construct_FDIFF + inverse transform + DIFF epilogue from the spectra FI; FD is a scratch plane
+static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_J, const double* d_solution, double* d_diff,
+                        hipStream_t s)
+{
     {
         StageTimer t(p, SFFT_ST_CONSTRUCT, s);
         hipLaunchKernelGGL(kernel_ctab, dim3((p->Nh + 255) / 256, p->Fij * p->L), dim3(256), 0, s, d_solution, p->d_ctab, p->d_soff,
                            p->Fij, p->L, p->L, p->w, p->Nh, p->Nhp, p->N1, p->ax1.root);
-        hipLaunchKernelGGL(construct_fd, dim3((p->Nh + 255) / 256, (p->N0 + CRL - 1) / CRL), dim3(256), 0, s, p->d_spec, FD, p->d_ctab,
+        hipLaunchKernelGGL(construct_fd, dim3((p->Nh + 255) / 256, (p->N0 + CRL - 1) / CRL), dim3(256), 0, s, FI, FD, p->d_ctab,
                            p->d_soff, p->ax0.root, p->N0, p->Nh, p->Nhp, p->Fij, p->L, p->w, p->scale);
         LAUNCH_CHECK();
     }
@@ -1843,14 +1904,51 @@ extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, co
     return SFFT_OK;
 }
 
+extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, const double* d_solution, double* d_diff,
+                          void* stream)
+{
+    if (!p || !d_I || !d_J || !d_solution || !d_diff) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    int rc;
+    if ((rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
+    return apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_J, d_solution, d_diff, s);
+}
+
+// GSS: the forward transforms of the full pair do not depend on the solution, and the dense solve leaves most
+// CUs idle, so they run on the plan's second (low priority) stream while the caller's stream establishes and
+// solves the system; the streams join before Construct_FDIFF.
 extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J, const double* d_mI, const double* d_mJ,
                              double* d_solution, double* d_diff, void* stream)
 {
-    int rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream);
-    if (rc) return rc;
-    rc = sfft_apply(p, d_I, d_J, d_solution, d_diff, stream);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (!p || !d_I || !d_J || !d_mI || !d_mJ || !d_solution || !d_diff) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    int rc;
+    if (p->no_overlap) {
+        if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
+        if ((rc = sfft_apply(p, d_I, d_J, d_solution, d_diff, stream))) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+        return SFFT_OK;
+    }
+    if (!p->d_spec2) {
+        if ((rc = dev_alloc(p, &p->d_spec2, (size_t)p->Fij * p->N0 * p->Nhp))) return rc;
+    }
+    if (d_I == d_mI) {
+        // the caller passed the full image as its own mask ("'same' means it is identical with I",
+        // SFFTSubtract.py:849): the spectra of the solve pass are the spectra of the apply pass
+        if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
+        if ((rc = apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_J, d_solution, d_diff, s))) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+        return SFFT_OK;
+    }
+    p->overlap_I = d_I;
+    rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream);
+    p->overlap_I = nullptr;
+    if (rc) { hipStreamSynchronize(p->s2); return rc; }
+    HIPCHK(hipStreamWaitEvent(s, p->ev_pre, 0));
+    if ((rc = apply_finish(p, p->d_spec2, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_J, d_solution, d_diff, s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;
 }
 
@@ -1876,7 +1974,7 @@ extern "C" int sfft_dbg_forward_spectrum(sfft_plan* p, const double* d_I, int i,
     RowsArgs ra;
     for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
     ra.src[0] = d_I; ra.ei[0] = i; ra.ej[0] = j;
-    int rc = forward_planes(p, ra, 1, s);
+    int rc = forward_planes(p, ra, 1, p->d_spec, s);
     if (rc) return rc;
     hipLaunchKernelGGL(copy_spectrum, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec_out, p->N0, p->Nh, p->Nhp);
     LAUNCH_CHECK();

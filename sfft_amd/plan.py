@@ -105,13 +105,15 @@ class Plan:
 
 
 _CACHE = collections.OrderedDict()
-_CACHE_MAX = 4
+_CACHE_MAX = 6
 
 
-def get_plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device=0):
+def get_plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device=0, slot=0):
     """Plans are cached per (device, shape, KerHW, DK, DB, ConstPhotRatio): the reference re-JITs on every
-    SSC call (sfft/PureCupyCustomizedPacket.py:139-141, 7.6 s); here repeated packets reuse tables and workspaces."""
-    key = (int(device), int(N0), int(N1), int(KerHW), int(DK), int(DB), bool(ConstPhotRatio))
+    SSC call (sfft/PureCupyCustomizedPacket.py:139-141, 7.6 s); here repeated packets reuse tables and workspaces.
+    `slot` distinguishes independent plans of the same geometry (one per host thread / stream when several pairs
+    are pipelined on one GPU)."""
+    key = (int(device), int(N0), int(N1), int(KerHW), int(DK), int(DB), bool(ConstPhotRatio), int(slot))
     p = _CACHE.get(key)
     if p is not None:
         _CACHE.move_to_end(key)

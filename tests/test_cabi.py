@@ -34,7 +34,7 @@ def test_header_enums_match_python_binding():
     assert [f.upper() for f in _lib.QUERY_FIELDS] == [f.upper().replace("CONSTPHOTRATIO", "CONSTPHOTRATIO").replace("NEQ_FSFREE", "NEQ_FSFREE") for f in fields]
     st = re.search(r"SFFT_ST_PRELIM_SOLVE = 0,(.*?)SFFT_ST_COUNT", txt, re.S).group(1)
     stages = ["PRELIM_SOLVE"] + [f.strip()[len("SFFT_ST_"):] for f in re.sub(r"/\*.*?\*/", "", st, flags=re.S).split(",") if f.strip()]
-    assert [s.upper() for s in _lib.STAGES] == stages
+    assert [s.upper() for s in _lib.STAGES] == stages, (stages, _lib.STAGES)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -43,7 +43,7 @@ NAMES = golden_names()
 # (0) building blocks
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(8, 8), (64, 64), (128, 32), (48, 40), (45, 35), (100, 96), (512, 256), (300, 500),
-                                   (1024, 2048)])
+                                   (1024, 2048), (4096, 64), (64, 4096), (4096, 4096), (4095, 4096), (8192, 16)])
 @pytest.mark.parametrize("ij", [(0, 0), (2, 1)])
 def test_forward_spectrum_matches_numpy_fft2(dev, shape, ij):
     from sfft_amd.plan import get_plan
@@ -189,6 +189,21 @@ def test_gss_matches_oracle(dev, case):
     p = O.SSC(N0, N1, w, DK, DB, CPR)
     d2_o = O.ESS(I, J, p, SFFTSolution=sol_o, Subtract=True, workers=8)[1]
     assert rms(d2 - d2_o) <= 1e-10 * rms(J)
+
+
+def test_same_tensor_as_its_own_mask_reuses_spectra(dev):
+    """GSS with the full images passed as their own masks ('same', SFFTSubtract.py:849): the C ABI then skips the
+    second set of forward transforms; the result must equal the run with separate (identical) buffers."""
+    from sfft_amd.plan import get_plan
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1 = 256, 512
+    pair = make_pair(N0, N1, seed=5, mask=False)
+    plan = get_plan(N0, N1, 3, 2, 1, True, dev.index)
+    R, S = _to(dev, pair["REF"]), _to(dev, pair["SCI"])
+    sol_a, diff_a = plan.subtract(R, S, R, S)
+    sol_b, diff_b = plan.subtract(R, S, R.clone(), S.clone())
+    assert torch.equal(sol_a, sol_b)
+    assert rms((diff_a - diff_b).cpu().numpy()) <= 1e-12 * rms(pair["SCI"])
 
 
 def test_contamination_mask_matches_oracle(dev):
