@@ -850,15 +850,16 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 }
 
 // One panel step.  Every workgroup factors the 64x64 diagonal block (right-looking; thread (i, cg) owns elements
-// (i, cg + 4q), q < 16, in registers; one barrier per column; the column loop is fully unrolled so that all
-// register indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
-// b >= 1 then solve X L^T = A_panel for 64 rows below it (border row n included) the same way.
+// (i, cg + 4q), q < 16, in registers; four columns per pair of barriers; fully unrolled so that all register
+// indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
+// b >= 1 then solve X L^T = A_panel for 64 rows below it (border row n included) without barriers (see below).
 __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
                                                   int* __restrict__ status, double* __restrict__ rd)
 {
     __shared__ double Dl[CB][CB + 1];     // factor of the diagonal block
     __shared__ double rdiag[CB];          // 1 / L[j][j]
-    __shared__ double col[2][CB];         // published column (double buffered)
+    __shared__ double Rw[CB][4];          // raw column block published in step 1
+    __shared__ double Fw[CB][4];          // final column block published in step 3
     const int tid = threadIdx.x;
     const int nb = min(CB, n - k);
     const int i = tid >> 2, cg = tid & 3;
@@ -868,22 +869,48 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
         const int c = cg + 4 * q;
         a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
     }
+    // Four columns per step (16 steps, two barriers each).  Step jq eliminates columns 4 jq .. 4 jq + 3:
+    //   1. every thread publishes its raw element of that column block (the quad of a row holds the four of them);
+    //   2. all threads factor the 4x4 pivot block T redundantly (four reciprocal square roots in sequence);
+    //   3. thread (i, cg) forward-substitutes its row through T up to column cg -> final L[i][4 jq + cg], published;
+    //   4. rank-4 update of the columns to the right from the published finals.
 #pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        const int buf = j & 1, jq = j >> 2, jr = j & 3;
-        if (cg == jr) col[buf][i] = a[jq];
+    for (int jq = 0; jq < 16; ++jq) {
+        Rw[i][cg] = a[jq];
         __syncthreads();
-        const double d = col[buf][j];
-        if (j < nb && !(d > 0.0) && tid == 0 && blockIdx.x == 0) atomicOr(status, 1);
-        const double rs = rsqrt_nr(d);
-        const double xi = col[buf][i];
-        const double nx = -xi * (rs * rs);
-        if (cg == jr) { a[jq] = xi * rs; if (i == j) rdiag[j] = rs; }            // final L[i][j] (rows < j: unused)
+        const int j0 = 4 * jq;
+        const double r00 = Rw[j0][0];
+        const double r10 = Rw[j0 + 1][0], r11 = Rw[j0 + 1][1];
+        const double r20 = Rw[j0 + 2][0], r21 = Rw[j0 + 2][1], r22 = Rw[j0 + 2][2];
+        const double r30 = Rw[j0 + 3][0], r31 = Rw[j0 + 3][1], r32 = Rw[j0 + 3][2], r33 = Rw[j0 + 3][3];
+        const double x0 = Rw[i][0], x1 = Rw[i][1], x2 = Rw[i][2], x3 = Rw[i][3];
+        const double rs0 = rsqrt_nr(r00);
+        const double t10 = r10 * rs0, t20 = r20 * rs0, t30 = r30 * rs0;
+        const double d1 = fma(-t10, t10, r11);
+        const double rs1 = rsqrt_nr(d1);
+        const double t21 = fma(-t20, t10, r21) * rs1, t31 = fma(-t30, t10, r31) * rs1;
+        const double d2 = fma(-t21, t21, fma(-t20, t20, r22));
+        const double rs2 = rsqrt_nr(d2);
+        const double t32 = fma(-t31, t21, fma(-t30, t20, r32)) * rs2;
+        const double d3 = fma(-t32, t32, fma(-t31, t31, fma(-t30, t30, r33)));
+        const double rs3 = rsqrt_nr(d3);
+        if (tid == 0 && blockIdx.x == 0 && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
+        const double l0 = x0 * rs0;
+        const double l1 = fma(-l0, t10, x1) * rs1;
+        const double l2 = fma(-l1, t21, fma(-l0, t20, x2)) * rs2;
+        const double l3 = fma(-l2, t32, fma(-l1, t31, fma(-l0, t30, x3))) * rs3;
+        const double lf = (cg == 0) ? l0 : (cg == 1) ? l1 : (cg == 2) ? l2 : l3;
+        a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
+        Fw[i][cg] = lf;
+        if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
+        __syncthreads();
+        if (jq < 15) {
+            const double f0 = Fw[i][0], f1 = Fw[i][1], f2 = Fw[i][2], f3 = Fw[i][3];
 #pragma unroll
-        for (int q = jq; q < 16; ++q) {                                         // columns c > j (upper part: harmless garbage)
-            const double cv = col[buf][cg + 4 * q];
-            if (q > jq) a[q] = fma(nx, cv, a[q]);
-            else a[q] = (cg > jr) ? fma(nx, cv, a[q]) : a[q];
+            for (int q = jq + 1; q < 16; ++q) {
+                const int c = cg + 4 * q;
+                a[q] = fma(-f3, Fw[c][3], fma(-f2, Fw[c][2], fma(-f1, Fw[c][1], fma(-f0, Fw[c][0], a[q]))));
+            }
         }
     }
 #pragma unroll
@@ -909,18 +936,27 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
         const int c = cg + 4 * q;
         p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
     }
+    // X L^T = A_panel, row by row: x_j = (a_j - sum_{t<j} x_t L[j][t]) / L[j][j].  The four lanes of a row each hold
+    // the x_t with t = cg (mod 4); they form partial sums over their own t and combine them with two quad
+    // shuffles, so this phase needs no barrier at all (rows are independent).
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
-        const int buf = j & 1, jq = j >> 2, jr = j & 3;
-        if (cg == jr) { p[jq] *= rdiag[j]; col[buf][i] = p[jq]; }
-        __syncthreads();
-        const double xi = col[buf][i];
+        const int jq = j >> 2, jr = j & 3;
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int q = jq; q < 16; ++q) {
-            const double lv = Dl[cg + 4 * q][j];                                // zero for padded columns c >= nb
-            if (q > jq) p[q] = fma(-xi, lv, p[q]);
-            else p[q] = (cg > jr) ? fma(-xi, lv, p[q]) : p[q];
+        for (int q = 0; q < jq; ++q) {
+            const double lv = Dl[j][cg + 4 * q];
+            if (q & 1) acc1 = fma(p[q], lv, acc1); else acc0 = fma(p[q], lv, acc0);
         }
+        {   // columns 4 jq + cg < j only
+            const double lv = (cg < jr) ? Dl[j][cg + 4 * jq] : 0.0;
+            acc0 = fma(p[jq], lv, acc0);
+        }
+        double tot = acc0 + acc1;
+        tot += __shfl_xor(tot, 1);
+        tot += __shfl_xor(tot, 2);
+        const double xj = (p[jq] - tot) * rdiag[j];
+        p[jq] = (cg == jr) ? xj : p[jq];
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
