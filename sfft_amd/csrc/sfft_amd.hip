@@ -301,6 +301,119 @@ __global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ F
 }
 
 // ================================================================================================
+// Axes too long for one on-chip transform (e.g. 6144, 9216, 9232): four-step decomposition N = A * B,
+//     X[ka + A kb] = sum_nb W_N^(nb ka) [ sum_na x[B na + nb] W_A^(na ka) ] W_B^(nb kb),
+// as two passes of batched strided sub-transforms (lengths A and B, each power of two or Bluestein on chip)
+// through global memory.  Correctness path for the large BASELINE configs; not tuned.
+// ================================================================================================
+struct PassDesc {
+    int len, J, nlines, mode;              // mode: which index runs fastest over threads (0: element, 1: j, 2: line)
+    long long js_in, es_in, lst_in;        // strides in complex elements: sequence j, element e, line
+    long long js_out, es_out, lst_out;
+    int twiddle, N;                        // multiply output k of sequence j by rootN[(j k) mod N]
+    int conj_in, conj_out;
+    double scale;
+};
+
+__global__ void __launch_bounds__(1024) strided_dft(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax,
+                                                     const cplx* __restrict__ rootN, int TC, int MS)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int M = ax.M;
+    for (int x = tid; x < TC * M; x += nt) {
+        int c, e;
+        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
+        const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
+        const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
+        cplx z = make_double2(0.0, 0.0);
+        if (e < d.len && j < d.J && line < d.nlines) {
+            z = in[(long long)line * d.lst_in + (long long)j * d.js_in + (long long)e * d.es_in];
+            if (d.conj_in) z.y = -z.y;
+        }
+        s[c * MS + e] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, TC, MS);
+    for (int x = tid; x < TC * M; x += nt) {
+        int c, e;
+        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
+        const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
+        const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
+        if (e < d.len && j < d.J && line < d.nlines) {
+            cplx z = s[c * MS + e];
+            if (d.twiddle) z = cmul(z, rootN[(int)(((long long)j * e) % d.N)]);
+            if (d.conj_out) z.y = -z.y;
+            out[(long long)line * d.lst_out + (long long)j * d.js_out + (long long)e * d.es_out] = make_double2(z.x * d.scale, z.y * d.scale);
+        }
+    }
+}
+
+// Z[pair][n] = (I[2 pair][n] w, I[2 pair + 1][n] w'): two real rows per complex sequence, SpatialPoly fused
+__global__ void __launch_bounds__(256) pack_rows(const double* __restrict__ src, int ei, int ej, cplx* __restrict__ Z, int N0, int N1)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (n >= N1) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const double cyp = ipow((double(n) + 1.0) / N1, ej);
+    const double v0 = src[(size_t)l0 * N1 + n] * (ipow((double(l0) + 1.0) / N0, ei) * cyp);
+    const double v1 = (l1 < N0) ? src[(size_t)l1 * N1 + n] * (ipow((double(l1) + 1.0) / N0, ei) * cyp) : 0.0;
+    Z[(size_t)pr * N1 + n] = make_double2(v0, v1);
+}
+
+// half spectra of the two real rows from the transform of their packed sequence (same algebra as rows_r2c)
+__global__ void __launch_bounds__(256) untangle_rows(const cplx* __restrict__ Zf, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
+                                                     double scale)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (m >= Nh) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const cplx z = Zf[(size_t)pr * N1 + m];
+    const cplx zp = Zf[(size_t)pr * N1 + (m == 0 ? 0 : N1 - m)];
+    const cplx zc = make_double2(zp.x, -zp.y);
+    const double hs = 0.5 * scale;
+    out[(size_t)l0 * Nhp + m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
+    if (l1 < N0) out[(size_t)l1 * Nhp + m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+}
+
+// conj(X0 + i X1) on the full length from the half spectra of two rows (input of the inverse row transform)
+__global__ void __launch_bounds__(256) retangle_rows(const cplx* __restrict__ FD, cplx* __restrict__ Z, int N0, int N1, int Nh, int Nhp)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (m >= N1) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const bool has1 = l1 < N0, even = (N1 & 1) == 0;
+    const bool mir = m >= Nh;
+    const int mm = mir ? N1 - m : m;
+    cplx x0 = FD[(size_t)l0 * Nhp + mm];
+    cplx x1 = has1 ? FD[(size_t)l1 * Nhp + mm] : make_double2(0.0, 0.0);
+    if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
+    if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
+    Z[(size_t)pr * N1 + m] = make_double2(x0.x - x1.y, -(x0.y + x1.x));
+}
+
+// DIFF = J - sum_pq b_pq cx^p cy^q - conv from the transformed packed rows (see rows_c2r_diff)
+__global__ void __launch_bounds__(256) finish_diff(const cplx* __restrict__ Zf, const double* __restrict__ J, const double* __restrict__ bpq,
+                                                   BkgArgs bk, double* __restrict__ DIFF, int N0, int N1)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (n >= N1) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const cplx z = Zf[(size_t)pr * N1 + n];
+    const double cy = (double(n) + 1.0) / N1;
+    const double cx0 = (double(l0) + 1.0) / N0, cx1 = (double(l1) + 1.0) / N0;
+    double B0 = 0.0, B1 = 0.0;
+    for (int t = 0; t < bk.npq; ++t) {
+        const double b = bpq[t], cyq = ipow(cy, bk.q[t]);
+        B0 += b * (ipow(cx0, bk.p[t]) * cyq);
+        B1 += b * (ipow(cx1, bk.p[t]) * cyq);
+    }
+    DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - B0 - z.x;
+    if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - B1 + z.y;
+}
+
+// ================================================================================================
 // Fast path for 4096-point axes: register-resident radix-16 FFT.  256 threads own 16 points each through
 // three radix-16 stages (4096 = 16^3); LDS is used only for the two inter-stage exchanges (padded by one
 // element per 16 so that the stride-16 writes of stage 1 are conflict free), not as the working array.
@@ -1270,6 +1383,11 @@ struct AxisHost {
     int N = 0, M = 0, logM = 0, blue = 0;
     cplx *tw = nullptr, *chirp = nullptr, *bf = nullptr, *root = nullptr;
     bool root_is_tw = false;
+    // four-step decomposition for lengths that do not fit one on-chip transform: N = A * B
+    bool big = false;
+    int A = 0, B = 0;
+    AxisHost* subA = nullptr;
+    AxisHost* subB = nullptr;
 };
 
 struct sfft_plan {
@@ -1300,6 +1418,7 @@ struct sfft_plan {
     FillArgs fa;
     // workspaces
     cplx* d_spec = nullptr;             // [Fij+1][N0][Nhp]   (plane Fij: J in solve, FD in apply)
+    cplx *d_big1 = nullptr, *d_big2 = nullptr, *d_colscr = nullptr;   // work arrays of the four-step path
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
     hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr; int no_overlap = 0;
     const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
@@ -1363,9 +1482,48 @@ static void host_fft_pow2(std::vector<long double>& re, std::vector<long double>
     }
 }
 
+static const size_t LDS_MAX_ELEMS = 8192;   // longest on-chip transform: 128 KiB of complex128 (160 KiB LDS per CU on gfx950)
+static const size_t LDS_COL_ELEMS = 9216;   // column tile budget (144 KiB): two padded 4096-point columns fit
+
+static bool fits_on_chip(int N)
+{
+    if (is_pow2(N)) return (size_t)N <= LDS_MAX_ELEMS;
+    int M = 1; while (M < 2 * N - 1) M <<= 1;
+    return (size_t)M <= LDS_MAX_ELEMS;
+}
+
+static int build_axis(sfft_plan* p, AxisHost& ax, int N);
+
+// N = A * B with A the largest power-of-two factor (<= 4096) such that B fits on chip too
+static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
+{
+    const long double PI = acosl(-1.0L);
+    int a = 1;
+    while (N % (a * 2) == 0 && a * 2 <= 4096) a *= 2;
+    int A = 0, B = 0;
+    for (; a >= 2; a /= 2) { if (fits_on_chip(N / a)) { A = a; B = N / a; break; } }
+    if (!A) return set_err(SFFT_ERR_UNSUPPORTED_SIZE,
+                           "image side not supported by this build: it must fit one on-chip transform (power of two <= 8192, "
+                           "any length <= 4096) or factor as 2^k * B with both factors on chip");
+    ax.N = N; ax.big = true; ax.A = A; ax.B = B; ax.M = 0; ax.logM = 0; ax.blue = 0;
+    ax.subA = new AxisHost(); ax.subB = new AxisHost();
+    int rc;
+    if ((rc = build_axis(p, *ax.subA, A))) return rc;
+    if ((rc = build_axis(p, *ax.subB, B))) return rc;
+    std::vector<cplx> r(N);
+    for (int k = 0; k < N; ++k) {
+        const long double ang = -2.0L * PI * k / N;
+        r[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    if ((rc = dev_alloc(p, &ax.root, N))) return rc;
+    HIPCHK(hipMemcpy(ax.root, r.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
+    return SFFT_OK;
+}
+
 static int build_axis(sfft_plan* p, AxisHost& ax, int N)
 {
     const long double PI = acosl(-1.0L);
+    if (!fits_on_chip(N)) return build_big_axis(p, ax, N);
     ax.N = N;
     if (is_pow2(N)) { ax.M = N; ax.blue = 0; }
     else { int M = 1; while (M < 2 * N - 1) M <<= 1; ax.M = M; ax.blue = 1; }
@@ -1436,9 +1594,6 @@ static void poly_axis_dft(int N, int e, int nout, std::vector<cplx>& out)
     }
 }
 
-static const size_t LDS_MAX_ELEMS = 8192;   // longest on-chip transform: 128 KiB of complex128 (160 KiB LDS per CU on gfx950)
-static const size_t LDS_COL_ELEMS = 9216;   // column tile budget (144 KiB): two padded 4096-point columns fit
-
 extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int DK, int DB, int cpr, int device)
 {
     if (!out) return set_err(SFFT_ERR_INVALID_ARG, "plan pointer is NULL");
@@ -1496,19 +1651,24 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
     }
     PLAN_TRY(build_axis(p, p->ax0, N0));
     PLAN_TRY(build_axis(p, p->ax1, N1));
-    if ((size_t)p->ax0.M > LDS_MAX_ELEMS || (size_t)p->ax1.M > LDS_MAX_ELEMS) {
-        sfft_plan_destroy(p);
-        return set_err(SFFT_ERR_UNSUPPORTED_SIZE,
-                       "image side not supported by this build: power-of-two sides up to 8192, other sides up to 4096");
+    // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
+    if (!p->ax1.big) {
+        p->nt_rows = std::min(1024, std::max(64, p->ax1.M / 16));
+        p->lds_rows = (size_t)p->ax1.M * sizeof(cplx);
     }
-    // launch geometry of the FFT kernels
-    p->nt_rows = std::min(1024, std::max(64, p->ax1.M / 16));
-    p->lds_rows = (size_t)p->ax1.M * sizeof(cplx);
-    p->MS = p->ax0.M + 1;
-    p->TC = 1;
-    while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS) p->TC *= 2;
-    p->nt_cols = std::min(1024, std::max(64, p->TC * p->ax0.M / 16));
-    p->lds_cols = (size_t)p->TC * p->MS * sizeof(cplx);
+    if (!p->ax0.big) {
+        p->MS = p->ax0.M + 1;
+        p->TC = 1;
+        while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS) p->TC *= 2;
+        p->nt_cols = std::min(1024, std::max(64, p->TC * p->ax0.M / 16));
+        p->lds_cols = (size_t)p->TC * p->MS * sizeof(cplx);
+    }
+    PLAN_HIP(hipFuncSetAttribute((const void*)strided_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (p->ax1.big) {          // two packed-row work arrays [ceil(N0/2)][N1]
+        PLAN_TRY(dev_alloc(p, &p->d_big1, (size_t)((N0 + 1) / 2) * N1));
+        PLAN_TRY(dev_alloc(p, &p->d_big2, (size_t)((N0 + 1) / 2) * N1));
+    }
+    if (p->ax0.big) PLAN_TRY(dev_alloc(p, &p->d_colscr, (size_t)N0 * p->Nhp));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1640,6 +1800,8 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
 
 static void free_axis(AxisHost& a)
 {
+    if (a.subA) { free_axis(*a.subA); delete a.subA; a.subA = nullptr; }
+    if (a.subB) { free_axis(*a.subB); delete a.subB; a.subB = nullptr; }
     if (a.tw) hipFree(a.tw);
     if (a.root && !a.root_is_tw) hipFree(a.root);
     if (a.chirp) hipFree(a.chirp);
@@ -1653,7 +1815,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     hipSetDevice(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2};
+                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -1715,10 +1877,46 @@ struct StageTimer {
 #define LAUNCH_CHECK() HIPCHK(hipGetLastError())
 
 // forward transforms of `nplanes` polynomial-weighted planes into spec planes [0, nplanes)
-static bool fast_axis(const AxisHost& a) { return !a.blue && a.M == 4096; }
+static bool fast_axis(const AxisHost& a) { return !a.big && !a.blue && a.M == 4096; }
+
+// one pass of batched strided sub-transforms
+static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, const AxisHost& sub, const cplx* rootN, hipStream_t s)
+{
+    const int MS = sub.M + 1;
+    int TC = 1;
+    while (TC < 16 && (size_t)(2 * TC) * MS <= LDS_COL_ELEMS) TC *= 2;
+    const int nt = std::min(1024, std::max(64, TC * sub.M / 16));
+    const int ngroups = (d.mode == 2) ? (d.nlines + TC - 1) / TC : (d.J + TC - 1) / TC;
+    const int gy = (d.mode == 2) ? d.J : d.nlines;
+    hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, MS);
+}
+
+// four-step transform of `nlines` lines of length ax.N; element stride st, line stride lst (complex elements).
+// Result lands in `data` again (scr is a same-shaped scratch).  inverse: e^{+i} (conjugation on the way in and out).
+static void big_axis_transform(sfft_plan* p, const AxisHost& ax, cplx* data, cplx* scr, long long st, long long lst, int nlines,
+                               bool lines_fastest, int inverse, hipStream_t s)
+{
+    PassDesc d1; memset(&d1, 0, sizeof(d1));
+    d1.len = ax.A; d1.J = ax.B; d1.nlines = nlines; d1.mode = lines_fastest ? 2 : 1;
+    d1.js_in = st; d1.es_in = (long long)ax.B * st; d1.lst_in = lst;
+    d1.js_out = d1.js_in; d1.es_out = d1.es_in; d1.lst_out = lst;
+    d1.twiddle = 1; d1.N = ax.N; d1.conj_in = inverse; d1.conj_out = 0; d1.scale = 1.0;
+    launch_pass(p, data, scr, d1, *ax.subA, ax.root, s);
+    PassDesc d2; memset(&d2, 0, sizeof(d2));
+    d2.len = ax.B; d2.J = ax.A; d2.nlines = nlines; d2.mode = lines_fastest ? 2 : 0;
+    d2.js_in = (long long)ax.B * st; d2.es_in = st; d2.lst_in = lst;
+    d2.js_out = st; d2.es_out = (long long)ax.A * st; d2.lst_out = lst;
+    d2.twiddle = 0; d2.N = ax.N; d2.conj_in = 0; d2.conj_out = inverse; d2.scale = 1.0;
+    launch_pass(p, scr, data, d2, *ax.subB, ax.root, s);
+}
 
 static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipStream_t s)
 {
+    if (p->ax0.big) {
+        for (int k = 0; k < nplanes; ++k)
+            big_axis_transform(p, p->ax0, data + (size_t)k * p->N0 * p->Nhp, p->d_colscr, p->Nhp, 1, p->Nh, true, inverse, s);
+        return;
+    }
     if (fast_axis(p->ax0) && !p->no_fast_fft) {
         const int npairs = (p->Nh + 1) / 2;
         const int per = (npairs + 7) / 8;
@@ -1734,7 +1932,15 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
 static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* dst, hipStream_t s)
 {
     dim3 g1((p->N0 + 1) / 2, nplanes);
-    if (fast_axis(p->ax1) && !p->no_fast_fft)
+    if (p->ax1.big) {
+        const int npr = (p->N0 + 1) / 2;
+        for (int k = 0; k < nplanes; ++k) {
+            hipLaunchKernelGGL(pack_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, ra.src[k], ra.ei[k], ra.ej[k], p->d_big1, p->N0, p->N1);
+            big_axis_transform(p, p->ax1, p->d_big1, p->d_big2, 1, p->N1, npr, false, 0, s);
+            hipLaunchKernelGGL(untangle_rows, dim3((p->Nh + 255) / 256, npr), dim3(256), 0, s, p->d_big1, dst + (size_t)k * p->N0 * p->Nhp,
+                               p->N0, p->N1, p->Nh, p->Nhp, p->scale);
+        }
+    } else if (fast_axis(p->ax1) && !p->no_fast_fft)
         hipLaunchKernelGGL(rows_r2c_4096, g1, dim3(256), F4K_LDS * sizeof(cplx), s, ra, dst, p->N0, p->Nhp, p->ax1.tw, p->scale);
     else
         hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
@@ -1929,7 +2135,13 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
     {
         StageTimer t(p, SFFT_ST_INVERSE, s);
         launch_cols(p, FD, 1, 1, s);
-        if (fast_axis(p->ax1) && !p->no_fast_fft)
+        if (p->ax1.big) {
+            const int npr = (p->N0 + 1) / 2;
+            hipLaunchKernelGGL(retangle_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, FD, p->d_big1, p->N0, p->N1, p->Nh, p->Nhp);
+            big_axis_transform(p, p->ax1, p->d_big1, p->d_big2, 1, p->N1, npr, false, 0, s);
+            hipLaunchKernelGGL(finish_diff, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, p->d_big1, d_J, d_solution + p->Fijab, p->bk,
+                               d_diff, p->N0, p->N1);
+        } else if (fast_axis(p->ax1) && !p->no_fast_fft)
             hipLaunchKernelGGL(rows_c2r_diff_4096, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
                                d_solution + p->Fijab, p->bk, d_diff, p->N0, p->Nhp, p->ax1.tw);
         else

@@ -43,7 +43,8 @@ NAMES = golden_names()
 # (0) building blocks
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(8, 8), (64, 64), (128, 32), (48, 40), (45, 35), (100, 96), (512, 256), (300, 500),
-                                   (1024, 2048), (4096, 64), (64, 4096), (4096, 4096), (4095, 4096), (8192, 16)])
+                                   (1024, 2048), (4096, 64), (64, 4096), (4096, 4096), (4095, 4096), (8192, 16),
+                                   (6144, 40), (40, 6144), (9232, 64), (64, 9216), (4100, 5000)])   # last rows: four-step axes
 @pytest.mark.parametrize("ij", [(0, 0), (2, 1)])
 def test_forward_spectrum_matches_numpy_fft2(dev, shape, ij):
     from sfft_amd.plan import get_plan
@@ -163,6 +164,8 @@ ORACLE_CASES = [
     (512, 512, 8, 2, 2, True, "REF", True),     # BASELINE kernel geometry at a size the oracle finishes in seconds
     (128, 128, 0, 2, 1, True, "REF", False),    # degenerate 1x1 kernel
     (64, 48, 9, 0, 0, True, "REF", False),      # 4w+1 > N1/2: lags wrap around the image
+    (6144, 72, 2, 1, 1, True, "REF", False),    # axis 0 needs the four-step transform (6144 = 2048 x 3)
+    (80, 9232, 2, 1, 0, True, "SCI", True),     # axis 1 needs it (9232 = 16 x 577, Bluestein inside)
 ]
 
 
@@ -250,7 +253,7 @@ def test_error_behaviour(dev):
         ElementalSFFTSubtract.ESS(b, b, cfg, VERBOSE_LEVEL=0)
     # unsupported size is reported, not mis-computed
     with pytest.raises(Exception, match="not supported by this build"):
-        SingleSFFTConfigure.SSC(6144, 64, 2, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+        SingleSFFTConfigure.SSC(10007, 64, 2, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)   # prime > 4096
 
 
 # ------------------------------------------------------------------------------------------------
@@ -328,3 +331,51 @@ def test_baseline_size_system_is_symmetric_gram_and_solution_is_stationary(dev, 
     # recovered photometric ratio: kernel sum = a_00,centre / (N0*N1) (SFFTSolutionReader.py:173-181) ~ 1.3
     ksum = float(sol[8 * 17 + 8].item()) / (4096.0 * 4096.0)
     assert abs(ksum - 1.3) < 0.05
+
+
+# ------------------------------------------------------------------------------------------------
+# (d) the large BASELINE shapes (configs 3 and 5 sizes; four-step transforms): properties only
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(6144, 6144, 8, 2, 2), (9232, 9216, 12, 3, 3)])
+def test_large_shapes_properties(dev, cfg):
+    from sfft_amd.plan import get_plan, clear_plan_cache
+    clear_plan_cache()
+    N0, N1, w, DK, DB = cfg
+    rng = np.random.default_rng(N0)
+    # cheap synthetic pair: smooth blobs + noise (the star renderer is too slow for 85 Mpix in a test)
+    x = np.linspace(0, 40 * np.pi, N0)[:, None]
+    y = np.linspace(0, 36 * np.pi, N1)[None, :]
+    base = 50.0 * (np.sin(x) * np.cos(y)) ** 8
+    REF = base + rng.normal(0, 1.0, (N0, N1))
+    SCI = 1.2 * (0.6 * base + 0.2 * np.roll(base, 1, 0) + 0.2 * np.roll(base, -1, 1)) + 3.0 + rng.normal(0, 1.0, (N0, N1))
+    plan = get_plan(N0, N1, w, DK, DB, True, dev.index)
+    R, S = _to(dev, REF), _to(dev, SCI)
+    L = 2 * w + 1
+    Fij = (DK + 1) * (DK + 2) // 2
+    # (1) identity kernel + constant background: DIFF = SCI - REF - b00 exactly
+    sol = np.zeros(plan.NEQ)
+    sol[w * L + w] = float(N0) * float(N1)
+    sol[plan.Fijab] = 2.5
+    D = plan.apply(R, S, _to(dev, sol)).cpu().numpy()
+    assert rms(D - (SCI - REF - 2.5)) <= 1e-10 * rms(SCI)
+    # (2) shift kernel reproduces a circular shift
+    a, b = -w, w
+    sol = np.zeros(plan.NEQ)
+    sol[(a + w) * L + (b + w)] = float(N0) * float(N1)
+    sol[w * L + w] = float(N0) * float(N1)
+    D = plan.apply(R, S, _to(dev, sol)).cpu().numpy()
+    assert rms(D - (SCI - np.roll(REF, (a, b), (0, 1)))) <= 1e-10 * rms(SCI)
+    del D
+    # (3) end to end: symmetric Gram system, stationary solution, sane residual and photometric ratio
+    solution, diff = plan.subtract(R, S, R, S)
+    LH, rhs = plan.get_system()
+    assert float((LH - LH.T).abs().max() / LH.abs().max()) <= 1e-13
+    idx = np.ones(plan.NEQ, dtype=bool)
+    idx[[ij * L * L + w * L + w for ij in range(1, Fij)]] = False
+    it = torch.from_numpy(np.where(idx)[0]).to(dev)
+    r = LH[it][:, it] @ solution[it] - rhs[it]
+    assert float(r.abs().max()) <= 1e-6 * float(rhs.abs().max())
+    d = diff.cpu().numpy()
+    assert np.isfinite(d).all() and rms(d) < 2.0
+    assert abs(float(solution[w * L + w].item()) / (float(N0) * float(N1)) - 1.2) < 0.05
+    clear_plan_cache()
