@@ -69,6 +69,19 @@ enum {
 int sfft_plan_create(sfft_plan** plan, int N0, int N1, int KerHW, int KerPolyOrder, int BGPolyOrder,
                      int ConstPhotRatio, int device);
 
+/* The same "compile" step for general separable spatial bases -- the B-spline form of SFFT
+ * (sfft/BSplineSFFT.py: SingleSFFTConfigure.SSC :2536-2607, bases tabulated on the host like :2624-2645).
+ * Kernel term ij is  kbx[ker_pairs[2 ij]][row] * kby[ker_pairs[2 ij + 1]][col]; background term pq is
+ * tbx[bkg_pairs[2 pq]][row] * tby[bkg_pairs[2 pq + 1]][col].  Tables are HOST pointers, row-major
+ * [n factors][axis length]; they are copied.  scaling_mode: 0 = scaling entangled with the kernel (no constraint),
+ * 1 = unknowns ij00[1:] removed (polynomial ConstPhotRatio, Remove_LSFStripes), 2 = unknowns ij00 tied to one
+ * value (B-spline constant scaling: rows/columns summed, BSplineSFFT.py:2201-2272).
+ * Limits: Fij <= 64, Fpq <= 64, <= 16 factors per axis. */
+int sfft_plan_create_basis(sfft_plan** plan, int N0, int N1, int KerHW,
+                           int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
+                           int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
+                           int scaling_mode, int device);
+
 int sfft_plan_destroy(sfft_plan* plan);
 
 /* read one SFFT_Q_* field */
@@ -96,8 +109,8 @@ int sfft_subtract(sfft_plan* plan, const double* d_I, const double* d_J, const d
  * Either pointer may be NULL. Synchronises. */
 int sfft_get_system(sfft_plan* plan, double* d_LHMAT, double* d_RHb, void* stream);
 
-/* Parity aid: SCALE * DFT2(I * cx^i * cy^j) in the plan's half-spectrum layout, d_spec: [N0][N1/2+1]
- * complex128 (interleaved re,im) -- items 3+4 of SURVEY.md 8(a). */
+/* Parity aid: SCALE * DFT2(I * kbx[i][row] * kby[j][col]) (= I * cx^i * cy^j for polynomial plans with i, j <= DK)
+ * in the plan's half-spectrum layout, d_spec: [N0][N1/2+1] complex128 (interleaved re,im) -- items 3+4 of SURVEY.md 8(a). */
 int sfft_dbg_forward_spectrum(sfft_plan* plan, const double* d_I, int i, int j, double* d_spec, void* stream);
 
 /* enable (1) / disable (0) hipEvent timing of the stages of subsequent calls */

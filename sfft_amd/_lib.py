@@ -22,7 +22,7 @@ QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1"
                 "NUM_GREEK_PAIRS"]
 STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b"]
 
-EXPORTS = ["sfft_plan_create", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
+EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
            "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",
            "sfft_last_error", "sfft_version"]
 
@@ -39,6 +39,7 @@ def _load():
     lib = ctypes.CDLL(LIB_PATH)
     vp, dp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int
     lib.sfft_plan_create.argtypes = [ctypes.POINTER(vp), ip, ip, ip, ip, ip, ip, ip]
+    lib.sfft_plan_create_basis.argtypes = [ctypes.POINTER(vp), ip, ip, ip, ip, ip, dp, dp, ip, dp, ip, ip, dp, dp, ip, dp, ip, ip]
     lib.sfft_plan_destroy.argtypes = [vp]
     lib.sfft_plan_query.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_longlong)]
     lib.sfft_solve.argtypes = [vp, dp, dp, dp, vp]

@@ -174,10 +174,10 @@ __device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int 
 // forward pass 1: rows, real -> half complex, two image rows per complex transform, SpatialPoly fused
 // ------------------------------------------------------------------------------------------------
 #define SFFT_MAX_PLANES 12
-struct RowsArgs {
+struct RowsArgs {                           // plane k = src[k] * wx[k][row] * wy[k][col]   (null weight = 1)
     const double* src[SFFT_MAX_PLANES];
-    int ei[SFFT_MAX_PLANES];
-    int ej[SFFT_MAX_PLANES];
+    const double* wx[SFFT_MAX_PLANES];      // [N0] factor of the spatial basis along axis 0 (cx^i or a B-spline basis function)
+    const double* wy[SFFT_MAX_PLANES];      // [N1] factor along axis 1
 };
 
 __global__ void __launch_bounds__(1024) rows_r2c(RowsArgs a, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
@@ -189,14 +189,15 @@ __global__ void __launch_bounds__(1024) rows_r2c(RowsArgs a, cplx* __restrict__ 
     const int plane = blockIdx.y;
     const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
     const double* __restrict__ src = a.src[plane];
-    const int ei = a.ei[plane], ej = a.ej[plane];
-    const double cx0 = ipow((double(l0) + 1.0) / N0, ei);
-    const double cx1 = ipow((double(l1) + 1.0) / N0, ei);
+    const double* __restrict__ wx = a.wx[plane];
+    const double* __restrict__ wy = a.wy[plane];
     const bool has1 = l1 < N0;
+    const double cx0 = wx ? wx[l0] : 1.0;
+    const double cx1 = (wx && has1) ? wx[l1] : 1.0;
     for (int n = tid; n < ax.M; n += nt) {
         cplx z = make_double2(0.0, 0.0);
         if (n < N1) {
-            const double cyp = ipow((double(n) + 1.0) / N1, ej);
+            const double cyp = wy ? wy[n] : 1.0;
             z.x = src[(size_t)l0 * N1 + n] * (cx0 * cyp);
             if (has1) z.y = src[(size_t)l1 * N1 + n] * (cx1 * cyp);
         }
@@ -253,7 +254,34 @@ __global__ void __launch_bounds__(1024) cols_c2c(cplx* __restrict__ data, int N0
 // inverse pass 2: rows, half complex -> real, two rows per transform, DIFF epilogue fused:
 //   DIFF = J - sum_pq b_pq cx^p cy^q - conv          (SFFTSubtract.py:452-461 with the J and T terms kept in real space)
 // ------------------------------------------------------------------------------------------------
-struct BkgArgs { int npq; int p[10]; int q[10]; };
+#define SFFT_MAX_PQ 64
+#define SFFT_MAX_BQ 16
+// differential background B(row, col) = sum_t b[t] * tbx[p[t]][row] * tby[q[t]][col]  (tables of the 1-D basis factors)
+struct BkgArgs {
+    int npq, nq;                    // terms, distinct column factors
+    const double* tbx;              // [nbx][N0]
+    const double* tby;              // [nby][N1]
+    int p[SFFT_MAX_PQ], q[SFFT_MAX_PQ];
+};
+
+// per-row coefficients of the column factors: c[q] = sum_{t: q[t] = q} b[t] * tbx[p[t]][row]
+__device__ __forceinline__ void bkg_row_coeffs(const BkgArgs& bk, const double* __restrict__ bpq, int row, int N0, double (&c)[SFFT_MAX_BQ])
+{
+#pragma unroll
+    for (int q = 0; q < SFFT_MAX_BQ; ++q) c[q] = 0.0;
+    for (int t = 0; t < bk.npq; ++t) {
+        const double v = bpq[t] * bk.tbx[(size_t)bk.p[t] * N0 + row];
+#pragma unroll
+        for (int q = 0; q < SFFT_MAX_BQ; ++q) if (bk.q[t] == q) c[q] += v;
+    }
+}
+__device__ __forceinline__ double bkg_eval(const BkgArgs& bk, const double (&c)[SFFT_MAX_BQ], int col, int N1)
+{
+    double B = 0.0;
+#pragma unroll
+    for (int q = 0; q < SFFT_MAX_BQ; ++q) if (q < bk.nq) B = fma(c[q], bk.tby[(size_t)q * N1 + col], B);
+    return B;
+}
 
 __global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ FD, const double* __restrict__ J,
                                                        const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
@@ -283,20 +311,13 @@ __global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ F
     }
     __syncthreads();
     lds_dft(s, ax, 1, ax.M);
-    double b[10];
-    for (int t = 0; t < bk.npq; ++t) b[t] = bpq[t];
-    const double cx0 = (double(l0) + 1.0) / N0, cx1 = (double(l1) + 1.0) / N0;
+    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
+    bkg_row_coeffs(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs(bk, bpq, has1 ? l1 : l0, N0, c1);
     for (int n = tid; n < N1; n += nt) {
         const cplx z = s[n];                 // conj(result): row0 = z.x, row1 = -z.y
-        const double cy = (double(n) + 1.0) / N1;
-        double B0 = 0.0, B1 = 0.0;
-        for (int t = 0; t < bk.npq; ++t) {
-            const double cyq = ipow(cy, bk.q[t]);
-            B0 += b[t] * (ipow(cx0, bk.p[t]) * cyq);
-            B1 += b[t] * (ipow(cx1, bk.p[t]) * cyq);
-        }
-        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - B0 - z.x;
-        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - B1 + z.y;
+        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval(bk, c0, n, N1) - z.x;
+        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval(bk, c1, n, N1) + z.y;
     }
 }
 
@@ -351,14 +372,15 @@ __global__ void __launch_bounds__(1024) strided_dft(const cplx* __restrict__ in,
 }
 
 // Z[pair][n] = (I[2 pair][n] w, I[2 pair + 1][n] w'): two real rows per complex sequence, SpatialPoly fused
-__global__ void __launch_bounds__(256) pack_rows(const double* __restrict__ src, int ei, int ej, cplx* __restrict__ Z, int N0, int N1)
+__global__ void __launch_bounds__(256) pack_rows(const double* __restrict__ src, const double* __restrict__ wx,
+                                                 const double* __restrict__ wy, cplx* __restrict__ Z, int N0, int N1)
 {
     const int n = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
     if (n >= N1) return;
     const int l0 = 2 * pr, l1 = l0 + 1;
-    const double cyp = ipow((double(n) + 1.0) / N1, ej);
-    const double v0 = src[(size_t)l0 * N1 + n] * (ipow((double(l0) + 1.0) / N0, ei) * cyp);
-    const double v1 = (l1 < N0) ? src[(size_t)l1 * N1 + n] * (ipow((double(l1) + 1.0) / N0, ei) * cyp) : 0.0;
+    const double cyp = wy ? wy[n] : 1.0;
+    const double v0 = src[(size_t)l0 * N1 + n] * ((wx ? wx[l0] : 1.0) * cyp);
+    const double v1 = (l1 < N0) ? src[(size_t)l1 * N1 + n] * ((wx ? wx[l1] : 1.0) * cyp) : 0.0;
     Z[(size_t)pr * N1 + n] = make_double2(v0, v1);
 }
 
@@ -401,16 +423,11 @@ __global__ void __launch_bounds__(256) finish_diff(const cplx* __restrict__ Zf, 
     if (n >= N1) return;
     const int l0 = 2 * pr, l1 = l0 + 1;
     const cplx z = Zf[(size_t)pr * N1 + n];
-    const double cy = (double(n) + 1.0) / N1;
-    const double cx0 = (double(l0) + 1.0) / N0, cx1 = (double(l1) + 1.0) / N0;
-    double B0 = 0.0, B1 = 0.0;
-    for (int t = 0; t < bk.npq; ++t) {
-        const double b = bpq[t], cyq = ipow(cy, bk.q[t]);
-        B0 += b * (ipow(cx0, bk.p[t]) * cyq);
-        B1 += b * (ipow(cx1, bk.p[t]) * cyq);
-    }
-    DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - B0 - z.x;
-    if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - B1 + z.y;
+    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
+    bkg_row_coeffs(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs(bk, bpq, (l1 < N0) ? l1 : l0, N0, c1);
+    DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval(bk, c0, n, N1) - z.x;
+    if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval(bk, c1, n, N1) + z.y;
 }
 
 // ================================================================================================
@@ -499,17 +516,18 @@ __global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, cplx* __restric
     const int plane = blockIdx.y;
     const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
     const double* __restrict__ src = a.src[plane];
-    const int ei = a.ei[plane], ej = a.ej[plane];
+    const double* __restrict__ wx = a.wx[plane];
+    const double* __restrict__ wy = a.wy[plane];
     const bool has1 = l1 < N0;
-    const double cx0 = ipow((double(l0) + 1.0) / N0, ei);
-    const double cx1 = ipow((double(l1) + 1.0) / N0, ei);
+    const double cx0 = wx ? wx[l0] : 1.0;
+    const double cx1 = (wx && has1) ? wx[l1] : 1.0;
     const double* r0p = src + (size_t)l0 * N1;
     const double* r1p = src + (size_t)(has1 ? l1 : l0) * N1;
     cplx u[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = j + 256 * r;
-        const double cyp = ipow((double(n) + 1.0) * (1.0 / 4096.0), ej);   // exact: N1 is a power of two
+        const double cyp = wy ? wy[n] : 1.0;
         const double v0 = r0p[n] * (cx0 * cyp);
         const double v1 = has1 ? r1p[n] * (cx1 * cyp) : 0.0;
         u[r] = make_double2(v0, v1);
@@ -591,15 +609,9 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
         u[r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
     }
     fft4096_core(u, j, lds, tw);
-    // background polynomial per row as a polynomial in cy: B(l, n) = sum_q cq[q] cy^q
-    double c0[4] = {0.0, 0.0, 0.0, 0.0}, c1[4] = {0.0, 0.0, 0.0, 0.0};
-    const double cx0 = (double(l0) + 1.0) / N0, cx1 = (double(l1) + 1.0) / N0;
-    for (int t = 0; t < bk.npq; ++t) {
-        const double b = bpq[t];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (bk.q[t] == q) { c0[q] = fma(b, ipow(cx0, bk.p[t]), c0[q]); c1[q] = fma(b, ipow(cx1, bk.p[t]), c1[q]); }
-    }
+    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
+    bkg_row_coeffs(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs(bk, bpq, has1 ? l1 : l0, N0, c1);
     const double* j0 = J + (size_t)l0 * N1;
     const double* j1 = J + (size_t)(has1 ? l1 : l0) * N1;
     double* d0 = DIFF + (size_t)l0 * N1;
@@ -608,11 +620,8 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
     for (int sx = 0; sx < 16; ++sx) {
         const int n = j + 256 * sx;
         const cplx z = u[R16_OUT(sx)];
-        const double cy = (double(n) + 1.0) * (1.0 / 4096.0);
-        const double B0 = fma(fma(fma(c0[3], cy, c0[2]), cy, c0[1]), cy, c0[0]);
-        const double B1 = fma(fma(fma(c1[3], cy, c1[2]), cy, c1[1]), cy, c1[0]);
-        d0[n] = j0[n] - B0 - z.x;
-        if (has1) d1[n] = j1[n] - B1 + z.y;
+        d0[n] = j0[n] - bkg_eval(bk, c0, n, N1) - z.x;
+        if (has1) d1[n] = j1[n] - bkg_eval(bk, c1, n, N1) + z.y;
     }
 }
 
@@ -794,34 +803,38 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
     }
 }
 
-// Delta: rowmom[l][q] = sum_n J[l][n] cy^q  (q <= 3), then delta[pq] = SCALE * sum_l cx^p rowmom[l][q]
+// Delta: rowmom[l][q] = sum_n J[l][n] tby[q][n], then delta[t] = SCALE * sum_l tbx[p[t]][l] rowmom[l][q[t]]
 // (= PreDEL[pq][0][0], SFFTSubtract.py:706-729, evaluated in real space: only element [0][0] is ever read).
-__global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J, double* __restrict__ rowmom, int N0, int N1)
+__global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J, double* __restrict__ rowmom, int N0, int N1,
+                                                   const double* __restrict__ tby, int nq)
 {
     const int l = blockIdx.x, tid = threadIdx.x;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[SFFT_MAX_BQ];
+#pragma unroll
+    for (int q = 0; q < SFFT_MAX_BQ; ++q) acc[q] = 0.0;
     for (int n = tid; n < N1; n += 256) {
         const double v = J[(size_t)l * N1 + n];
-        const double cy = (double(n) + 1.0) / N1;
-        acc[0] += v; acc[1] = fma(v, cy, acc[1]); acc[2] = fma(v, cy * cy, acc[2]); acc[3] = fma(v, cy * cy * cy, acc[3]);
+#pragma unroll
+        for (int q = 0; q < SFFT_MAX_BQ; ++q) if (q < nq) acc[q] = fma(v, tby[(size_t)q * N1 + n], acc[q]);
     }
-    __shared__ double red[4][4];
-    for (int q = 0; q < 4; ++q) {
+    __shared__ double red[4][SFFT_MAX_BQ];
+#pragma unroll
+    for (int q = 0; q < SFFT_MAX_BQ; ++q) {
         double u = acc[q];
         for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
         if ((tid & 63) == 0) red[tid >> 6][q] = u;
     }
     __syncthreads();
-    if (tid < 4) rowmom[(size_t)l * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < SFFT_MAX_BQ) rowmom[(size_t)l * SFFT_MAX_BQ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 __global__ void __launch_bounds__(256) delta_finish(const double* __restrict__ rowmom, double* __restrict__ delta, int N0,
                                                     BkgArgs bk, double scale)
 {
     const int pq = blockIdx.x, tid = threadIdx.x;
-    const int p = bk.p[pq], q = bk.q[pq];
+    const int pi = bk.p[pq], q = bk.q[pq];
     double acc = 0.0;
-    for (int l = tid; l < N0; l += 256) acc = fma(ipow((double(l) + 1.0) / N0, p), rowmom[(size_t)l * 4 + q], acc);
+    for (int l = tid; l < N0; l += 256) acc = fma(bk.tbx[(size_t)pi * N0 + l], rowmom[(size_t)l * SFFT_MAX_BQ + q], acc);
     __shared__ double red[4];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
@@ -842,6 +855,9 @@ struct FillArgs {
     int omg_off;          // patches offset of Omega pair 0; pair (i'<=i) index = i'*Fij - i'(i'-1)/2 + (i - i')
     int gam_off;          // Gam pair (ij, pq) at gam_off + (ij*Fpq+pq)*PHg*PHg
     int the_off;          // Theta pair ij at the_off + ij*PHg*PHg
+    // tied scaling (B-spline constant photometric ratio, BSplineSFFT.py:2201-2272): the unknowns tie_first + k*tie_stride,
+    // k < tie_cnt, are one unknown; its row / column is the SUM of theirs.  tie_cnt = 0: no tie.
+    int tie_first, tie_cnt, tie_stride;
 };
 
 __device__ __forceinline__ double omg_at(const double* P, const FillArgs& f, int i8, int ij, int r0, int r1)
@@ -900,6 +916,17 @@ __device__ double sys_element(const double* P, const double* phi, const double* 
     return phi[(R - f.Fijab) * f.Fpq + (C - f.Fijab)];
 }
 
+// element of the (possibly tied) system: sum over the members of the row group and of the column group
+__device__ double sys_group_element(const double* P, const double* phi, const double* delta, const FillArgs& f, int R, int C, int NEQ)
+{
+    const int nr = (f.tie_cnt && R == f.tie_first) ? f.tie_cnt : 1;
+    const int nc = (f.tie_cnt && C == f.tie_first) ? f.tie_cnt : 1;
+    double acc = 0.0;
+    for (int a = 0; a < nr; ++a)
+        for (int b = 0; b < nc; ++b) acc += sys_element(P, phi, delta, f, R + a * f.tie_stride, C + b * f.tie_stride, NEQ);
+    return acc;
+}
+
 __global__ void __launch_bounds__(256) fill_system(const double* __restrict__ P, const double* __restrict__ phi,
                                                    const double* __restrict__ delta, FillArgs f, const int* __restrict__ idx,
                                                    int n, int NEQ, double* __restrict__ out, int ld,
@@ -911,16 +938,16 @@ __global__ void __launch_bounds__(256) fill_system(const double* __restrict__ P,
     if (Rp == n && Cp == n) { if (out) out[(size_t)n * ld + n] = 0.0; return; }
     if (Rp == n) {   // rhs row (and optional separate vector)
         const int C = idx ? idx[Cp] : Cp;
-        const double v = sys_element(P, phi, delta, f, C, NEQ, NEQ);
+        const double v = sys_group_element(P, phi, delta, f, C, NEQ, NEQ);
         if (out) out[(size_t)n * ld + Cp] = v;
         if (rhs_vec) rhs_vec[Cp] = v;
         return;
     }
     if (!out) return;
     const int R = idx ? idx[Rp] : Rp;
-    if (Cp == n) { out[(size_t)Rp * ld + n] = sys_element(P, phi, delta, f, R, NEQ, NEQ); return; }
+    if (Cp == n) { out[(size_t)Rp * ld + n] = sys_group_element(P, phi, delta, f, R, NEQ, NEQ); return; }
     const int C = idx ? idx[Cp] : Cp;
-    out[(size_t)Rp * ld + Cp] = sys_element(P, phi, delta, f, R, C, NEQ);
+    out[(size_t)Rp * ld + Cp] = sys_group_element(P, phi, delta, f, R, C, NEQ);
 }
 
 // plain LHMAT export for sfft_get_system (no border)
@@ -1207,12 +1234,14 @@ __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__
     }
 }
 
-// Extend_Solution scatter (SFFTConfigure.py:1299-1311): solution[idx[i]] = x[i], forbidden entries stay zero
+// Extend_Solution / Restore_Solution scatter (SFFTConfigure.py:1299-1311; BSplineSFFT.py:2274-2338):
+// solution[idx[i]] = x[i]; removed entries stay zero, tied entries all receive the value of their representative
 __global__ void __launch_bounds__(256) scatter_solution(const double* __restrict__ xv, int n, const int* __restrict__ idx,
-                                                        double* __restrict__ solution, int NEQ)
+                                                        double* __restrict__ solution, int NEQ, int tie_first, int tie_cnt, int tie_stride)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < n) solution[idx ? idx[t] : t] = xv[t];
+    if (t >= 1 && t < tie_cnt) solution[tie_first + t * tie_stride] = xv[tie_first];   // position of tie_first in x equals its value
 }
 
 // ---- LU with partial pivoting (fallback; matches the reference's getrf/gesv semantics) --------------------
@@ -1266,14 +1295,12 @@ __global__ void __launch_bounds__(256) lu_rank1(double* __restrict__ A, int ld, 
     }
 }
 
-__global__ void __launch_bounds__(1024) lu_backsolve(const double* __restrict__ A, int ld, int n, const int* __restrict__ idx,
-                                                      double* __restrict__ solution, int NEQ)
+__global__ void __launch_bounds__(1024) lu_backsolve(const double* __restrict__ A, int ld, int n, double* __restrict__ xv)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* yv = reinterpret_cast<double*>(smem_raw);
     const int tid = threadIdx.x;
     for (int c = tid; c < n; c += 1024) yv[c] = A[(size_t)c * ld + n];
-    for (int c = tid; c < NEQ; c += 1024) solution[c] = 0.0;
     __syncthreads();
     for (int i = n - 1; i >= 0; --i) {
         if (tid == 0) yv[i] = yv[i] / A[(size_t)i * ld + i];
@@ -1282,7 +1309,7 @@ __global__ void __launch_bounds__(1024) lu_backsolve(const double* __restrict__ 
         for (int c = tid; c < i; c += 1024) yv[c] = fma(-A[(size_t)c * ld + i], xi, yv[c]);
         __syncthreads();
     }
-    for (int i = tid; i < n; i += 1024) solution[idx ? idx[i] : i] = yv[i];
+    for (int i = tid; i < n; i += 1024) xv[i] = yv[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1400,13 +1427,17 @@ struct sfft_plan {
     int TC = 1, MS = 0;                 // column pass tiling
     int nt_rows = 64, nt_cols = 64;
     size_t lds_rows = 0, lds_cols = 0;
-    int ref_ij[10][2], ref_pq[10][2];
+    // separable spatial bases (polynomial powers or B-spline basis functions), tabulated per axis
+    int nkx = 0, nky = 0, nbx = 0, nby = 0;
+    std::vector<int> kpair, bpair;      // [Fij][2] / [Fpq][2]: (x-factor, y-factor) of kernel term ij / background term pq
+    double *d_kbx = nullptr, *d_kby = nullptr, *d_tbx = nullptr, *d_tby = nullptr;   // [nkx][N0], [nky][N1], [nbx][N0], [nby][N1]
+    int mode = 0;                       // 0: free scaling, 1: unknowns ij00[1:] removed, 2: unknowns ij00 tied together
     BkgArgs bk;
     // device tables
-    int* d_idx = nullptr;               // [NEQfs] (only when cpr)
+    int* d_idx = nullptr;               // [NEQfs] (only when mode != 0)
     double* d_phi = nullptr;            // [Fpq*Fpq]
-    cplx* d_Xp = nullptr;               // [4][N0]
-    cplx* d_Yq = nullptr;               // [4][Nhp]
+    cplx* d_Xp = nullptr;               // [nbx][N0]   DFT of the background x-factors
+    cplx* d_Yq = nullptr;               // [nby][Nhp]  DFT of the background y-factors (half spectrum)
     cplx* d_w0tab = nullptr; int hm = 1;   // [N0][hm] twiddle rows of the pruned column transform
     G1Pass* d_passes = nullptr;
     PatchJob* d_jobs = nullptr;
@@ -1570,47 +1601,55 @@ static AxisDev axis_dev(const AxisHost& a)
     return d;
 }
 
-// DFT of the polynomial factor v[x] = ((x+1)/N)^e over one axis, e = 0..3, direct O(N^2) in extended precision
-static void poly_axis_dft(int N, int e, int nout, std::vector<cplx>& out)
+static double ipow_host(double x, int e) { double r = 1.0; for (int t = 0; t < e; ++t) r *= x; return r; }
+
+struct BasisSpec {
+    int nkx = 0, nky = 0, nbx = 0, nby = 0, Fij = 0, Fpq = 0, mode = 0;
+    std::vector<double> kbx, kby, tbx, tby;   // [nkx][N0], [nky][N1], [nbx][N0], [nby][N1]
+    std::vector<int> kpair, bpair;            // [Fij][2], [Fpq][2]
+};
+
+// DFT of a tabulated 1-D factor, direct O(N^2) in extended precision; an all-ones factor gives exactly N * delta
+static void table_axis_dft(const double* v, int N, int nout, std::vector<cplx>& out, bool* is_const)
 {
     const long double PI = acosl(-1.0L);
-    std::vector<long double> v(N), cr(N), ci(N);
-    for (int x = 0; x < N; ++x) {
-        long double c = ((long double)x + 1.0L) / N, r = 1.0L;
-        for (int t = 0; t < e; ++t) r *= c;
-        v[x] = (long double)(double)r;   // the device computes the factor in double
-        const long double ang = -2.0L * PI * x / N;
-        cr[x] = cosl(ang); ci[x] = sinl(ang);
-    }
-    out.resize(nout);
+    bool ones = true;
+    for (int x = 0; x < N; ++x) ones &= (v[x] == 1.0);
+    *is_const = ones;
+    out.assign(nout, make_double2(0.0, 0.0));
+    if (ones) { out[0] = make_double2((double)N, 0.0); return; }
+    std::vector<long double> cr(N), ci(N);
+    for (int x = 0; x < N; ++x) { const long double ang = -2.0L * PI * x / N; cr[x] = cosl(ang); ci[x] = sinl(ang); }
     for (int k = 0; k < nout; ++k) {
         long double sr = 0.0L, si = 0.0L;
         long long q = 0;
         for (int x = 0; x < N; ++x) {
-            sr += v[x] * cr[q]; si += v[x] * ci[q];
+            sr += (long double)v[x] * cr[q]; si += (long double)v[x] * ci[q];
             q += k; if (q >= N) q -= N;
         }
         out[k] = make_double2((double)sr, (double)si);
     }
 }
 
-extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int DK, int DB, int cpr, int device)
+static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const BasisSpec& BS, int DK, int DB, int device)
 {
     if (!out) return set_err(SFFT_ERR_INVALID_ARG, "plan pointer is NULL");
     *out = nullptr;
-    if (DK < 0 || DK > 3) return set_err(SFFT_ERR_INVALID_ARG, "Input KerPolyOrder should be 0/1/2/3!");
-    if (DB < 0 || DB > 3) return set_err(SFFT_ERR_INVALID_ARG, "Input BGPolyOrder should be 0/1/2/3!");
     if (N0 < 8 || N1 < 8) return set_err(SFFT_ERR_INVALID_ARG, "Input Image has dramatically small size!");
     if (KerHW < 0 || KerHW > 32) return set_err(SFFT_ERR_INVALID_ARG, "KerHW must be in [0, 32]");
+    if (BS.Fij < 1 || BS.Fij > 64 || BS.Fpq < 1 || BS.Fpq > SFFT_MAX_PQ || BS.nby > SFFT_MAX_BQ || BS.nbx > 16 || BS.nkx > 16 || BS.nky > 16)
+        return set_err(SFFT_ERR_INVALID_ARG, "spatial basis too large: at most 64 kernel terms, 64 background terms, 16 factors per axis");
     HIPCHK(hipSetDevice(device));
     sfft_plan* p = new sfft_plan();
     p->dev = device;
     if (const char* ev = getenv("SFFT_G1_VARIANT")) p->g1_variant = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
-    p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->cpr = cpr ? 1 : 0;
+    p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = BS.mode != 0;
     p->L = 2 * KerHW + 1; p->Fab = p->L * p->L;
-    p->Fij = (DK + 1) * (DK + 2) / 2; p->Fpq = (DB + 1) * (DB + 2) / 2;
+    p->Fij = BS.Fij; p->Fpq = BS.Fpq;
+    p->nkx = BS.nkx; p->nky = BS.nky; p->nbx = BS.nbx; p->nby = BS.nby;
+    p->kpair = BS.kpair; p->bpair = BS.bpair;
     p->Fijab = p->Fij * p->Fab; p->NEQ = p->Fijab + p->Fpq;
     p->NEQfs = p->cpr ? p->NEQ - (p->Fij - 1) : p->NEQ;
     p->scale = 1.0 / ((double)N0 * (double)N1);
@@ -1641,13 +1680,18 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         PLAN_HIP(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
         PLAN_HIP(hipEventCreateWithFlags(&p->ev_pre, hipEventDisableTiming));
     }
-    {
-        int n = 0;
-        for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { p->ref_ij[n][0] = i; p->ref_ij[n][1] = j; ++n; }
-        n = 0;
-        for (int a = 0; a <= DB; ++a) for (int b = 0; b <= DB - a; ++b) { p->ref_pq[n][0] = a; p->ref_pq[n][1] = b; ++n; }
-        p->bk.npq = p->Fpq;
-        for (int t = 0; t < p->Fpq; ++t) { p->bk.p[t] = p->ref_pq[t][0]; p->bk.q[t] = p->ref_pq[t][1]; }
+    {   // basis tables on the device
+        PLAN_TRY(dev_alloc(p, &p->d_kbx, (size_t)BS.nkx * N0));
+        PLAN_TRY(dev_alloc(p, &p->d_kby, (size_t)BS.nky * N1));
+        PLAN_TRY(dev_alloc(p, &p->d_tbx, (size_t)BS.nbx * N0));
+        PLAN_TRY(dev_alloc(p, &p->d_tby, (size_t)BS.nby * N1));
+        PLAN_HIP(hipMemcpy(p->d_kbx, BS.kbx.data(), (size_t)BS.nkx * N0 * sizeof(double), hipMemcpyHostToDevice));
+        PLAN_HIP(hipMemcpy(p->d_kby, BS.kby.data(), (size_t)BS.nky * N1 * sizeof(double), hipMemcpyHostToDevice));
+        PLAN_HIP(hipMemcpy(p->d_tbx, BS.tbx.data(), (size_t)BS.nbx * N0 * sizeof(double), hipMemcpyHostToDevice));
+        PLAN_HIP(hipMemcpy(p->d_tby, BS.tby.data(), (size_t)BS.nby * N1 * sizeof(double), hipMemcpyHostToDevice));
+        memset(&p->bk, 0, sizeof(p->bk));
+        p->bk.npq = p->Fpq; p->bk.nq = BS.nby; p->bk.tbx = p->d_tbx; p->bk.tby = p->d_tby;
+        for (int t = 0; t < p->Fpq; ++t) { p->bk.p[t] = BS.bpair[2 * t]; p->bk.q[t] = BS.bpair[2 * t + 1]; }
     }
     PLAN_TRY(build_axis(p, p->ax0, N0));
     PLAN_TRY(build_axis(p, p->ax1, N1));
@@ -1681,7 +1725,8 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "linear system too large for the on-chip back substitution of this build");
     }
 
-    // index map of Remove_LSFStripes (SFFTSubtract.py:83-90)
+    // index map of Remove_LSFStripes (SFFTSubtract.py:83-90); with tied scaling (mode 2) the kept entry ij00[0]
+    // stands for the whole tied group
     if (p->cpr) {
         std::vector<int> idx;
         std::vector<char> forb(p->NEQ, 0);
@@ -1691,34 +1736,42 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         PLAN_TRY(dev_alloc(p, &p->d_idx, idx.size()));
         PLAN_HIP(hipMemcpy(p->d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    // PHI block: PrePHI[p'q',pq][0][0] = SCALE * sum_x T_p'q' T_pq  (SFFTSubtract.py:680-694), separable closed form
+    // PHI block: PrePHI[p'q',pq][0][0] = SCALE * sum_x T_p'q' T_pq  (SFFTSubtract.py:680-694); T is separable, so
+    // the sum factors into one sum per axis
     {
-        long double Sx[7], Sy[7];
-        for (int e = 0; e < 7; ++e) {
-            long double ax = 0.0L, ay = 0.0L;
-            for (int x = 0; x < N0; ++x) { long double c = ((long double)x + 1.0L) / N0, r = 1.0L; for (int t = 0; t < e; ++t) r *= c; ax += r; }
-            for (int y = 0; y < N1; ++y) { long double c = ((long double)y + 1.0L) / N1, r = 1.0L; for (int t = 0; t < e; ++t) r *= c; ay += r; }
-            Sx[e] = ax; Sy[e] = ay;
+        std::vector<long double> Gx((size_t)BS.nbx * BS.nbx), Gy((size_t)BS.nby * BS.nby);
+        for (int a = 0; a < BS.nbx; ++a) for (int b = 0; b < BS.nbx; ++b) {
+            long double acc = 0.0L;
+            for (int x = 0; x < N0; ++x) acc += (long double)BS.tbx[(size_t)a * N0 + x] * (long double)BS.tbx[(size_t)b * N0 + x];
+            Gx[(size_t)a * BS.nbx + b] = acc;
         }
-        std::vector<double> phi(p->Fpq * p->Fpq);
+        for (int a = 0; a < BS.nby; ++a) for (int b = 0; b < BS.nby; ++b) {
+            long double acc = 0.0L;
+            for (int y = 0; y < N1; ++y) acc += (long double)BS.tby[(size_t)a * N1 + y] * (long double)BS.tby[(size_t)b * N1 + y];
+            Gy[(size_t)a * BS.nby + b] = acc;
+        }
+        std::vector<double> phi((size_t)p->Fpq * p->Fpq);
         for (int a = 0; a < p->Fpq; ++a) for (int b = 0; b < p->Fpq; ++b)
-            phi[a * p->Fpq + b] = (double)((long double)p->scale * Sx[p->ref_pq[a][0] + p->ref_pq[b][0]] * Sy[p->ref_pq[a][1] + p->ref_pq[b][1]]);
+            phi[(size_t)a * p->Fpq + b] = (double)((long double)p->scale * Gx[(size_t)BS.bpair[2 * a] * BS.nbx + BS.bpair[2 * b]]
+                                                   * Gy[(size_t)BS.bpair[2 * a + 1] * BS.nby + BS.bpair[2 * b + 1]]);
         PLAN_TRY(dev_alloc(p, &p->d_phi, phi.size()));
         PLAN_HIP(hipMemcpy(p->d_phi, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    // rank-1 spectra of T_pq: FT_pq[l][m] = SCALE * Xp[l] * Yq[m]
+    // rank-1 spectra of T_pq: FT_pq[l][m] = SCALE * Xp[p][l] * Yq[q][m]
+    std::vector<char> const_x(BS.nbx, 0);
     {
-        PLAN_TRY(dev_alloc(p, &p->d_Xp, (size_t)4 * N0));
-        PLAN_TRY(dev_alloc(p, &p->d_Yq, (size_t)4 * p->Nhp));
-        PLAN_HIP(hipMemset(p->d_Yq, 0, (size_t)4 * p->Nhp * sizeof(cplx)));
-        for (int e = 0; e <= DB; ++e) {
-            std::vector<cplx> v;
-            // e = 0: the factor is the constant 1, whose DFT is exactly N * delta (what an FFT of T_00 returns)
-            poly_axis_dft(N0, e, N0, v);
-            if (e == 0) { for (int k = 0; k < N0; ++k) v[k] = make_double2(k == 0 ? (double)N0 : 0.0, 0.0); }
+        PLAN_TRY(dev_alloc(p, &p->d_Xp, (size_t)BS.nbx * N0));
+        PLAN_TRY(dev_alloc(p, &p->d_Yq, (size_t)BS.nby * p->Nhp));
+        PLAN_HIP(hipMemset(p->d_Yq, 0, (size_t)BS.nby * p->Nhp * sizeof(cplx)));
+        std::vector<cplx> v;
+        bool cst;
+        for (int e = 0; e < BS.nbx; ++e) {
+            table_axis_dft(BS.tbx.data() + (size_t)e * N0, N0, N0, v, &cst);
+            const_x[e] = cst;
             PLAN_HIP(hipMemcpy(p->d_Xp + (size_t)e * N0, v.data(), (size_t)N0 * sizeof(cplx), hipMemcpyHostToDevice));
-            poly_axis_dft(N1, e, p->Nh, v);
-            if (e == 0) { for (int k = 0; k < p->Nh; ++k) v[k] = make_double2(k == 0 ? (double)N1 : 0.0, 0.0); }
+        }
+        for (int e = 0; e < BS.nby; ++e) {
+            table_axis_dft(BS.tby.data() + (size_t)e * N1, N1, p->Nh, v, &cst);
             PLAN_HIP(hipMemcpy(p->d_Yq + (size_t)e * p->Nhp, v.data(), (size_t)p->Nh * sizeof(cplx), hipMemcpyHostToDevice));
         }
     }
@@ -1729,7 +1782,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         const int PHo = 2 * hO + 1, PHg = 2 * hG + 1;
         int S = 1;
         const int colblocks = (p->Nh + 63) / 64;
-        const int npass_est = p->Fij * (p->Fij + 1) / 2 + p->Fij * DB + p->Fij;
+        const int npass_est = p->Fij * (p->Fij + 1) / 2 + p->Fij * BS.nbx + p->Fij;
         while (S < 16 && (long long)colblocks * S * npass_est < 6144 && N0 / (2 * S) >= 64) S *= 2;
         p->S = S;
         p->rows_per_chunk = (N0 + S - 1) / S;
@@ -1739,15 +1792,15 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
             p->passes.push_back(d); goff += (long long)S * (2 * h + 1) * p->Nhp;
             return (int)p->passes.size() - 1;
         };
-        std::vector<int> omg_pass, the_pass, gam_pass(p->Fij * (DB + 1));
+        std::vector<int> omg_pass, the_pass, gam_pass((size_t)p->Fij * BS.nbx);
         for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) omg_pass.push_back(add_pass(a, b, 0, hO));
         p->n_omg = (int)omg_pass.size();
         for (int a = 0; a < p->Fij; ++a) the_pass.push_back(add_pass(a, p->Fij, 0, hG));
         p->n_the = p->Fij;
-        for (int a = 0; a < p->Fij; ++a) for (int e = 1; e <= DB; ++e) gam_pass[a * (DB + 1) + e] = add_pass(a, -1, e, hG);
-        p->n_gamp = p->Fij * DB;
-        for (int a = 0; a < p->Fij; ++a) gam_pass[a * (DB + 1) + 0] = add_pass(a, -1, 0, hG);
-        p->n_gam0 = p->Fij;
+        // Gamma column-factor passes: dense ones first, then those whose x-factor is the constant 1 (Xp = N0 * delta)
+        p->n_gamp = 0; p->n_gam0 = 0;
+        for (int a = 0; a < p->Fij; ++a) for (int e = 0; e < BS.nbx; ++e) if (!const_x[e]) { gam_pass[(size_t)a * BS.nbx + e] = add_pass(a, -1, e, hG); ++p->n_gamp; }
+        for (int a = 0; a < p->Fij; ++a) for (int e = 0; e < BS.nbx; ++e) if (const_x[e]) { gam_pass[(size_t)a * BS.nbx + e] = add_pass(a, -1, e, hG); ++p->n_gam0; }
         int poff = 0;
         auto add_job = [&](int pass, int yq, int h, double scale) {
             PatchJob j; j.pass = pass; j.yq = yq; j.h = h; j.patch_off = poff; j.scale = scale;
@@ -1757,7 +1810,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         for (int k = 0; k < p->n_omg; ++k) add_job(omg_pass[k], -1, hO, p->scale * p->scale);   // PreOMG = SCALE*Re[SCALE*DFT] (SFFTSubtract.py:233-240)
         p->fa.gam_off = poff;
         for (int a = 0; a < p->Fij; ++a) for (int q = 0; q < p->Fpq; ++q)
-            add_job(gam_pass[a * (DB + 1) + p->ref_pq[q][0]], p->ref_pq[q][1], hG, p->scale);     // PreGAM = Re[SCALE*DFT] (:262-268)
+            add_job(gam_pass[(size_t)a * BS.nbx + BS.bpair[2 * q]], BS.bpair[2 * q + 1], hG, p->scale);   // PreGAM = Re[SCALE*DFT] (:262-268)
         p->n_gam = p->Fij * p->Fpq;
         p->fa.the_off = poff;
         for (int a = 0; a < p->Fij; ++a) add_job(the_pass[a], -1, hG, p->scale);                  // PreTHE = Re[SCALE*DFT] (:353-362)
@@ -1774,6 +1827,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
         p->fa.Fij = p->Fij; p->fa.Fpq = p->Fpq; p->fa.Fab = p->Fab; p->fa.Fijab = p->Fijab; p->fa.L1 = p->L;
         p->fa.w0 = KerHW; p->fa.w1 = KerHW; p->fa.h_omg = hO; p->fa.h_gam = hG;
+        p->fa.tie_first = KerHW * p->L + KerHW; p->fa.tie_stride = p->Fab; p->fa.tie_cnt = (p->mode == 2) ? p->Fij : 0;
     }
     PLAN_TRY(dev_alloc(p, &p->d_spec, (size_t)(p->Fij + 1) * N0 * p->Nhp));
     p->ld = (p->NEQfs + 1 + 3) & ~3;
@@ -1787,7 +1841,7 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
     PLAN_TRY(dev_alloc(p, &p->d_sol, (size_t)p->NEQ));
     PLAN_TRY(dev_alloc(p, &p->d_ctab, (size_t)p->Fij * p->L * p->Nhp));
     PLAN_TRY(dev_alloc(p, &p->d_soff, (size_t)p->Fij));
-    PLAN_TRY(dev_alloc(p, &p->d_rowmom, (size_t)N0 * 4));
+    PLAN_TRY(dev_alloc(p, &p->d_rowmom, (size_t)N0 * SFFT_MAX_BQ));
     PLAN_TRY(dev_alloc(p, &p->d_delta, (size_t)p->Fpq));
     PLAN_TRY(dev_alloc(p, &p->d_status, (size_t)1));
     PLAN_HIP(hipMemset(p->d_status, 0, sizeof(int)));
@@ -1796,6 +1850,49 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
 #undef PLAN_HIP
     *out = p;
     return SFFT_OK;
+}
+
+// SingleSFFTConfigure.SSC with polynomial spatial variation: kernel terms cx^i cy^j, i + j <= DK, background terms
+// cx^p cy^q, p + q <= DB (REF_ij / REF_pq order, SFFTSubtract.py:62-64), constant scaling by stripe removal.
+extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int DK, int DB, int cpr, int device)
+{
+    if (DK < 0 || DK > 3) return set_err(SFFT_ERR_INVALID_ARG, "Input KerPolyOrder should be 0/1/2/3!");
+    if (DB < 0 || DB > 3) return set_err(SFFT_ERR_INVALID_ARG, "Input BGPolyOrder should be 0/1/2/3!");
+    if (N0 < 8 || N1 < 8) return set_err(SFFT_ERR_INVALID_ARG, "Input Image has dramatically small size!");
+    BasisSpec B;
+    B.nkx = B.nky = DK + 1; B.nbx = B.nby = DB + 1; B.mode = cpr ? 1 : 0;
+    auto powers = [](int n, int N, std::vector<double>& t) {
+        t.resize((size_t)n * N);
+        for (int e = 0; e < n; ++e) for (int x = 0; x < N; ++x) t[(size_t)e * N + x] = ipow_host((double(x) + 1.0) / N, e);
+    };
+    powers(B.nkx, N0, B.kbx); powers(B.nky, N1, B.kby); powers(B.nbx, N0, B.tbx); powers(B.nby, N1, B.tby);
+    for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { B.kpair.push_back(i); B.kpair.push_back(j); }
+    for (int a = 0; a <= DB; ++a) for (int b = 0; b <= DB - a; ++b) { B.bpair.push_back(a); B.bpair.push_back(b); }
+    B.Fij = (int)B.kpair.size() / 2; B.Fpq = (int)B.bpair.size() / 2;
+    return plan_create_impl(out, N0, N1, KerHW, B, DK, DB, device);
+}
+
+// General separable spatial bases (B-spline SFFT, sfft/BSplineSFFT.py:2536-2607): the caller tabulates the 1-D basis
+// functions per axis (host pointers) and lists which (x-factor, y-factor) pair makes each kernel / background term.
+extern "C" int sfft_plan_create_basis(sfft_plan** out, int N0, int N1, int KerHW,
+                                      int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
+                                      int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
+                                      int scaling_mode, int device)
+{
+    if (!kbx || !kby || !tbx || !tby || !ker_pairs || !bkg_pairs) return set_err(SFFT_ERR_INVALID_ARG, "NULL basis table");
+    if (scaling_mode < 0 || scaling_mode > 2) return set_err(SFFT_ERR_INVALID_ARG, "scaling_mode must be 0, 1 or 2");
+    if (N0 < 8 || N1 < 8) return set_err(SFFT_ERR_INVALID_ARG, "Input Image has dramatically small size!");
+    if (nkx < 1 || nky < 1 || nbx < 1 || nby < 1 || Fij < 1 || Fpq < 1) return set_err(SFFT_ERR_INVALID_ARG, "empty basis");
+    BasisSpec B;
+    B.nkx = nkx; B.nky = nky; B.nbx = nbx; B.nby = nby; B.Fij = Fij; B.Fpq = Fpq; B.mode = scaling_mode;
+    B.kbx.assign(kbx, kbx + (size_t)nkx * N0); B.kby.assign(kby, kby + (size_t)nky * N1);
+    B.tbx.assign(tbx, tbx + (size_t)nbx * N0); B.tby.assign(tby, tby + (size_t)nby * N1);
+    B.kpair.assign(ker_pairs, ker_pairs + 2 * (size_t)Fij); B.bpair.assign(bkg_pairs, bkg_pairs + 2 * (size_t)Fpq);
+    for (int k = 0; k < Fij; ++k) if (B.kpair[2 * k] < 0 || B.kpair[2 * k] >= nkx || B.kpair[2 * k + 1] < 0 || B.kpair[2 * k + 1] >= nky)
+        return set_err(SFFT_ERR_INVALID_ARG, "kernel term refers to a basis factor that does not exist");
+    for (int k = 0; k < Fpq; ++k) if (B.bpair[2 * k] < 0 || B.bpair[2 * k] >= nbx || B.bpair[2 * k + 1] < 0 || B.bpair[2 * k + 1] >= nby)
+        return set_err(SFFT_ERR_INVALID_ARG, "background term refers to a basis factor that does not exist");
+    return plan_create_impl(out, N0, N1, KerHW, B, -1, -1, device);
 }
 
 static void free_axis(AxisHost& a)
@@ -1815,7 +1912,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     hipSetDevice(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr};
+                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -1935,7 +2032,7 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
     if (p->ax1.big) {
         const int npr = (p->N0 + 1) / 2;
         for (int k = 0; k < nplanes; ++k) {
-            hipLaunchKernelGGL(pack_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, ra.src[k], ra.ei[k], ra.ej[k], p->d_big1, p->N0, p->N1);
+            hipLaunchKernelGGL(pack_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, ra.src[k], ra.wx[k], ra.wy[k], p->d_big1, p->N0, p->N1);
             big_axis_transform(p, p->ax1, p->d_big1, p->d_big2, 1, p->N1, npr, false, 0, s);
             hipLaunchKernelGGL(untangle_rows, dim3((p->Nh + 255) / 256, npr), dim3(256), 0, s, p->d_big1, dst + (size_t)k * p->N0 * p->Nhp,
                                p->N0, p->N1, p->Nh, p->Nhp, p->scale);
@@ -1948,6 +2045,29 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
     LAUNCH_CHECK();
     launch_cols(p, dst, nplanes, 0, s);
     LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+// forward spectra of the Fij kernel-basis planes of image d_I (and, when d_J is given, of d_J itself as plane Fij)
+static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s)
+{
+    const int total = p->Fij + (d_J ? 1 : 0);
+    const size_t plane_sz = (size_t)p->N0 * p->Nhp;
+    for (int k0 = 0; k0 < total; k0 += SFFT_MAX_PLANES) {
+        const int n = std::min(SFFT_MAX_PLANES, total - k0);
+        RowsArgs ra;
+        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = nullptr; ra.wy[u] = nullptr; }
+        for (int u = 0; u < n; ++u) {
+            const int k = k0 + u;
+            if (k < p->Fij) {
+                ra.src[u] = d_I;
+                ra.wx[u] = p->d_kbx + (size_t)p->kpair[2 * k] * p->N0;
+                ra.wy[u] = p->d_kby + (size_t)p->kpair[2 * k + 1] * p->N1;
+            } else ra.src[u] = d_J;
+        }
+        int rc = forward_planes(p, ra, n, dst + (size_t)k0 * plane_sz, s);
+        if (rc) return rc;
+    }
     return SFFT_OK;
 }
 
@@ -2015,7 +2135,8 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
         const int nslice = rows_below > 0 ? std::min(BACK_SLICES, (rows_below + CB - 1) / CB) : 1;
         hipLaunchKernelGGL(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter, p->d_rd);
     }
-    hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ);
+    hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
+                       p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -2031,7 +2152,10 @@ static int run_lu(sfft_plan* p, double* d_solution, hipStream_t s)
     }
     LAUNCH_CHECK();
     const size_t lds = (size_t)(n + 2) * 8;
-    hipLaunchKernelGGL(lu_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_idx, d_solution, p->NEQ);
+    hipLaunchKernelGGL(lu_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_xv);
+    HIPCHK(hipMemsetAsync(d_solution, 0, (size_t)p->NEQ * sizeof(double), s));
+    hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
+                       p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -2046,12 +2170,8 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     int rc;
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
-        RowsArgs ra;
-        for (int k = 0; k < p->Fij; ++k) { ra.src[k] = d_I; ra.ei[k] = p->ref_ij[k][0]; ra.ej[k] = p->ref_ij[k][1]; }
-        ra.src[p->Fij] = d_J; ra.ei[p->Fij] = 0; ra.ej[p->Fij] = 0;
-        for (int k = p->Fij + 1; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
-        if ((rc = forward_planes(p, ra, p->Fij + 1, p->d_spec, s))) return rc;
-        hipLaunchKernelGGL(row_moments, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1);
+        if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s))) return rc;
+        hipLaunchKernelGGL(row_moments, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
     }
@@ -2114,10 +2234,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
 static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t s)
 {
     StageTimer t(p, SFFT_ST_PRELIM_APPLY, s);
-    RowsArgs ra;
-    for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
-    for (int k = 0; k < p->Fij; ++k) { ra.src[k] = d_I; ra.ei[k] = p->ref_ij[k][0]; ra.ej[k] = p->ref_ij[k][1]; }
-    return forward_planes(p, ra, p->Fij, dst, s);
+    return forward_basis_planes(p, d_I, nullptr, dst, s);
 }
 
 // Construct_FDIFF + inverse transform + DIFF epilogue from the spectra FI; FD is a scratch plane
@@ -2216,12 +2333,12 @@ extern "C" int sfft_get_system(sfft_plan* p, double* d_LHMAT, double* d_RHb, voi
 extern "C" int sfft_dbg_forward_spectrum(sfft_plan* p, const double* d_I, int i, int j, double* d_spec_out, void* stream)
 {
     if (!p || !d_I || !d_spec_out) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
-    if (i < 0 || j < 0 || i > 3 || j > 3) return set_err(SFFT_ERR_INVALID_ARG, "exponents must be in [0,3]");
+    if (i < 0 || j < 0 || i >= p->nkx || j >= p->nky) return set_err(SFFT_ERR_INVALID_ARG, "basis factor index out of range for this plan");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(p->dev));
     RowsArgs ra;
-    for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.ei[k] = ra.ej[k] = 0; }
-    ra.src[0] = d_I; ra.ei[0] = i; ra.ej[0] = j;
+    for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.wx[k] = nullptr; ra.wy[k] = nullptr; }
+    ra.src[0] = d_I; ra.wx[0] = p->d_kbx + (size_t)i * p->N0; ra.wy[0] = p->d_kby + (size_t)j * p->N1;
     int rc = forward_planes(p, ra, 1, p->d_spec, s);
     if (rc) return rc;
     hipLaunchKernelGGL(copy_spectrum, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec_out, p->N0, p->Nh, p->Nhp);

@@ -8,12 +8,29 @@ from . import _lib
 
 
 class Plan:
-    def __init__(self, N0, N1, KerHW, DK, DB, ConstPhotRatio, device=0):
+    def __init__(self, N0, N1, KerHW, DK=None, DB=None, ConstPhotRatio=True, device=0, basis=None):
+        """Polynomial plan (DK, DB, ConstPhotRatio) or, with `basis`, a plan over tabulated separable bases:
+        basis = dict(kbx=[nkx,N0], kby=[nky,N1], ker_pairs=[Fij,2], tbx=[nbx,N0], tby=[nby,N1], bkg_pairs=[Fpq,2],
+                     scaling_mode=0|1|2)   (see sfft_plan_create_basis in include/sfft_amd.h)."""
         self._h = ctypes.c_void_p()
         self.device = int(device)
-        self.key = (int(device), int(N0), int(N1), int(KerHW), int(DK), int(DB), bool(ConstPhotRatio))
-        rc = _lib.lib().sfft_plan_create(ctypes.byref(self._h), int(N0), int(N1), int(KerHW), int(DK), int(DB),
-                                         1 if ConstPhotRatio else 0, int(device))
+        if basis is None:
+            rc = _lib.lib().sfft_plan_create(ctypes.byref(self._h), int(N0), int(N1), int(KerHW), int(DK), int(DB),
+                                             1 if ConstPhotRatio else 0, int(device))
+        else:
+            import numpy as np
+            f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+            i4 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+            kbx, kby, tbx, tby = f8(basis["kbx"]), f8(basis["kby"]), f8(basis["tbx"]), f8(basis["tby"])
+            kp, bp = i4(basis["ker_pairs"]), i4(basis["bkg_pairs"])
+            assert kbx.shape[1] == N0 and tbx.shape[1] == N0 and kby.shape[1] == N1 and tby.shape[1] == N1
+            assert kp.ndim == 2 and kp.shape[1] == 2 and bp.ndim == 2 and bp.shape[1] == 2
+            self._keep = (kbx, kby, tbx, tby, kp, bp)
+            rc = _lib.lib().sfft_plan_create_basis(
+                ctypes.byref(self._h), int(N0), int(N1), int(KerHW),
+                kbx.shape[0], kby.shape[0], kbx.ctypes.data, kby.ctypes.data, kp.shape[0], kp.ctypes.data,
+                tbx.shape[0], tby.shape[0], tbx.ctypes.data, tby.ctypes.data, bp.shape[0], bp.ctypes.data,
+                int(basis.get("scaling_mode", 0)), int(device))
         _lib.check(rc)
         self.N0, self.N1 = int(N0), int(N1)
         self.NEQ = self.query("NEQ")

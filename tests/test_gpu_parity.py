@@ -51,7 +51,7 @@ def test_forward_spectrum_matches_numpy_fft2(dev, shape, ij):
     N0, N1 = shape
     rng = np.random.default_rng(N0 * 7 + N1)
     img = rng.normal(size=shape) * 50 + 10
-    plan = get_plan(N0, N1, 1, 0, 0, True, dev.index)
+    plan = get_plan(N0, N1, 1, 2, 0, True, dev.index)
     F = plan.forward_spectrum(_to(dev, img), ij[0], ij[1]).cpu().numpy()
     cx = ((np.arange(N0) + 1.0) / N0)[:, None]
     cy = ((np.arange(N1) + 1.0) / N1)[None, :]
