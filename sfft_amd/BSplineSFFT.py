@@ -1,0 +1,246 @@
+"""B-spline form of SFFT on the HIP backend -- mirror of the core classes of sfft/BSplineSFFT.py
+(SingleSFFTConfigure.SSC :2536-2607, ElementalSFFTSubtract.ESS :3865-3877, GeneralSFFTSubtract.GSS :3880-3965,
+BSpline_Packet.BSP :3967-4356).
+
+The kernel's and the background's spatial variation are separable per term (a function of the row times a function of
+the column), for polynomials and B-splines alike; this module tabulates those 1-D factors on the host exactly like the
+reference (scipy.interpolate.BSpline, BSplineSFFT.py:2624-2645) and hands them to `sfft_plan_create_basis`.
+
+Supported scaling modes (BSplineSFFT.py:47-60): 'ENTANGLED' (SEPARATE_SCALING=False) and 'SEPARATE-CONSTANT'
+(SEPARATE_SCALING=True, ScaSpDegree=0).  'SEPARATE-VARYING' scaling and REGULARIZE_KERNEL are not built yet and raise.
+"""
+import os.path as pa
+import time
+
+import numpy as np
+import torch
+
+from .plan import Plan
+from .sfftcore.SFFTSubtract import (ElementalSFFTSubtract, ElementalSFFTSubtract_PureCupy, GeneralSFFTSubtract,
+                                    GeneralSFFTSubtract_PureCupy)
+from .utils import minifits
+
+__all__ = ["SingleSFFTConfigure", "ElementalSFFTSubtract", "GeneralSFFTSubtract", "GeneralSFFTSubtract_PureCupy",
+           "BSpline_Packet", "Create_BSplineBasis"]
+
+try:  # pragma: no cover - astropy is absent from the target image
+    from astropy.io import fits as _afits
+except Exception:
+    _afits = None
+
+
+def Create_BSplineBasis(N, IntKnot, BSplineDegree):
+    """Basis functions on the scaled pixel-centre coordinates (1..N)/N, boundary knots at 0.5/N and (N+0.5)/N
+    (BSplineSFFT.py:2624-2645).  Returns [number of control points][N] float64."""
+    from scipy.interpolate import BSpline
+    PixCoord = (1.0 + np.arange(N)) / N
+    Knot = np.concatenate(([0.5] * (BSplineDegree + 1), list(IntKnot), [N + 0.5] * (BSplineDegree + 1))) / N
+    Nc = len(IntKnot) + BSplineDegree + 1
+    out = []
+    for idx in range(Nc):
+        Coeff = (np.arange(Nc) == idx).astype(float)
+        out.append(BSpline(t=Knot, c=Coeff, k=BSplineDegree, extrapolate=False)(PixCoord))
+    return np.array(out).astype(np.float64)
+
+
+def _axis_tables(N0, N1, SpType, Degree, IntKnotX, IntKnotY):
+    if SpType == 'Polynomial':
+        cx = (np.arange(N0, dtype=np.float64) + 1.0) / N0
+        cy = (np.arange(N1, dtype=np.float64) + 1.0) / N1
+        bx = np.stack([np.ones(N0) if e == 0 else cx ** e for e in range(Degree + 1)])
+        by = np.stack([np.ones(N1) if e == 0 else cy ** e for e in range(Degree + 1)])
+        # integer powers by repeated multiplication, like the polynomial plan (bit-identical factors)
+        for e in range(2, Degree + 1):
+            bx[e] = bx[e - 1] * cx
+            by[e] = by[e - 1] * cy
+        pairs = [(i, j) for i in range(Degree + 1) for j in range(Degree + 1 - i)]
+    else:
+        bx = Create_BSplineBasis(N0, IntKnotX, Degree)
+        by = Create_BSplineBasis(N1, IntKnotY, Degree)
+        pairs = [(i, j) for i in range(bx.shape[0]) for j in range(by.shape[0])]
+    return bx, by, np.array(pairs, dtype=np.int32)
+
+
+_PLANS = {}
+
+
+class SingleSFFTConfigure:
+    @staticmethod
+    def SSC(NX, NY, KerHW=8, KerSpType='Polynomial', KerSpDegree=2, KerIntKnotX=[], KerIntKnotY=[],
+            SEPARATE_SCALING=True, ScaSpType='Polynomial', ScaSpDegree=0, ScaIntKnotX=[], ScaIntKnotY=[],
+            BkgSpType='Polynomial', BkgSpDegree=2, BkgIntKnotX=[], BkgIntKnotY=[],
+            REGULARIZE_KERNEL=False, IGNORE_LAPLACIAN_KERCENT=True, XY_REGULARIZE=None, WEIGHT_REGULARIZE=None,
+            LAMBDA_REGULARIZE=1e-6, BACKEND_4SUBTRACT='Cupy', MAX_THREADS_PER_BLOCK=8,
+            MINIMIZE_GPU_MEMORY_USAGE=False, NUM_CPU_THREADS_4SUBTRACT=8, VERBOSE_LEVEL=2, CUDA_DEVICE_4SUBTRACT=None):
+        """Same arguments as the reference (MAX_THREADS_PER_BLOCK, MINIMIZE_GPU_MEMORY_USAGE, NUM_CPU_THREADS_4SUBTRACT are
+        accepted and ignored: Greek planes are always streamed here).  Returns SFFTConfig = (SFFTParam_dict, SFFTModule_dict)."""
+        N0, N1, w0 = int(NX), int(NY), int(KerHW)
+        DK, DB = int(KerSpDegree), int(BkgSpDegree)
+        if BACKEND_4SUBTRACT not in ('Cupy', 'HIP'):
+            raise Exception("MeLOn ERROR: sfft_amd only provides the GPU backend (BACKEND_4SUBTRACT='Cupy'); there is no CPU path")
+        assert DK >= 0 and DB >= 0
+        assert KerSpType in ['Polynomial', 'B-Spline']
+        assert BkgSpType in ['Polynomial', 'B-Spline']
+        if KerSpType == 'B-Spline' and DK == 0:
+            assert len(KerIntKnotX) == 0 and len(KerIntKnotY) == 0   # otherwise, discontinuity
+        if BkgSpType == 'B-Spline' and DB == 0:
+            assert len(BkgIntKnotX) == 0 and len(BkgIntKnotY) == 0   # otherwise, discontinuity
+        # SCALING_MODE (BSplineSFFT.py:47-60)
+        if not SEPARATE_SCALING:
+            SCALING_MODE = 'ENTANGLED'
+        elif int(ScaSpDegree) == 0:
+            SCALING_MODE = 'SEPARATE-CONSTANT'
+        else:
+            SCALING_MODE = 'SEPARATE-VARYING'
+        if SCALING_MODE == 'SEPARATE-CONSTANT':
+            assert DK != 0   # otherwise, reduced to ENTANGLED
+        if SCALING_MODE == 'SEPARATE-VARYING':
+            raise NotImplementedError("MeLOn ERROR: SCALING_MODE 'SEPARATE-VARYING' (ScaSpDegree > 0) is not built in sfft_amd yet")
+        if REGULARIZE_KERNEL:
+            raise NotImplementedError("MeLOn ERROR: REGULARIZE_KERNEL is not built in sfft_amd yet")
+
+        kbx, kby, kpairs = _axis_tables(N0, N1, KerSpType, DK, KerIntKnotX, KerIntKnotY)
+        tbx, tby, bpairs = _axis_tables(N0, N1, BkgSpType, DB, BkgIntKnotX, BkgIntKnotY)
+        if SCALING_MODE == 'ENTANGLED':
+            mode = 0
+        else:
+            mode = 1 if KerSpType == 'Polynomial' else 2    # TweakLS: delete vs. sum the ij00 rows/columns (:2171-2272)
+        if CUDA_DEVICE_4SUBTRACT is None:
+            device = torch.cuda.current_device()
+        else:
+            device = int(CUDA_DEVICE_4SUBTRACT)
+        key = (device, N0, N1, w0, KerSpType, DK, tuple(KerIntKnotX), tuple(KerIntKnotY), BkgSpType, DB,
+               tuple(BkgIntKnotX), tuple(BkgIntKnotY), mode)
+        plan = _PLANS.get(key)
+        if plan is None:
+            if VERBOSE_LEVEL in [1, 2]:
+                print('\n --//--//--//--//-- TRIGGER SFFT COMPILATION [HIP] --//--//--//--//-- ')
+            plan = Plan(N0, N1, w0, device=device, basis=dict(kbx=kbx, kby=kby, ker_pairs=kpairs, tbx=tbx, tby=tby,
+                                                              bkg_pairs=bpairs, scaling_mode=mode))
+            if len(_PLANS) >= 3:
+                _PLANS.pop(next(iter(_PLANS)))
+            _PLANS[key] = plan
+
+        L0 = L1 = 2 * w0 + 1
+        Fab = L0 * L1
+        Fij, Fpq = len(kpairs), len(bpairs)
+        P = {}
+        P['KerHW'], P['KerSpType'], P['KerSpDegree'] = KerHW, KerSpType, KerSpDegree
+        P['KerIntKnotX'], P['KerIntKnotY'] = KerIntKnotX, KerIntKnotY
+        P['SEPARATE_SCALING'], P['SCALING_MODE'] = SEPARATE_SCALING, SCALING_MODE
+        P['BkgSpType'], P['BkgSpDegree'], P['BkgIntKnotX'], P['BkgIntKnotY'] = BkgSpType, BkgSpDegree, BkgIntKnotX, BkgIntKnotY
+        P['N0'], P['N1'], P['w0'], P['w1'], P['DK'], P['DB'] = N0, N1, w0, w0, DK, DB
+        P['SCALE'], P['SCALE_L'] = np.float64(1 / (N0 * N1)), np.float64(N0 * N1)
+        P['L0'], P['L1'], P['Fab'] = L0, L1, Fab
+        P['Fi'] = kbx.shape[0] if KerSpType == 'B-Spline' else -1
+        P['Fj'] = kby.shape[0] if KerSpType == 'B-Spline' else -1
+        P['Fp'] = tbx.shape[0] if BkgSpType == 'B-Spline' else -1
+        P['Fq'] = tby.shape[0] if BkgSpType == 'B-Spline' else -1
+        P['Fij'], P['Fpq'], P['Fijab'] = Fij, Fpq, Fij * Fab
+        P['FOMG'], P['FGAM'], P['FTHE'] = Fij ** 2, Fij * Fpq, Fij
+        P['FPSI'], P['FPHI'], P['FDEL'] = Fpq * Fij, Fpq ** 2, Fpq
+        P['NEQ'] = Fij * Fab + Fpq
+        P['NEQt'] = P['NEQ'] - Fij + 1 if mode != 0 else P['NEQ']
+        P['ConstPhotRatio'] = (mode != 0)
+        return (P, {'plan': plan, 'backend': 'HIP'})
+
+
+class BSpline_Packet:
+    @staticmethod
+    def BSP(FITS_REF, FITS_SCI, FITS_mREF, FITS_mSCI, FITS_DIFF=None, FITS_Solution=None,
+            ForceConv='REF', GKerHW=8, KerSpType='Polynomial', KerSpDegree=2, KerIntKnotX=[], KerIntKnotY=[],
+            SEPARATE_SCALING=True, ScaSpType='Polynomial', ScaSpDegree=0, ScaIntKnotX=[], ScaIntKnotY=[],
+            BkgSpType='Polynomial', BkgSpDegree=2, BkgIntKnotX=[], BkgIntKnotY=[],
+            REGULARIZE_KERNEL=False, IGNORE_LAPLACIAN_KERCENT=True, XY_REGULARIZE=None,
+            WEIGHT_REGULARIZE=None, LAMBDA_REGULARIZE=1e-6, BACKEND_4SUBTRACT='Cupy',
+            CUDA_DEVICE_4SUBTRACT='0', MAX_THREADS_PER_BLOCK=8, MINIMIZE_GPU_MEMORY_USAGE=False,
+            NUM_CPU_THREADS_4SUBTRACT=8, VERBOSE_LEVEL=2):
+        """FITS paths in, (Solution, PixA_DIFF) out; same parameters and conventions as the reference
+        (BSplineSFFT.py:3969-4356).  ForceConv='REF' -> DIFF = SCI - Conv(REF); 'SCI' -> DIFF = Conv(SCI) - REF."""
+        def read_T(path):
+            a = (_afits.getdata(path, ext=0) if _afits is not None else minifits.getdata(path)[0]).T
+            return np.ascontiguousarray(a, dtype=np.float64)
+        PixA_REF, PixA_SCI = read_T(FITS_REF), read_T(FITS_SCI)
+        PixA_mREF, PixA_mSCI = read_T(FITS_mREF), read_T(FITS_mSCI)
+        NaNmask_U = None
+        if np.isnan(PixA_REF).any() or np.isnan(PixA_SCI).any():
+            NaNmask_U = np.logical_or(np.isnan(PixA_REF), np.isnan(PixA_SCI))
+        assert np.sum(np.isnan(PixA_mREF)) == 0
+        assert np.sum(np.isnan(PixA_mSCI)) == 0
+        assert ForceConv in ['REF', 'SCI']
+        ConvdSide, KerHW = ForceConv, GKerHW
+        torch.cuda.set_device(int(CUDA_DEVICE_4SUBTRACT))
+        if VERBOSE_LEVEL in [0, 1, 2]:
+            print('MeLOn CheckPoint: TRIGGER Function Compilations of SFFT-SUBTRACTION!')
+        Tcomp_start = time.time()
+        SFFTConfig = SingleSFFTConfigure.SSC(
+            NX=PixA_REF.shape[0], NY=PixA_REF.shape[1], KerHW=KerHW, KerSpType=KerSpType, KerSpDegree=KerSpDegree,
+            KerIntKnotX=KerIntKnotX, KerIntKnotY=KerIntKnotY, SEPARATE_SCALING=SEPARATE_SCALING, ScaSpType=ScaSpType,
+            ScaSpDegree=ScaSpDegree, ScaIntKnotX=ScaIntKnotX, ScaIntKnotY=ScaIntKnotY, BkgSpType=BkgSpType,
+            BkgSpDegree=BkgSpDegree, BkgIntKnotX=BkgIntKnotX, BkgIntKnotY=BkgIntKnotY, REGULARIZE_KERNEL=REGULARIZE_KERNEL,
+            IGNORE_LAPLACIAN_KERCENT=IGNORE_LAPLACIAN_KERCENT, XY_REGULARIZE=XY_REGULARIZE, WEIGHT_REGULARIZE=WEIGHT_REGULARIZE,
+            LAMBDA_REGULARIZE=LAMBDA_REGULARIZE, BACKEND_4SUBTRACT=BACKEND_4SUBTRACT, VERBOSE_LEVEL=VERBOSE_LEVEL,
+            CUDA_DEVICE_4SUBTRACT=int(CUDA_DEVICE_4SUBTRACT))
+        if VERBOSE_LEVEL in [1, 2]:
+            print('\nMeLOn Report: FUNCTION COMPILATIONS OF SFFT-SUBTRACTION TAKES [%.3f s] \n' % (time.time() - Tcomp_start))
+        if ConvdSide == 'REF':
+            PixA_mI, PixA_mJ, PixA_I, PixA_J = PixA_mREF, PixA_mSCI, PixA_REF, PixA_SCI
+        else:
+            PixA_mI, PixA_mJ, PixA_I, PixA_J = PixA_mSCI, PixA_mREF, PixA_SCI, PixA_REF
+        if NaNmask_U is not None:
+            PixA_I, PixA_J = PixA_I.copy(), PixA_J.copy()
+            PixA_I[NaNmask_U] = PixA_mI[NaNmask_U]
+            PixA_J[NaNmask_U] = PixA_mJ[NaNmask_U]
+        Tsub_start = time.time()
+        Solution, PixA_DIFF = GeneralSFFTSubtract.GSS(PixA_I=PixA_I, PixA_J=PixA_J, PixA_mI=PixA_mI, PixA_mJ=PixA_mJ,
+                                                     SFFTConfig=SFFTConfig, ContamMask_I=None, VERBOSE_LEVEL=VERBOSE_LEVEL)[:2]
+        if VERBOSE_LEVEL in [1, 2]:
+            print('\nMeLOn Report: SFFT-SUBTRACTION TAKES [%.3f s] \n' % (time.time() - Tsub_start))
+        if NaNmask_U is not None:
+            PixA_DIFF[NaNmask_U] = np.nan
+        if ConvdSide == 'SCI':
+            PixA_DIFF = -PixA_DIFF
+
+        kw = [('NAME_REF', pa.basename(FITS_REF)), ('NAME_SCI', pa.basename(FITS_SCI)), ('BEND4SUB', BACKEND_4SUBTRACT),
+              ('CONVD', ConvdSide), ('KERHW', KerHW), ('KSPTYPE', str(KerSpType)), ('KSPDEG', KerSpDegree),
+              ('NKIKX', len(KerIntKnotX))] + [('KIKX%d' % i, k) for i, k in enumerate(KerIntKnotX)] + \
+             [('NKIKY', len(KerIntKnotY))] + [('KIKY%d' % i, k) for i, k in enumerate(KerIntKnotY)] + \
+             [('SEPSCA', str(SEPARATE_SCALING))]
+        if SEPARATE_SCALING:
+            kw += [('SSPTYPE', str(ScaSpType)), ('SSPDEG', ScaSpDegree), ('NSIKX', len(ScaIntKnotX))] + \
+                  [('SIKX%d' % i, k) for i, k in enumerate(ScaIntKnotX)] + [('NSIKY', len(ScaIntKnotY))] + \
+                  [('SIKY%d' % i, k) for i, k in enumerate(ScaIntKnotY)]
+        kw += [('BSPTYPE', str(BkgSpType)), ('BSPDEG', BkgSpDegree), ('NBIKX', len(BkgIntKnotX))] + \
+              [('BIKX%d' % i, k) for i, k in enumerate(BkgIntKnotX)] + [('NBIKY', len(BkgIntKnotY))] + \
+              [('BIKY%d' % i, k) for i, k in enumerate(BkgIntKnotY)] + [('REGKER', str(REGULARIZE_KERNEL))]
+        if FITS_DIFF is not None:
+            if _afits is not None:
+                with _afits.open(FITS_SCI) as hdl:
+                    hdl[0].data[:, :] = PixA_DIFF.T
+                    for k, v in kw:
+                        hdl[0].header[k] = (v, 'SFFT')
+                    hdl.writeto(FITS_DIFF, overwrite=True)
+            else:
+                data0, cards = minifits.getdata(FITS_SCI)
+                for k, v in kw:
+                    minifits.set_card(cards, k, v, 'SFFT')
+                out = PixA_DIFF.T
+                if data0.dtype.kind == 'f':
+                    out = out.astype(data0.dtype.newbyteorder('='))
+                minifits.writeto(FITS_DIFF, np.ascontiguousarray(out), cards)
+        if FITS_Solution is not None:
+            P = SFFTConfig[0]
+            skw = [('N0', P['N0']), ('N1', P['N1']), ('W0', P['w0']), ('W1', P['w1']), ('DK', P['DK']), ('DB', P['DB']),
+                   ('L0', P['L0']), ('L1', P['L1']), ('FIJ', P['Fij']), ('FAB', P['Fab']), ('FPQ', P['Fpq']), ('FIJAB', P['Fijab'])] + kw[5:]
+            if _afits is not None:
+                phdu = _afits.PrimaryHDU()
+                for k, v in skw:
+                    phdu.header[k] = (v, 'SFFT')
+                phdu.data = Solution.reshape((-1, 1)).T
+                _afits.HDUList([phdu]).writeto(FITS_Solution, overwrite=True)
+            else:
+                cards = []
+                for k, v in skw:
+                    minifits.set_card(cards, k, v, 'SFFT')
+                minifits.writeto(FITS_Solution, np.ascontiguousarray(Solution.reshape((-1, 1)).T), cards)
+        return Solution, PixA_DIFF

@@ -11,7 +11,20 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Fixtures of the polynomial path (sfft/sfftcore), made by make_golden.py."""
+    return sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(GOLDEN_DIR, "c*.npz")))
+
+
+def bspline_golden_names():
+    """Fixtures of the B-spline path, made by make_golden_bspline.py."""
+    return sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(GOLDEN_DIR, "bs_*.npz")))
+
+
+def load_bspline_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files if k != "meta"}
+    g["meta"] = ast.literal_eval(str(z["meta"][0]))
+    return g
 
 
 def load_golden(name):

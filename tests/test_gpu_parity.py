@@ -379,3 +379,83 @@ def test_large_shapes_properties(dev, cfg):
     assert np.isfinite(d).all() and rms(d) < 2.0
     assert abs(float(solution[w * L + w].item()) / (float(N0) * float(N1)) - 1.2) < 0.05
     clear_plan_cache()
+
+
+# ------------------------------------------------------------------------------------------------
+# (e) B-spline form (sfft_amd.BSplineSFFT): golden vectors from the reference's dev-version Numpy backend
+# ------------------------------------------------------------------------------------------------
+from _golden import bspline_golden_names, load_bspline_golden
+
+BS_NAMES = bspline_golden_names()
+
+
+def _bs_config(m, dev):
+    from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC
+    return BSSC.SSC(NX=m["N0"], NY=m["N1"], KerHW=m["w"], KerSpType=m["KerSpType"], KerSpDegree=m["KerSpDegree"],
+                    KerIntKnotX=m["KerIntKnotX"], KerIntKnotY=m["KerIntKnotY"], SEPARATE_SCALING=bool(m["CPR"]), ScaSpDegree=0,
+                    BkgSpType=m["BkgSpType"], BkgSpDegree=m["BkgSpDegree"], BkgIntKnotX=m["BkgIntKnotX"],
+                    BkgIntKnotY=m["BkgIntKnotY"], VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+
+
+@pytest.mark.parametrize("name", BS_NAMES)
+def test_bspline_matches_reference(dev, name):
+    from sfft_amd.BSplineSFFT import GeneralSFFTSubtract as BGSS, ElementalSFFTSubtract as BESS
+    g = load_bspline_golden(name)
+    m = g["meta"]
+    cfg = _bs_config(m, dev)
+    assert (cfg[0]["NEQ"], cfg[0]["Fij"], cfg[0]["Fpq"]) == (m["NEQ"], m["Fij"], m["Fpq"])
+    plan = cfg[1]["plan"]
+    plan.solve(_to(dev, g["mREF"]), _to(dev, g["mSCI"]))
+    LH, rhs = plan.get_system()
+    assert np.max(np.abs(LH.cpu().numpy() - g["LHMAT"])) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
+    assert np.max(np.abs(rhs.cpu().numpy() - g["RHb"])) <= 1e-11 * np.max(np.abs(g["RHb"]))
+    D = BESS.ESS(g["REF"], g["SCI"], cfg, SFFTSolution=g["Solution"], Subtract=True, VERBOSE_LEVEL=0)[1]
+    assert rms(D - g["DIFF"]) <= 1e-10 * rms(g["SCI"])
+    sol, D2, _ = BGSS.GSS(g["REF"], g["SCI"], g["mREF"], g["mSCI"], cfg, VERBOSE_LEVEL=0)
+    assert rel_rms_err(D2, g["DIFF"]) <= 1e-6
+    if bool(m["CPR"]) and m["KerSpType"] == "B-Spline":
+        L = 2 * m["w"] + 1
+        ij00 = np.arange(m["w"] * L + m["w"], m["Fij"] * L * L, L * L)
+        assert np.all(sol[ij00] == sol[ij00[0]])
+
+
+def test_bspline_background_matches_oracle(dev):
+    """B-spline BACKGROUND variation has no runnable CPU code in the reference (parity unpinned, see
+    tests/golden/make_golden_bspline.py); checked against the restated oracle only."""
+    from oracle import bspline_oracle as BO
+    from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC, GeneralSFFTSubtract as BGSS
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1, w = 96, 128, 2
+    pair = make_pair(N0, N1, seed=77, mask=False, density=500.0)
+    kw = dict(KerSpType="B-Spline", KerSpDegree=2, KerIntKnotX=[48.5], KerIntKnotY=[40.5, 88.5],
+              BkgSpType="B-Spline", BkgSpDegree=2, BkgIntKnotX=[30.5, 60.5], BkgIntKnotY=[64.5])
+    cfg = BSSC.SSC(NX=N0, NY=N1, KerHW=w, SEPARATE_SCALING=True, ScaSpDegree=0, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index, **kw)
+    sol, D, _ = BGSS.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)
+    basis = BO.make_basis(N0, N1, **kw)
+    p = BO.SSC(N0, N1, w, basis, True)
+    assert cfg[0]["Fij"] == 20 and cfg[0]["Fpq"] == 20 and cfg[0]["NEQ"] == p["NEQ"]
+    sol_o, D_o = BO.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], p, basis, workers=8)
+    assert rel_rms_err(D, D_o) <= 1e-6
+
+
+def test_bspline_packet_fits_and_unsupported_modes(dev, tmp_path):
+    from sfft_amd.BSplineSFFT import BSpline_Packet, SingleSFFTConfigure as BSSC
+    from sfft_amd.utils import minifits
+    g = load_bspline_golden("bs_64x48_w2_bspl1_k2_poly2_const")
+    m = g["meta"]
+    paths = {}
+    for k in ("REF", "SCI", "mREF", "mSCI"):
+        paths[k] = str(tmp_path / (k + ".fits"))
+        minifits.writeto(paths[k], np.ascontiguousarray(g[k].T))
+    fdiff = str(tmp_path / "d.fits")
+    sol, diff = BSpline_Packet.BSP(paths["REF"], paths["SCI"], paths["mREF"], paths["mSCI"], FITS_DIFF=fdiff, ForceConv="REF",
+                                   GKerHW=m["w"], KerSpType="B-Spline", KerSpDegree=1, KerIntKnotX=m["KerIntKnotX"],
+                                   KerIntKnotY=m["KerIntKnotY"], SEPARATE_SCALING=True, ScaSpDegree=0, BkgSpType="Polynomial",
+                                   BkgSpDegree=2, CUDA_DEVICE_4SUBTRACT=str(dev.index), VERBOSE_LEVEL=0)
+    assert rel_rms_err(diff, g["DIFF"]) <= 1e-6
+    h = minifits.header_dict(minifits.getdata(fdiff)[1])
+    assert h["KSPTYPE"] == "B-Spline" and h["NKIKX"] == 2 and abs(h["KIKX1"] - 44.5) < 1e-12 and h["SEPSCA"] == "True"
+    with pytest.raises(NotImplementedError, match="SEPARATE-VARYING"):
+        BSSC.SSC(64, 48, 2, KerSpType="B-Spline", KerSpDegree=2, SEPARATE_SCALING=True, ScaSpDegree=1, VERBOSE_LEVEL=0)
+    with pytest.raises(NotImplementedError, match="REGULARIZE_KERNEL"):
+        BSSC.SSC(64, 48, 2, KerSpType="B-Spline", KerSpDegree=2, REGULARIZE_KERNEL=True, VERBOSE_LEVEL=0)

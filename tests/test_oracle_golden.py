@@ -66,3 +66,38 @@ def test_param_validation():
         O.SSC(64, 64, 2, 0, -1)
     p = O.SSC(4096, 4096, 8, 2, 2, True)
     assert (p["NEQ"], p["NEQ_FSfree"], p["Fijab"], p["Fab"]) == (1740, 1735, 1734, 289)
+
+
+# ---------------------------------------------------------------------------------------------------
+# B-spline form (oracle/bspline_oracle.py) against vectors from the reference's dev-version Numpy backend
+# ---------------------------------------------------------------------------------------------------
+from oracle import bspline_oracle as BO
+from _golden import bspline_golden_names, load_bspline_golden
+
+BS_NAMES = bspline_golden_names()
+
+
+def _bs_setup(m):
+    basis = BO.make_basis(m["N0"], m["N1"], m["KerSpType"], m["KerSpDegree"], m["KerIntKnotX"], m["KerIntKnotY"],
+                          m["BkgSpType"], m["BkgSpDegree"], m["BkgIntKnotX"], m["BkgIntKnotY"])
+    return basis, BO.SSC(m["N0"], m["N1"], m["w"], basis, bool(m["CPR"]))
+
+
+@pytest.mark.parametrize("name", BS_NAMES)
+def test_bspline_oracle_matches_reference(name):
+    g = load_bspline_golden(name)
+    basis, p = _bs_setup(g["meta"])
+    assert (p["NEQ"], p["Fij"], p["Fpq"]) == (g["meta"]["NEQ"], g["meta"]["Fij"], g["meta"]["Fpq"])
+    LHMAT, RHb = BO.establish_system(g["mREF"], g["mSCI"], p, basis)
+    assert np.max(np.abs(LHMAT - g["LHMAT"])) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
+    assert np.max(np.abs(RHb - g["RHb"])) <= 1e-11 * np.max(np.abs(g["RHb"]))
+    # apply-only with the reference's solution
+    D = BO.ESS(g["REF"], g["SCI"], p, basis, SFFTSolution=g["Solution"], Subtract=True)[1]
+    assert rms(D - g["DIFF"]) <= 1e-10 * rms(g["SCI"])
+    # end to end, including the tied-scaling (TweakLS sum) rule
+    sol, D2 = BO.GSS(g["REF"], g["SCI"], g["mREF"], g["mSCI"], p, basis)
+    assert rel_rms_err(D2, g["DIFF"]) <= 1e-6
+    if bool(g["meta"]["CPR"]) and g["meta"]["KerSpType"] == "B-Spline":
+        Fab = p["Fab"]
+        ij00 = np.arange(p["w0"] * p["L1"] + p["w1"], p["Fijab"], Fab)
+        assert np.all(sol[ij00] == sol[ij00[0]])          # tied scaling: all centre coefficients equal
