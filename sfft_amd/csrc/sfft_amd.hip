@@ -505,50 +505,61 @@ __device__ __forceinline__ void fft4096_core(cplx (&u)[16], int j, cplx* lds, co
     dft16(u);
 }
 
-// rows, real -> half complex (N1 = 4096), two image rows per transform, SpatialPoly fused
-__global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, cplx* __restrict__ out, int N0, int Nhp,
+// rows, real -> half complex (N1 = 4096), two image rows per transform, spatial factors fused.  Planes [first, first +
+// count) of a launch group share their source image: the workgroup reads its two rows once and produces every plane.
+struct RowGroups { int ngroups; int first[SFFT_MAX_PLANES]; int count[SFFT_MAX_PLANES]; };
+
+__global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp,
                                                      const cplx* __restrict__ tw, double scale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* lds = reinterpret_cast<cplx*>(smem_raw);
     const int N1 = 4096;
     const int j = threadIdx.x;
-    const int plane = blockIdx.y;
+    const int pfirst = grp.first[blockIdx.y], pcount = grp.count[blockIdx.y];
     const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
-    const double* __restrict__ src = a.src[plane];
-    const double* __restrict__ wx = a.wx[plane];
-    const double* __restrict__ wy = a.wy[plane];
     const bool has1 = l1 < N0;
-    const double cx0 = wx ? wx[l0] : 1.0;
-    const double cx1 = (wx && has1) ? wx[l1] : 1.0;
+    const double* __restrict__ src = a.src[pfirst];
     const double* r0p = src + (size_t)l0 * N1;
     const double* r1p = src + (size_t)(has1 ? l1 : l0) * N1;
-    cplx u[16];
+    double x0[16], x1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = j + 256 * r;
-        const double cyp = wy ? wy[n] : 1.0;
-        const double v0 = r0p[n] * (cx0 * cyp);
-        const double v1 = has1 ? r1p[n] * (cx1 * cyp) : 0.0;
-        u[r] = make_double2(v0, v1);
+        x0[r] = r0p[n];
+        x1[r] = has1 ? r1p[n] : 0.0;
     }
-    fft4096_core(u, j, lds, tw);
-    __syncthreads();
-#pragma unroll
-    for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)];
-    __syncthreads();
-    cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
-    cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
     const double hs = 0.5 * scale;
+    for (int pp = 0; pp < pcount; ++pp) {
+        const int plane = pfirst + pp;
+        const double* __restrict__ wx = a.wx[plane];
+        const double* __restrict__ wy = a.wy[plane];
+        const double cx0 = wx ? wx[l0] : 1.0;
+        const double cx1 = (wx && has1) ? wx[l1] : 1.0;
+        cplx u[16];
 #pragma unroll
-    for (int sx = 0; sx <= 8; ++sx) {
-        const int m = j + 256 * sx;
-        if (sx < 8 || j == 0) {
-            const cplx z = u[R16_OUT(sx)];
-            const cplx zp = lds[(N1 - m) & (N1 - 1)];
-            const cplx zc = make_double2(zp.x, -zp.y);
-            o0[m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
-            if (has1) o1[m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+        for (int r = 0; r < 16; ++r) {
+            const double cyp = wy ? wy[j + 256 * r] : 1.0;
+            u[r] = make_double2(x0[r] * (cx0 * cyp), x1[r] * (cx1 * cyp));
+        }
+        if (pp > 0) __syncthreads();            // the previous plane's partner reads are done
+        fft4096_core(u, j, lds, tw);
+        __syncthreads();
+#pragma unroll
+        for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)];
+        __syncthreads();
+        cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
+        cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
+#pragma unroll
+        for (int sx = 0; sx <= 8; ++sx) {
+            const int m = j + 256 * sx;
+            if (sx < 8 || j == 0) {
+                const cplx z = u[R16_OUT(sx)];
+                const cplx zp = lds[(N1 - m) & (N1 - 1)];
+                const cplx zc = make_double2(zp.x, -zp.y);
+                o0[m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
+                if (has1) o1[m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+            }
         }
     }
 }
@@ -2037,8 +2048,15 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
             hipLaunchKernelGGL(untangle_rows, dim3((p->Nh + 255) / 256, npr), dim3(256), 0, s, p->d_big1, dst + (size_t)k * p->N0 * p->Nhp,
                                p->N0, p->N1, p->Nh, p->Nhp, p->scale);
         }
-    } else if (fast_axis(p->ax1) && !p->no_fast_fft)
-        hipLaunchKernelGGL(rows_r2c_4096, g1, dim3(256), F4K_LDS * sizeof(cplx), s, ra, dst, p->N0, p->Nhp, p->ax1.tw, p->scale);
+    } else if (fast_axis(p->ax1) && !p->no_fast_fft) {
+        RowGroups grp; grp.ngroups = 0;
+        for (int k = 0; k < nplanes; ++k) {
+            if (k > 0 && ra.src[k] == ra.src[k - 1]) ++grp.count[grp.ngroups - 1];
+            else { grp.first[grp.ngroups] = k; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
+        }
+        hipLaunchKernelGGL(rows_r2c_4096, dim3((p->N0 + 1) / 2, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp, dst,
+                           p->N0, p->Nhp, p->ax1.tw, p->scale);
+    }
     else
         hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
                            axis_dev(p->ax1), p->scale);
@@ -2078,7 +2096,7 @@ static void launch_g1(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
     const int per_launch = HBW * RS;
     for (int rb = 0; rb < h || rb == 0; rb += per_launch) {
         hipLaunchKernelGGL((greek_g1<HBW, RS>), g, dim3(64 * RS), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
-                           p->Nhp, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp);
+                               p->Nhp, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp);
         if (h == 0) break;
     }
 }
