@@ -265,21 +265,27 @@ struct BkgArgs {
 };
 
 // per-row coefficients of the column factors: c[q] = sum_{t: q[t] = q} b[t] * tbx[p[t]][row]
-__device__ __forceinline__ void bkg_row_coeffs(const BkgArgs& bk, const double* __restrict__ bpq, int row, int N0, double (&c)[SFFT_MAX_BQ])
+// (NQ = compile-time bound on the number of column factors: 4 covers polynomial backgrounds, 16 the general case)
+template <int NQ>
+__device__ __forceinline__ void bkg_row_coeffs(const BkgArgs& bk, const double* __restrict__ bpq, int row, int N0, double (&c)[NQ])
 {
 #pragma unroll
-    for (int q = 0; q < SFFT_MAX_BQ; ++q) c[q] = 0.0;
+    for (int q = 0; q < NQ; ++q) c[q] = 0.0;
     for (int t = 0; t < bk.npq; ++t) {
         const double v = bpq[t] * bk.tbx[(size_t)bk.p[t] * N0 + row];
 #pragma unroll
-        for (int q = 0; q < SFFT_MAX_BQ; ++q) if (bk.q[t] == q) c[q] += v;
+        for (int q = 0; q < NQ; ++q) c[q] += (bk.q[t] == q) ? v : 0.0;
     }
 }
-__device__ __forceinline__ double bkg_eval(const BkgArgs& bk, const double (&c)[SFFT_MAX_BQ], int col, int N1)
+template <int NQ>
+__device__ __forceinline__ double bkg_eval(const BkgArgs& bk, const double (&c)[NQ], int col, int N1)
 {
     double B = 0.0;
 #pragma unroll
-    for (int q = 0; q < SFFT_MAX_BQ; ++q) if (q < bk.nq) B = fma(c[q], bk.tby[(size_t)q * N1 + col], B);
+    for (int q = 0; q < NQ; ++q) {
+        const double t = bk.tby[(size_t)min(q, bk.nq - 1) * N1 + col];      // clamped: always a valid, branch-free load
+        B = fma((q < bk.nq) ? c[q] : 0.0, t, B);
+    }
     return B;
 }
 
@@ -312,12 +318,12 @@ __global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ F
     __syncthreads();
     lds_dft(s, ax, 1, ax.M);
     double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
-    bkg_row_coeffs(bk, bpq, l0, N0, c0);
-    bkg_row_coeffs(bk, bpq, has1 ? l1 : l0, N0, c1);
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
     for (int n = tid; n < N1; n += nt) {
         const cplx z = s[n];                 // conj(result): row0 = z.x, row1 = -z.y
-        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval(bk, c0, n, N1) - z.x;
-        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval(bk, c1, n, N1) + z.y;
+        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c0, n, N1) - z.x;
+        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
     }
 }
 
@@ -424,10 +430,10 @@ __global__ void __launch_bounds__(256) finish_diff(const cplx* __restrict__ Zf, 
     const int l0 = 2 * pr, l1 = l0 + 1;
     const cplx z = Zf[(size_t)pr * N1 + n];
     double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
-    bkg_row_coeffs(bk, bpq, l0, N0, c0);
-    bkg_row_coeffs(bk, bpq, (l1 < N0) ? l1 : l0, N0, c1);
-    DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval(bk, c0, n, N1) - z.x;
-    if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval(bk, c1, n, N1) + z.y;
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, (l1 < N0) ? l1 : l0, N0, c1);
+    DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c0, n, N1) - z.x;
+    if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
 }
 
 // ================================================================================================
@@ -595,6 +601,7 @@ __global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, in
 }
 
 // rows, half complex -> real (N1 = 4096), two rows per transform, DIFF epilogue (see rows_c2r_diff)
+template <int NQ>
 __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict__ FD, const double* __restrict__ J,
                                                           const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
                                                           int N0, int Nhp, const cplx* __restrict__ tw)
@@ -620,9 +627,9 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
         u[r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
     }
     fft4096_core(u, j, lds, tw);
-    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
-    bkg_row_coeffs(bk, bpq, l0, N0, c0);
-    bkg_row_coeffs(bk, bpq, has1 ? l1 : l0, N0, c1);
+    double c0[NQ], c1[NQ];
+    bkg_row_coeffs<NQ>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<NQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
     const double* j0 = J + (size_t)l0 * N1;
     const double* j1 = J + (size_t)(has1 ? l1 : l0) * N1;
     double* d0 = DIFF + (size_t)l0 * N1;
@@ -631,8 +638,8 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
     for (int sx = 0; sx < 16; ++sx) {
         const int n = j + 256 * sx;
         const cplx z = u[R16_OUT(sx)];
-        d0[n] = j0[n] - bkg_eval(bk, c0, n, N1) - z.x;
-        if (has1) d1[n] = j1[n] - bkg_eval(bk, c1, n, N1) + z.y;
+        d0[n] = j0[n] - bkg_eval<NQ>(bk, c0, n, N1) - z.x;
+        if (has1) d1[n] = j1[n] - bkg_eval<NQ>(bk, c1, n, N1) + z.y;
     }
 }
 
@@ -816,27 +823,28 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
 
 // Delta: rowmom[l][q] = sum_n J[l][n] tby[q][n], then delta[t] = SCALE * sum_l tbx[p[t]][l] rowmom[l][q[t]]
 // (= PreDEL[pq][0][0], SFFTSubtract.py:706-729, evaluated in real space: only element [0][0] is ever read).
+template <int NQ>
 __global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J, double* __restrict__ rowmom, int N0, int N1,
                                                    const double* __restrict__ tby, int nq)
 {
     const int l = blockIdx.x, tid = threadIdx.x;
-    double acc[SFFT_MAX_BQ];
+    double acc[NQ];
 #pragma unroll
-    for (int q = 0; q < SFFT_MAX_BQ; ++q) acc[q] = 0.0;
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
     for (int n = tid; n < N1; n += 256) {
         const double v = J[(size_t)l * N1 + n];
 #pragma unroll
-        for (int q = 0; q < SFFT_MAX_BQ; ++q) if (q < nq) acc[q] = fma(v, tby[(size_t)q * N1 + n], acc[q]);
+        for (int q = 0; q < NQ; ++q) acc[q] = fma(v, tby[(size_t)min(q, nq - 1) * N1 + n], acc[q]);   // q >= nq: unused copies
     }
-    __shared__ double red[4][SFFT_MAX_BQ];
+    __shared__ double red[4][NQ];
 #pragma unroll
-    for (int q = 0; q < SFFT_MAX_BQ; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         double u = acc[q];
         for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
         if ((tid & 63) == 0) red[tid >> 6][q] = u;
     }
     __syncthreads();
-    if (tid < SFFT_MAX_BQ) rowmom[(size_t)l * SFFT_MAX_BQ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < NQ) rowmom[(size_t)l * SFFT_MAX_BQ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 __global__ void __launch_bounds__(256) delta_finish(const double* __restrict__ rowmom, double* __restrict__ delta, int N0,
@@ -1727,7 +1735,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)lu_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2189,7 +2198,8 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
         if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s))) return rc;
-        hipLaunchKernelGGL(row_moments, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
+        if (p->nby <= 4) hipLaunchKernelGGL(row_moments<4>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
+        else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
     }
@@ -2277,8 +2287,14 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
             hipLaunchKernelGGL(finish_diff, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, p->d_big1, d_J, d_solution + p->Fijab, p->bk,
                                d_diff, p->N0, p->N1);
         } else if (fast_axis(p->ax1) && !p->no_fast_fft)
-            hipLaunchKernelGGL(rows_c2r_diff_4096, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
-                               d_solution + p->Fijab, p->bk, d_diff, p->N0, p->Nhp, p->ax1.tw);
+        {
+            if (p->nby <= 4)
+                hipLaunchKernelGGL(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
+                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->Nhp, p->ax1.tw);
+            else
+                hipLaunchKernelGGL(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
+                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->Nhp, p->ax1.tw);
+        }
         else
             hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
                                d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, axis_dev(p->ax1));
