@@ -113,6 +113,32 @@ int sfft_get_system(sfft_plan* plan, double* d_LHMAT, double* d_RHb, void* strea
  * in the plan's half-spectrum layout, d_spec: [N0][N1/2+1] complex128 (interleaved re,im) -- items 3+4 of SURVEY.md 8(a). */
 int sfft_dbg_forward_spectrum(sfft_plan* plan, const double* d_I, int i, int j, double* d_spec, void* stream);
 
+/* ---- FFT utilities behind the post-subtraction helpers: sfft/utils/PureCupyFFTKits.py
+ * (KERNEL_CSZ, FFT_CONVOLVE :37-105) and sfft/utils/PureCupyDeCorrelationCalculator.py (PCDC :46-126),
+ * CPU twin sfft/utils/DeCorrelationCalculator.py (DCC :11-104).  cupy.fft.fft2 / ifft2 of REAL images become: ---- */
+
+/* plan that only serves the FFT entry points below (any supported shape) */
+int sfft_fft_plan_create(sfft_plan** plan, int N0, int N1, int device);
+
+/* d_spec [N0][N1/2+1] complex128 (dense, interleaved) = scale * DFT2(d_real [N0][N1]); numpy.fft.rfft2 layout */
+int sfft_fft2_r2c(sfft_plan* plan, const double* d_real, double* d_spec, double scale, void* stream);
+
+/* d_real [N0][N1] = scale * sum_k d_spec[k] exp(+2 pi i k.x / N), d_spec the half spectrum of a real image
+ * (scale = 1/(N0*N1) reproduces numpy.fft.irfft2) */
+int sfft_ifft2_c2r(sfft_plan* plan, const double* d_spec, double* d_real, double scale, void* stream);
+
+/* d_acc[i] += coeff * |d_a[i]|^2 * |d_b[i]|^2   (d_b may be NULL); a, b complex128, acc float64 */
+int sfft_spec_abs2_accumulate(const double* d_a, const double* d_b, double coeff, double* d_acc, long long n, void* stream);
+
+/* d_out[i] = 1 / sqrt(d_acc[i]) */
+int sfft_real_rsqrt(const double* d_acc, double* d_out, long long n, void* stream);
+
+/* d_out[i] = d_a[i] * d_b[i]; a, out complex128; b complex128 (b_is_real = 0) or float64 (b_is_real = 1) */
+int sfft_spec_multiply(const double* d_a, const double* d_b, int b_is_real, double* d_out, long long n, void* stream);
+
+/* d_full [N0][N1] float64 of a real conjugate-symmetric spectrum quantity from its half d_half [N0][N1/2+1] */
+int sfft_half_to_full_real(const double* d_half, double* d_full, int N0, int N1, void* stream);
+
 /* enable (1) / disable (0) hipEvent timing of the stages of subsequent calls */
 int sfft_set_timing(sfft_plan* plan, int enable);
 

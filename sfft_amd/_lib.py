@@ -23,7 +23,8 @@ QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1"
 STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b"]
 
 EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
-           "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",
+           "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",
+           "sfft_spec_abs2_accumulate", "sfft_real_rsqrt", "sfft_spec_multiply", "sfft_half_to_full_real", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",
            "sfft_last_error", "sfft_version"]
 
 
@@ -47,6 +48,14 @@ def _load():
     lib.sfft_subtract.argtypes = [vp, dp, dp, dp, dp, dp, dp, vp]
     lib.sfft_get_system.argtypes = [vp, dp, dp, vp]
     lib.sfft_dbg_forward_spectrum.argtypes = [vp, dp, ip, ip, dp, vp]
+    dbl, ll = ctypes.c_double, ctypes.c_longlong
+    lib.sfft_fft_plan_create.argtypes = [ctypes.POINTER(vp), ip, ip, ip]
+    lib.sfft_fft2_r2c.argtypes = [vp, dp, dp, dbl, vp]
+    lib.sfft_ifft2_c2r.argtypes = [vp, dp, dp, dbl, vp]
+    lib.sfft_spec_abs2_accumulate.argtypes = [dp, dp, dbl, dp, ll, vp]
+    lib.sfft_real_rsqrt.argtypes = [dp, dp, ll, vp]
+    lib.sfft_spec_multiply.argtypes = [dp, dp, ip, dp, ll, vp]
+    lib.sfft_half_to_full_real.argtypes = [dp, dp, ip, ip, vp]
     lib.sfft_set_timing.argtypes = [vp, ip]
     lib.sfft_stage_ms.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_float)]
     lib.sfft_set_force_lu.argtypes = [vp, ip]

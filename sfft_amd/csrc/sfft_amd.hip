@@ -1415,6 +1415,52 @@ __global__ void __launch_bounds__(256) construct_fd(const cplx* __restrict__ FI,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small spectrum-arithmetic kernels behind the FFT utilities (noise decorrelation, FFT convolution:
+// sfft/utils/PureCupyFFTKits.py, PureCupyDeCorrelationCalculator.py)
+// ------------------------------------------------------------------------------------------------
+__global__ void copy_spectrum_scaled(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, int src_ld, int dst_ld, double f)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (m < Nh) { const cplx v = src[(size_t)l * src_ld + m]; dst[(size_t)l * dst_ld + m] = make_double2(v.x * f, v.y * f); }
+}
+__global__ void scale_real(double* __restrict__ a, double f, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] *= f;
+}
+// acc[i] += coeff * |a[i]|^2 * (b ? |b[i]|^2 : 1)
+__global__ void spec_abs2_acc(const cplx* __restrict__ a, const cplx* __restrict__ b, double coeff, double* __restrict__ acc, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const cplx u = a[i];
+    double v = coeff * (u.x * u.x + u.y * u.y);
+    if (b) { const cplx w = b[i]; v *= (w.x * w.x + w.y * w.y); }
+    acc[i] += v;
+}
+__global__ void real_rsqrt(const double* __restrict__ acc, double* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = 1.0 / sqrt(acc[i]);
+}
+// out[i] = a[i] * (b is complex ? b[i] : breal[i])
+__global__ void spec_mul(const cplx* __restrict__ a, const cplx* __restrict__ b, const double* __restrict__ breal, cplx* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const cplx u = a[i];
+    if (b) out[i] = cmul(u, b[i]);
+    else { const double r = breal[i]; out[i] = make_double2(u.x * r, u.y * r); }
+}
+// full[l][m] of a real, conjugate-symmetric spectrum quantity from its half [N0][Nh]: full[l][N1-m] = half[(N0-l)%N0][m]
+__global__ void half_to_full_real(const double* __restrict__ half, double* __restrict__ full, int N0, int N1, int Nh)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (m >= N1) return;
+    full[(size_t)l * N1 + m] = (m < Nh) ? half[(size_t)l * Nh + m] : half[(size_t)((N0 - l) % N0) * Nh + (N1 - m)];
+}
+
 // debug: copy a padded half-spectrum plane to a dense [N0][Nh] array
 __global__ void copy_spectrum(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, int Nhp)
 {
@@ -1469,6 +1515,7 @@ struct sfft_plan {
     // workspaces
     cplx* d_spec = nullptr;             // [Fij+1][N0][Nhp]   (plane Fij: J in solve, FD in apply)
     cplx *d_big1 = nullptr, *d_big2 = nullptr, *d_colscr = nullptr;   // work arrays of the four-step path
+    double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
     hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr; int no_overlap = 0;
     const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
@@ -1932,7 +1979,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     hipSetDevice(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby};
+                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -2361,6 +2408,105 @@ extern "C" int sfft_get_system(sfft_plan* p, double* d_LHMAT, double* d_RHb, voi
     hipLaunchKernelGGL(fill_plain, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->NEQ, d_LHMAT, d_RHb);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(s));
+    return SFFT_OK;
+}
+
+// ---- general real 2-D FFT entry points (used by the decorrelation / FFT-convolution utilities) ---------------------
+extern "C" int sfft_fft_plan_create(sfft_plan** out, int N0, int N1, int device)
+{
+    return sfft_plan_create(out, N0, N1, 0, 0, 0, 0, device);     // a plan with the smallest SFFT geometry: the FFT machinery only
+}
+
+// d_spec[N0][N1/2+1] (dense complex128) = scale * DFT2(d_real[N0][N1]), numpy.fft.rfft2 convention
+extern "C" int sfft_fft2_r2c(sfft_plan* p, const double* d_real, double* d_spec, double scale, void* stream)
+{
+    if (!p || !d_real || !d_spec) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    RowsArgs ra;
+    for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.wx[k] = nullptr; ra.wy[k] = nullptr; }
+    ra.src[0] = d_real;
+    int rc = forward_planes(p, ra, 1, p->d_spec, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec, p->N0, p->Nh,
+                       p->Nhp, p->Nh, scale / p->scale);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+// d_real[N0][N1] = scale * sum_k spec[k] e^{+2 pi i k x / N} from the half spectrum of a real image (numpy.fft.irfft2 * N0*N1
+// when scale = 1; pass scale = 1/(N0*N1) for numpy's normalisation)
+extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real, double scale, void* stream)
+{
+    if (!p || !d_real || !d_spec) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(p->dev));
+    int rc;
+    if (!p->d_zero) {
+        if ((rc = dev_alloc(p, &p->d_zero, (size_t)p->N0 * p->N1))) return rc;
+        HIPCHK(hipMemsetAsync(p->d_zero, 0, (size_t)p->N0 * p->N1 * sizeof(double), s));
+        if ((rc = dev_alloc(p, &p->d_zsol, (size_t)p->NEQ))) return rc;
+        HIPCHK(hipMemsetAsync(p->d_zsol, 0, (size_t)p->NEQ * sizeof(double), s));
+    }
+    cplx* FD = p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp;
+    hipLaunchKernelGGL(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, (const cplx*)d_spec, FD, p->N0, p->Nh,
+                       p->Nh, p->Nhp, 1.0);
+    LAUNCH_CHECK();
+    // reuse the inverse path of the subtraction: with J = 0 and b = 0 it returns -IDFT2(FD)
+    launch_cols(p, FD, 1, 1, s);
+    if (p->ax1.big) {
+        const int npr = (p->N0 + 1) / 2;
+        hipLaunchKernelGGL(retangle_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, FD, p->d_big1, p->N0, p->N1, p->Nh, p->Nhp);
+        big_axis_transform(p, p->ax1, p->d_big1, p->d_big2, 1, p->N1, npr, false, 0, s);
+        hipLaunchKernelGGL(finish_diff, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, p->d_big1, p->d_zero, p->d_zsol + p->Fijab, p->bk,
+                           d_real, p->N0, p->N1);
+    } else if (fast_axis(p->ax1) && !p->no_fast_fft)
+        hipLaunchKernelGGL(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, p->d_zero,
+                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->Nhp, p->ax1.tw);
+    else
+        hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, p->d_zero,
+                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->N1, p->Nh, p->Nhp, axis_dev(p->ax1));
+    const size_t n = (size_t)p->N0 * p->N1;
+    hipLaunchKernelGGL(scale_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_real, -scale, n);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+// acc[i] += coeff * |a[i]|^2 * |b[i]|^2 (b may be NULL); a, b complex128, acc float64, n elements
+extern "C" int sfft_spec_abs2_accumulate(const double* d_a, const double* d_b, double coeff, double* d_acc, long long n, void* stream)
+{
+    if (!d_a || !d_acc || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    hipLaunchKernelGGL(spec_abs2_acc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a, (const cplx*)d_b,
+                       coeff, d_acc, (size_t)n);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+// out[i] = 1 / sqrt(acc[i])
+extern "C" int sfft_real_rsqrt(const double* d_acc, double* d_out, long long n, void* stream)
+{
+    if (!d_acc || !d_out || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    hipLaunchKernelGGL(real_rsqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_acc, d_out, (size_t)n);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+// out[i] = a[i] * b[i] with b complex (b_is_real = 0) or real (b_is_real = 1); a, out complex128
+extern "C" int sfft_spec_multiply(const double* d_a, const double* d_b, int b_is_real, double* d_out, long long n, void* stream)
+{
+    if (!d_a || !d_b || !d_out || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    hipLaunchKernelGGL(spec_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a,
+                       b_is_real ? (const cplx*)nullptr : (const cplx*)d_b, b_is_real ? d_b : (const double*)nullptr, (cplx*)d_out, (size_t)n);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+// full [N0][N1] of a real, conjugate-symmetric spectrum quantity from its half [N0][N1/2+1]
+extern "C" int sfft_half_to_full_real(const double* d_half, double* d_full, int N0, int N1, void* stream)
+{
+    if (!d_half || !d_full) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipLaunchKernelGGL(half_to_full_real, dim3((N1 + 255) / 256, N0), dim3(256), 0, (hipStream_t)stream, d_half, d_full, N0, N1, N1 / 2 + 1);
+    LAUNCH_CHECK();
     return SFFT_OK;
 }
 

@@ -459,3 +459,60 @@ def test_bspline_packet_fits_and_unsupported_modes(dev, tmp_path):
         BSSC.SSC(64, 48, 2, KerSpType="B-Spline", KerSpDegree=2, SEPARATE_SCALING=True, ScaSpDegree=1, VERBOSE_LEVEL=0)
     with pytest.raises(NotImplementedError, match="REGULARIZE_KERNEL"):
         BSSC.SSC(64, 48, 2, KerSpType="B-Spline", KerSpDegree=2, REGULARIZE_KERNEL=True, VERBOSE_LEVEL=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# (f) FFT utilities / noise decorrelation
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(64, 64), (276, 300), (4096, 128), (100, 4100)])
+def test_rfft2_irfft2_roundtrip_and_numpy(dev, shape):
+    from sfft_amd.fftkit import get_fft_plan
+    rng = np.random.default_rng(shape[0])
+    x = rng.normal(size=shape)
+    plan = get_fft_plan(shape[0], shape[1], dev.index)
+    F = plan.rfft2(_to(dev, x))
+    ref = np.fft.rfft2(x)
+    assert np.max(np.abs(F.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    back = plan.irfft2(F).cpu().numpy()
+    assert np.max(np.abs(back - x)) <= 1e-12 * np.max(np.abs(x))
+
+
+def test_decorrelation_kernel_matches_reference(dev):
+    """DCC on the reference's own decorrelation test inputs against the reference's DCC output (and, transitively, its
+    4check/DeCorrKernel.fits: see tests/golden/make_golden_decorr.py)."""
+    import os
+    from sfft_amd.utils.DeCorrelationCalculator import DeCorrelation_Calculator
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decorr_case.npz"))
+    mkS = [None] + [z["mkS%d" % k] for k in range(1, 5)]
+    mkR = [None] + [z["mkR%d" % k] for k in range(1, 5)]
+    sigS = [float(z["sigS%d" % k]) for k in range(5)]
+    sigR = [float(z["sigR%d" % k]) for k in range(5)]
+    K = DeCorrelation_Calculator.DCC(MK_JLst=mkS, SkySig_JLst=sigS, MK_ILst=mkR, SkySig_ILst=sigR, MK_Fin=z["mkFin"], KERatio=2.0,
+                                     VERBOSE_LEVEL=0, CUDA_DEVICE=dev.index)
+    assert K.shape == z["KDeCo_sub"].shape
+    assert np.max(np.abs(K - z["KDeCo_sub"])) <= 1e-11 * np.max(np.abs(z["KDeCo_sub"]))
+    Ks = DeCorrelation_Calculator.DCC(MK_JLst=mkS, SkySig_JLst=sigS, KERatio=1.5, VERBOSE_LEVEL=0, CUDA_DEVICE=dev.index)
+    assert np.max(np.abs(Ks - z["KDeCo_stack"])) <= 1e-11 * np.max(np.abs(z["KDeCo_stack"]))
+    with pytest.raises(Exception, match="at least 2 J-images"):
+        DeCorrelation_Calculator.DCC(MK_JLst=[z["mkFin"]], SkySig_JLst=[1.0], VERBOSE_LEVEL=0)
+
+
+def test_pcdc_and_fft_convolve_match_oracle(dev):
+    from oracle import decorr_oracle as DO
+    from sfft_amd.utils.PureCupyDeCorrelationCalculator import PureCupy_DeCorrelation_Calculator as P
+    from sfft_amd.utils.PureCupyFFTKits import PureCupy_FFTKits as FK
+    rng = np.random.default_rng(8)
+    g = lambda L: np.exp(-0.5 * (np.arange(L) - L // 2)[:, None] ** 2 / 2.0 - 0.5 * (np.arange(L) - L // 2)[None, :] ** 2 / 3.0) * (1 + 0.05 * rng.normal(size=(L, L)))
+    KJ, KI, MK = [g(9), None, g(11)], [g(7), g(9)], g(13)
+    sJ, sI = [2.0, 3.0, 2.5], [1.5, 1.0]
+    NX, NY = 200, 144
+    t = lambda a: None if a is None else _to(dev, a)
+    F = P.PCDC(NX, NY, [t(k) for k in KJ], sJ, [t(k) for k in KI], sI, MATCH_KERNEL_GPU=t(MK), REAL_OUTPUT=False).cpu().numpy()
+    Fo = DO.pcdc_fourier(NX, NY, KJ, sJ, KI, sI, MK)
+    assert F.shape == (NX, NY) and np.max(np.abs(F - Fo)) <= 1e-12 * np.max(np.abs(Fo))
+    img = rng.normal(size=(150, 131)) * 10
+    img[5, 7] = np.nan
+    K11 = np.exp(-0.5 * (np.arange(11) - 5)[:, None] ** 2 / 2.0 - 0.5 * (np.arange(11) - 5)[None, :] ** 2 / 3.0)
+    out = FK.FFT_CONVOLVE(t(img), t(K11), PAD_FILL_VALUE=1.0, NAN_FILL_VALUE=0.0, NORMALIZE_KERNEL=True).cpu().numpy()
+    ref = DO.fft_convolve(img.copy(), K11, 1.0, 0.0, True)
+    assert out.shape == img.shape and np.max(np.abs(out - ref)) <= 1e-11 * np.max(np.abs(ref))
