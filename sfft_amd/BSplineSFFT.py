@@ -15,6 +15,7 @@ import time
 import numpy as np
 import torch
 
+from ._packet_common import union_nan_mask, assign_roles, finish_diff
 from .plan import Plan
 from .sfftcore.SFFTSubtract import (ElementalSFFTSubtract, ElementalSFFTSubtract_PureCupy, GeneralSFFTSubtract,
                                     GeneralSFFTSubtract_PureCupy)
@@ -162,12 +163,9 @@ class BSpline_Packet:
             return np.ascontiguousarray(a, dtype=np.float64)
         PixA_REF, PixA_SCI = read_T(FITS_REF), read_T(FITS_SCI)
         PixA_mREF, PixA_mSCI = read_T(FITS_mREF), read_T(FITS_mSCI)
-        NaNmask_U = None
-        if np.isnan(PixA_REF).any() or np.isnan(PixA_SCI).any():
-            NaNmask_U = np.logical_or(np.isnan(PixA_REF), np.isnan(PixA_SCI))
+        NaNmask_U = union_nan_mask(np, PixA_REF, PixA_SCI)
         assert np.sum(np.isnan(PixA_mREF)) == 0
         assert np.sum(np.isnan(PixA_mSCI)) == 0
-        assert ForceConv in ['REF', 'SCI']
         ConvdSide, KerHW = ForceConv, GKerHW
         torch.cuda.set_device(int(CUDA_DEVICE_4SUBTRACT))
         if VERBOSE_LEVEL in [0, 1, 2]:
@@ -183,23 +181,13 @@ class BSpline_Packet:
             CUDA_DEVICE_4SUBTRACT=int(CUDA_DEVICE_4SUBTRACT))
         if VERBOSE_LEVEL in [1, 2]:
             print('\nMeLOn Report: FUNCTION COMPILATIONS OF SFFT-SUBTRACTION TAKES [%.3f s] \n' % (time.time() - Tcomp_start))
-        if ConvdSide == 'REF':
-            PixA_mI, PixA_mJ, PixA_I, PixA_J = PixA_mREF, PixA_mSCI, PixA_REF, PixA_SCI
-        else:
-            PixA_mI, PixA_mJ, PixA_I, PixA_J = PixA_mSCI, PixA_mREF, PixA_SCI, PixA_REF
-        if NaNmask_U is not None:
-            PixA_I, PixA_J = PixA_I.copy(), PixA_J.copy()
-            PixA_I[NaNmask_U] = PixA_mI[NaNmask_U]
-            PixA_J[NaNmask_U] = PixA_mJ[NaNmask_U]
+        PixA_I, PixA_J, PixA_mI, PixA_mJ = assign_roles(np, PixA_REF, PixA_SCI, PixA_mREF, PixA_mSCI, ConvdSide, NaNmask_U)
         Tsub_start = time.time()
         Solution, PixA_DIFF = GeneralSFFTSubtract.GSS(PixA_I=PixA_I, PixA_J=PixA_J, PixA_mI=PixA_mI, PixA_mJ=PixA_mJ,
                                                      SFFTConfig=SFFTConfig, ContamMask_I=None, VERBOSE_LEVEL=VERBOSE_LEVEL)[:2]
         if VERBOSE_LEVEL in [1, 2]:
             print('\nMeLOn Report: SFFT-SUBTRACTION TAKES [%.3f s] \n' % (time.time() - Tsub_start))
-        if NaNmask_U is not None:
-            PixA_DIFF[NaNmask_U] = np.nan
-        if ConvdSide == 'SCI':
-            PixA_DIFF = -PixA_DIFF
+        PixA_DIFF = finish_diff(PixA_DIFF, ConvdSide, NaNmask_U)
 
         kw = [('NAME_REF', pa.basename(FITS_REF)), ('NAME_SCI', pa.basename(FITS_SCI)), ('BEND4SUB', BACKEND_4SUBTRACT),
               ('CONVD', ConvdSide), ('KERHW', KerHW), ('KSPTYPE', str(KerSpType)), ('KSPDEG', KerSpDegree),

@@ -9,6 +9,7 @@ import time
 import numpy as np
 import torch
 
+from ._packet_common import union_nan_mask, assign_roles, finish_diff
 from .sfftcore.SFFTConfigure import SingleSFFTConfigure
 from .sfftcore.SFFTSubtract import GeneralSFFTSubtract
 from .utils import minifits
@@ -43,16 +44,10 @@ class Customized_Packet:
         PixA_mREF = _read_T(FITS_mREF)
         PixA_mSCI = _read_T(FITS_mSCI)
 
-        NaNmask_U = None
-        NaNmask_REF = np.isnan(PixA_REF)
-        NaNmask_SCI = np.isnan(PixA_SCI)
-        if NaNmask_REF.any() or NaNmask_SCI.any():
-            NaNmask_U = np.logical_or(NaNmask_REF, NaNmask_SCI)
+        NaNmask_U = union_nan_mask(np, PixA_REF, PixA_SCI)
         assert np.sum(np.isnan(PixA_mREF)) == 0
         assert np.sum(np.isnan(PixA_mSCI)) == 0
-        assert ForceConv in ['REF', 'SCI']
-        ConvdSide = ForceConv
-        KerHW = GKerHW
+        ConvdSide, KerHW = ForceConv, GKerHW
 
         if BACKEND_4SUBTRACT not in ('Cupy', 'HIP'):
             raise Exception("MeLOn ERROR: sfft_amd only provides the GPU backend (BACKEND_4SUBTRACT='Cupy')")
@@ -70,23 +65,7 @@ class Customized_Packet:
         if VERBOSE_LEVEL in [1, 2]:
             print('\nMeLOn Report: Function Compilations of SFFT-SUBTRACTION TAKES [%.3f s]' % (time.time() - Tcomp_start))
 
-        # * role swap and NaN fill (CustomizedPacket.py:148-162)
-        if ConvdSide == 'REF':
-            PixA_mI, PixA_mJ = PixA_mREF, PixA_mSCI
-            if NaNmask_U is not None:
-                PixA_I, PixA_J = PixA_REF.copy(), PixA_SCI.copy()
-                PixA_I[NaNmask_U] = PixA_mI[NaNmask_U]
-                PixA_J[NaNmask_U] = PixA_mJ[NaNmask_U]
-            else:
-                PixA_I, PixA_J = PixA_REF, PixA_SCI
-        if ConvdSide == 'SCI':
-            PixA_mI, PixA_mJ = PixA_mSCI, PixA_mREF
-            if NaNmask_U is not None:
-                PixA_I, PixA_J = PixA_SCI.copy(), PixA_REF.copy()
-                PixA_I[NaNmask_U] = PixA_mI[NaNmask_U]
-                PixA_J[NaNmask_U] = PixA_mJ[NaNmask_U]
-            else:
-                PixA_I, PixA_J = PixA_SCI, PixA_REF
+        PixA_I, PixA_J, PixA_mI, PixA_mJ = assign_roles(np, PixA_REF, PixA_SCI, PixA_mREF, PixA_mSCI, ConvdSide, NaNmask_U)
 
         if VERBOSE_LEVEL in [0, 1, 2]:
             print('MeLOn CheckPoint: TRIGGER SFFT-SUBTRACTION!')
@@ -98,10 +77,7 @@ class Customized_Packet:
         if VERBOSE_LEVEL in [1, 2]:
             print('\nMeLOn Report: SFFT-SUBTRACTION TAKES [%.3f s]' % (time.time() - Tsub_start))
 
-        if NaNmask_U is not None:
-            PixA_DIFF[NaNmask_U] = np.nan
-        if ConvdSide == 'SCI':
-            PixA_DIFF = -PixA_DIFF
+        PixA_DIFF = finish_diff(PixA_DIFF, ConvdSide, NaNmask_U)
 
         # * Save difference image (CustomizedPacket.py:191-203): SCI's header + the SFFT keywords
         if FITS_DIFF is not None:

@@ -8,6 +8,7 @@ import time
 import numpy as np
 import torch
 
+from ._packet_common import union_nan_mask, assign_roles, finish_diff
 from .sfftcore.SFFTConfigure import SingleSFFTConfigure
 from .sfftcore.SFFTSubtract import GeneralSFFTSubtract_PureCupy
 
@@ -47,12 +48,7 @@ class PureCupy_Customized_Packet:
         KerHW = GKerHW
         torch.cuda.set_device(dev)
 
-        # * Create the union NaN mask (:125-131)
-        NaNmask_REF_GPU = torch.isnan(PixA_REF_GPU)
-        NaNmask_SCI_GPU = torch.isnan(PixA_SCI_GPU)
-        NaNmask_GPU = None
-        if bool(NaNmask_REF_GPU.any()) or bool(NaNmask_SCI_GPU.any()):
-            NaNmask_GPU = torch.logical_or(NaNmask_REF_GPU, NaNmask_SCI_GPU)
+        NaNmask_GPU = union_nan_mask(torch, PixA_REF_GPU, PixA_SCI_GPU)
 
         if VERBOSE_LEVEL in [0, 1, 2]:
             print('MeLOn CheckPoint: TRIGGER Function Compilations of SFFT-SUBTRACTION!')
@@ -65,23 +61,8 @@ class PureCupy_Customized_Packet:
         if VERBOSE_LEVEL in [1, 2]:
             print('\nMeLOn Report: Function Compilations of SFFT-SUBTRACTION TAKES [%.3f s]' % (time.time() - Tcomp_start))
 
-        # * role swap and NaN fill (:148-162)
-        if ConvdSide == 'REF':
-            PixA_mI_GPU, PixA_mJ_GPU = PixA_mREF_GPU, PixA_mSCI_GPU
-            if NaNmask_GPU is not None:
-                PixA_I_GPU, PixA_J_GPU = PixA_REF_GPU.clone(), PixA_SCI_GPU.clone()
-                PixA_I_GPU[NaNmask_GPU] = PixA_mI_GPU[NaNmask_GPU]
-                PixA_J_GPU[NaNmask_GPU] = PixA_mJ_GPU[NaNmask_GPU]
-            else:
-                PixA_I_GPU, PixA_J_GPU = PixA_REF_GPU, PixA_SCI_GPU
-        if ConvdSide == 'SCI':
-            PixA_mI_GPU, PixA_mJ_GPU = PixA_mSCI_GPU, PixA_mREF_GPU
-            if NaNmask_GPU is not None:
-                PixA_I_GPU, PixA_J_GPU = PixA_SCI_GPU.clone(), PixA_REF_GPU.clone()
-                PixA_I_GPU[NaNmask_GPU] = PixA_mI_GPU[NaNmask_GPU]
-                PixA_J_GPU[NaNmask_GPU] = PixA_mJ_GPU[NaNmask_GPU]
-            else:
-                PixA_I_GPU, PixA_J_GPU = PixA_SCI_GPU, PixA_REF_GPU
+        PixA_I_GPU, PixA_J_GPU, PixA_mI_GPU, PixA_mJ_GPU = assign_roles(
+            torch, PixA_REF_GPU, PixA_SCI_GPU, PixA_mREF_GPU, PixA_mSCI_GPU, ConvdSide, NaNmask_GPU)
 
         Tsub_start = time.time()
         Solution_GPU, PixA_DIFF_GPU, _ = GeneralSFFTSubtract_PureCupy.GSS(
@@ -90,9 +71,5 @@ class PureCupy_Customized_Packet:
         if VERBOSE_LEVEL in [1, 2]:
             print('\nMeLOn Report: SFFT-SUBTRACTION TAKES [%.3f s]' % (time.time() - Tsub_start))
 
-        # * Modifications on the difference image (:170-185)
-        if NaNmask_GPU is not None:
-            PixA_DIFF_GPU[NaNmask_GPU] = np.nan
-        if ConvdSide == 'SCI':
-            PixA_DIFF_GPU *= -1.
+        PixA_DIFF_GPU = finish_diff(PixA_DIFF_GPU, ConvdSide, NaNmask_GPU)
         return Solution_GPU, PixA_DIFF_GPU
