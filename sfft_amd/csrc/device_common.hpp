@@ -1,0 +1,132 @@
+// device_common.hpp -- complex arithmetic helpers and the on-chip (LDS) FFT core: Stockham radix-4 + Bluestein.
+// Part of libsfft_amd (MI355X / gfx950); included by sfft_amd.hip only.
+#ifndef SFFT_AMD_DEVICE_COMMON_HPP
+#define SFFT_AMD_DEVICE_COMMON_HPP
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double ipow(double x, int e) { double r = 1.0; for (int t = 0; t < e; ++t) r *= x; return r; }
+
+// In-place Stockham autosort FFT (forward, e^{-i}) of `nb` transforms of length M = 2^logM held in LDS at
+// s + f*stride.  Radix-4 stages (one leading radix-2 stage when logM is odd).  Every thread of the block
+// must call; requires nb*M <= 16*blockDim.x so that a thread owns at most 4 radix-4 butterflies per stage.
+// tw[k] = exp(-2*pi*i*k/M), k < M (global memory, cached).
+__device__ __forceinline__ void lds_fft(cplx* s, int M, int logM, int nb, int stride, const cplx* __restrict__ tw)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int p = 1, logp = 0;
+    if (logM & 1) {
+        const int T = M >> 1, logT = logM - 1, total = nb * T;
+        cplx u[8][2];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                const cplx* b = s + f * stride;
+                u[it][0] = b[i];
+                u[it][1] = b[i + T];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                cplx* b = s + f * stride;
+                b[2 * i] = cadd(u[it][0], u[it][1]);
+                b[2 * i + 1] = csub(u[it][0], u[it][1]);
+            }
+        }
+        __syncthreads();
+        p = 2; logp = 1;
+    }
+    const int T = M >> 2, logT = logM - 2, total = nb * T;
+    for (; p < M; p <<= 2, logp += 2) {
+        cplx y[4][4];
+        const int tshift = logM - logp - 2;   // twiddle step M/(4p)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                const int k = i & (p - 1);
+                const cplx* b = s + f * stride;
+                cplx u0 = b[i], u1 = b[i + T], u2 = b[i + 2 * T], u3 = b[i + 3 * T];
+                if (p > 1) {
+                    const int q = k << tshift;
+                    u1 = cmul(u1, tw[q]);
+                    u2 = cmul(u2, tw[2 * q]);
+                    u3 = cmul(u3, tw[3 * q]);
+                }
+                const cplx a02 = cadd(u0, u2), s02 = csub(u0, u2);
+                const cplx a13 = cadd(u1, u3), s13 = csub(u1, u3);
+                y[it][0] = cadd(a02, a13);
+                y[it][2] = csub(a02, a13);
+                // -i*(u1-u3) = (s13.y, -s13.x)
+                y[it][1] = make_double2(s02.x + s13.y, s02.y - s13.x);
+                y[it][3] = make_double2(s02.x - s13.y, s02.y + s13.x);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int g = tid + it * nt;
+            if (g < total) {
+                const int f = g >> logT, i = g & (T - 1);
+                const int k = i & (p - 1);
+                cplx* b = s + f * stride + (((i - k) << 2) + k);
+                b[0] = y[it][0];
+                b[p] = y[it][1];
+                b[2 * p] = y[it][2];
+                b[3 * p] = y[it][3];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One 1-D axis: length N transformed either directly (N = M power of two) or by Bluestein's chirp-z
+// (M = power of two >= 2N-1).  All tables live in device memory.
+struct AxisDev {
+    int N, M, logM, blue;
+    const cplx* tw;     // [M]   exp(-2 pi i k / M)
+    const cplx* chirp;  // [N]   exp(-i pi n^2 / N)            (Bluestein only)
+    const cplx* bf;     // [M]   FFT_M(conj-chirp filter) / M  (Bluestein only)
+    const cplx* root;   // [N]   exp(-2 pi i k / N)
+};
+
+// forward length-N DFT of nb sequences already resident in LDS (entries n >= N must be zero when blue).
+// On return entries [0, N) of each sequence hold the DFT.
+__device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int stride)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (!ax.blue) { lds_fft(s, ax.M, ax.logM, nb, stride, ax.tw); return; }
+    const int M = ax.M;
+    for (int e = tid; e < nb * M; e += nt) {           // a[n] = x[n] * chirp[n]
+        const int f = e / M, n = e - f * M;
+        if (n < ax.N) s[f * stride + n] = cmul(s[f * stride + n], ax.chirp[n]);
+    }
+    __syncthreads();
+    lds_fft(s, M, ax.logM, nb, stride, ax.tw);
+    for (int e = tid; e < nb * M; e += nt) {           // conj(A * Bf): second forward FFT then acts as inverse
+        const int f = e / M, k = e - f * M;
+        s[f * stride + k] = cconj(cmul(s[f * stride + k], ax.bf[k]));
+    }
+    __syncthreads();
+    lds_fft(s, M, ax.logM, nb, stride, ax.tw);
+    for (int e = tid; e < nb * M; e += nt) {
+        const int f = e / M, k = e - f * M;
+        if (k < ax.N) s[f * stride + k] = cmul(ax.chirp[k], cconj(s[f * stride + k]));
+    }
+    __syncthreads();
+}
+
+#endif

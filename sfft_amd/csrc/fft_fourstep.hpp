@@ -1,0 +1,115 @@
+// fft_fourstep.hpp -- four-step transforms for axes that do not fit one on-chip FFT.
+// Part of libsfft_amd (MI355X / gfx950); included by sfft_amd.hip only.
+#ifndef SFFT_AMD_FFT_FOURSTEP_HPP
+#define SFFT_AMD_FFT_FOURSTEP_HPP
+
+// ================================================================================================
+// Axes too long for one on-chip transform (e.g. 6144, 9216, 9232): four-step decomposition N = A * B,
+//     X[ka + A kb] = sum_nb W_N^(nb ka) [ sum_na x[B na + nb] W_A^(na ka) ] W_B^(nb kb),
+// as two passes of batched strided sub-transforms (lengths A and B, each power of two or Bluestein on chip)
+// through global memory.  Correctness path for the large BASELINE configs; not tuned.
+// ================================================================================================
+struct PassDesc {
+    int len, J, nlines, mode;              // mode: which index runs fastest over threads (0: element, 1: j, 2: line)
+    long long js_in, es_in, lst_in;        // strides in complex elements: sequence j, element e, line
+    long long js_out, es_out, lst_out;
+    int twiddle, N;                        // multiply output k of sequence j by rootN[(j k) mod N]
+    int conj_in, conj_out;
+    double scale;
+};
+
+__global__ void __launch_bounds__(1024) strided_dft(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax,
+                                                     const cplx* __restrict__ rootN, int TC, int MS)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int M = ax.M;
+    for (int x = tid; x < TC * M; x += nt) {
+        int c, e;
+        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
+        const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
+        const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
+        cplx z = make_double2(0.0, 0.0);
+        if (e < d.len && j < d.J && line < d.nlines) {
+            z = in[(long long)line * d.lst_in + (long long)j * d.js_in + (long long)e * d.es_in];
+            if (d.conj_in) z.y = -z.y;
+        }
+        s[c * MS + e] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, TC, MS);
+    for (int x = tid; x < TC * M; x += nt) {
+        int c, e;
+        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
+        const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
+        const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
+        if (e < d.len && j < d.J && line < d.nlines) {
+            cplx z = s[c * MS + e];
+            if (d.twiddle) z = cmul(z, rootN[(int)(((long long)j * e) % d.N)]);
+            if (d.conj_out) z.y = -z.y;
+            out[(long long)line * d.lst_out + (long long)j * d.js_out + (long long)e * d.es_out] = make_double2(z.x * d.scale, z.y * d.scale);
+        }
+    }
+}
+
+// Z[pair][n] = (I[2 pair][n] w, I[2 pair + 1][n] w'): two real rows per complex sequence, SpatialPoly fused
+__global__ void __launch_bounds__(256) pack_rows(const double* __restrict__ src, const double* __restrict__ wx,
+                                                 const double* __restrict__ wy, cplx* __restrict__ Z, int N0, int N1)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (n >= N1) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const double cyp = wy ? wy[n] : 1.0;
+    const double v0 = src[(size_t)l0 * N1 + n] * ((wx ? wx[l0] : 1.0) * cyp);
+    const double v1 = (l1 < N0) ? src[(size_t)l1 * N1 + n] * ((wx ? wx[l1] : 1.0) * cyp) : 0.0;
+    Z[(size_t)pr * N1 + n] = make_double2(v0, v1);
+}
+
+// half spectra of the two real rows from the transform of their packed sequence (same algebra as rows_r2c)
+__global__ void __launch_bounds__(256) untangle_rows(const cplx* __restrict__ Zf, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
+                                                     double scale)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (m >= Nh) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const cplx z = Zf[(size_t)pr * N1 + m];
+    const cplx zp = Zf[(size_t)pr * N1 + (m == 0 ? 0 : N1 - m)];
+    const cplx zc = make_double2(zp.x, -zp.y);
+    const double hs = 0.5 * scale;
+    out[(size_t)l0 * Nhp + m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
+    if (l1 < N0) out[(size_t)l1 * Nhp + m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+}
+
+// conj(X0 + i X1) on the full length from the half spectra of two rows (input of the inverse row transform)
+__global__ void __launch_bounds__(256) retangle_rows(const cplx* __restrict__ FD, cplx* __restrict__ Z, int N0, int N1, int Nh, int Nhp)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (m >= N1) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const bool has1 = l1 < N0, even = (N1 & 1) == 0;
+    const bool mir = m >= Nh;
+    const int mm = mir ? N1 - m : m;
+    cplx x0 = FD[(size_t)l0 * Nhp + mm];
+    cplx x1 = has1 ? FD[(size_t)l1 * Nhp + mm] : make_double2(0.0, 0.0);
+    if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
+    if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
+    Z[(size_t)pr * N1 + m] = make_double2(x0.x - x1.y, -(x0.y + x1.x));
+}
+
+// DIFF = J - sum_pq b_pq cx^p cy^q - conv from the transformed packed rows (see rows_c2r_diff)
+__global__ void __launch_bounds__(256) finish_diff(const cplx* __restrict__ Zf, const double* __restrict__ J, const double* __restrict__ bpq,
+                                                   BkgArgs bk, double* __restrict__ DIFF, int N0, int N1)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (n >= N1) return;
+    const int l0 = 2 * pr, l1 = l0 + 1;
+    const cplx z = Zf[(size_t)pr * N1 + n];
+    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, (l1 < N0) ? l1 : l0, N0, c1);
+    DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c0, n, N1) - z.x;
+    if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
+}
+
+#endif

@@ -1,0 +1,163 @@
+// fft_generic.hpp -- generic on-chip 2-D FFT passes: rows r2c, columns c2c, rows c2r + DIFF epilogue; background evaluation helpers.
+// Part of libsfft_amd (MI355X / gfx950); included by sfft_amd.hip only.
+#ifndef SFFT_AMD_FFT_GENERIC_HPP
+#define SFFT_AMD_FFT_GENERIC_HPP
+
+// ------------------------------------------------------------------------------------------------
+// forward pass 1: rows, real -> half complex, two image rows per complex transform, SpatialPoly fused
+// ------------------------------------------------------------------------------------------------
+#define SFFT_MAX_PLANES 12
+struct RowsArgs {                           // plane k = src[k] * wx[k][row] * wy[k][col]   (null weight = 1)
+    const double* src[SFFT_MAX_PLANES];
+    const double* wx[SFFT_MAX_PLANES];      // [N0] factor of the spatial basis along axis 0 (cx^i or a B-spline basis function)
+    const double* wy[SFFT_MAX_PLANES];      // [N1] factor along axis 1
+};
+
+__global__ void __launch_bounds__(1024) rows_r2c(RowsArgs a, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
+                                                  AxisDev ax, double scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int plane = blockIdx.y;
+    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const double* __restrict__ src = a.src[plane];
+    const double* __restrict__ wx = a.wx[plane];
+    const double* __restrict__ wy = a.wy[plane];
+    const bool has1 = l1 < N0;
+    const double cx0 = wx ? wx[l0] : 1.0;
+    const double cx1 = (wx && has1) ? wx[l1] : 1.0;
+    for (int n = tid; n < ax.M; n += nt) {
+        cplx z = make_double2(0.0, 0.0);
+        if (n < N1) {
+            const double cyp = wy ? wy[n] : 1.0;
+            z.x = src[(size_t)l0 * N1 + n] * (cx0 * cyp);
+            if (has1) z.y = src[(size_t)l1 * N1 + n] * (cx1 * cyp);
+        }
+        s[n] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, 1, ax.M);
+    cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
+    cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
+    for (int m = tid; m < Nh; m += nt) {
+        const cplx z = s[m];
+        const cplx zc = cconj(s[m == 0 ? 0 : N1 - m]);
+        o0[m] = make_double2(0.5 * scale * (z.x + zc.x), 0.5 * scale * (z.y + zc.y));
+        if (has1) {
+            const double dx = z.x - zc.x, dy = z.y - zc.y;   // (Z - Zc) / (2i) = (dy, -dx)/2
+            o1[m] = make_double2(0.5 * scale * dy, -0.5 * scale * dx);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: columns, complex -> complex in place, TC adjacent columns per workgroup
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) cols_c2c(cplx* __restrict__ data, int N0, int ncols, int Nhp, int TC, int MS,
+                                                  AxisDev ax, int inverse, double scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int c0 = blockIdx.x * TC;
+    cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp;
+    for (int e = tid; e < TC * ax.M; e += nt) {
+        const int l = e / TC, c = e - l * TC;
+        cplx z = make_double2(0.0, 0.0);
+        if (l < N0 && c0 + c < ncols) {
+            z = base[(size_t)l * Nhp + c0 + c];
+            if (inverse) z.y = -z.y;
+        }
+        s[c * MS + l] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, TC, MS);
+    for (int e = tid; e < TC * N0; e += nt) {
+        const int l = e / TC, c = e - l * TC;
+        if (c0 + c < ncols) {
+            cplx z = s[c * MS + l];
+            if (inverse) z.y = -z.y;
+            base[(size_t)l * Nhp + c0 + c] = make_double2(z.x * scale, z.y * scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse pass 2: rows, half complex -> real, two rows per transform, DIFF epilogue fused:
+//   DIFF = J - sum_pq b_pq cx^p cy^q - conv          (SFFTSubtract.py:452-461 with the J and T terms kept in real space)
+// ------------------------------------------------------------------------------------------------
+#define SFFT_MAX_PQ 64
+#define SFFT_MAX_BQ 16
+// differential background B(row, col) = sum_t b[t] * tbx[p[t]][row] * tby[q[t]][col]  (tables of the 1-D basis factors)
+struct BkgArgs {
+    int npq, nq;                    // terms, distinct column factors
+    const double* tbx;              // [nbx][N0]
+    const double* tby;              // [nby][N1]
+    int p[SFFT_MAX_PQ], q[SFFT_MAX_PQ];
+};
+
+// per-row coefficients of the column factors: c[q] = sum_{t: q[t] = q} b[t] * tbx[p[t]][row]
+// (NQ = compile-time bound on the number of column factors: 4 covers polynomial backgrounds, 16 the general case)
+template <int NQ>
+__device__ __forceinline__ void bkg_row_coeffs(const BkgArgs& bk, const double* __restrict__ bpq, int row, int N0, double (&c)[NQ])
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) c[q] = 0.0;
+    for (int t = 0; t < bk.npq; ++t) {
+        const double v = bpq[t] * bk.tbx[(size_t)bk.p[t] * N0 + row];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) c[q] += (bk.q[t] == q) ? v : 0.0;
+    }
+}
+template <int NQ>
+__device__ __forceinline__ double bkg_eval(const BkgArgs& bk, const double (&c)[NQ], int col, int N1)
+{
+    double B = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double t = bk.tby[(size_t)min(q, bk.nq - 1) * N1 + col];      // clamped: always a valid, branch-free load
+        B = fma((q < bk.nq) ? c[q] : 0.0, t, B);
+    }
+    return B;
+}
+
+__global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ FD, const double* __restrict__ J,
+                                                       const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
+                                                       int N0, int N1, int Nh, int Nhp, AxisDev ax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const bool has1 = l1 < N0;
+    const cplx* f0 = FD + (size_t)l0 * Nhp;
+    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * Nhp;
+    const bool even = (N1 & 1) == 0;
+    for (int m = tid; m < ax.M; m += nt) {
+        cplx z = make_double2(0.0, 0.0);
+        if (m < N1) {
+            const bool mir = m >= Nh;
+            const int mm = mir ? N1 - m : m;
+            cplx x0 = f0[mm];
+            cplx x1 = has1 ? f1[mm] : make_double2(0.0, 0.0);
+            if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
+            if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
+            // Z = X0 + i X1, conjugated on input so that the forward transform acts as the inverse
+            z = make_double2(x0.x - x1.y, -(x0.y + x1.x));
+        }
+        s[m] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, 1, ax.M);
+    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
+    for (int n = tid; n < N1; n += nt) {
+        const cplx z = s[n];                 // conj(result): row0 = z.x, row1 = -z.y
+        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c0, n, N1) - z.x;
+        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
+    }
+}
+
+#endif

@@ -1,0 +1,213 @@
+// fft_r16_4096.hpp -- register-resident radix-16 fast path for 4096-point axes.
+// Part of libsfft_amd (MI355X / gfx950); included by sfft_amd.hip only.
+#ifndef SFFT_AMD_FFT_R16_4096_HPP
+#define SFFT_AMD_FFT_R16_4096_HPP
+
+// ================================================================================================
+// Fast path for 4096-point axes: register-resident radix-16 FFT.  256 threads own 16 points each through
+// three radix-16 stages (4096 = 16^3); LDS is used only for the two inter-stage exchanges (padded by one
+// element per 16 so that the stride-16 writes of stage 1 are conflict free), not as the working array.
+// ================================================================================================
+#define R16_OUT(s) (4 * ((s) & 3) + ((s) >> 2))      // register holding output s of dft16()
+#define F4K_LDS 4352                                 // 4096 + 4096/16 complex per transform
+
+__device__ __forceinline__ void dft4(cplx& a, cplx& b, cplx& c, cplx& d)
+{
+    const cplx s02 = cadd(a, c), d02 = csub(a, c), s13 = cadd(b, d), d13 = csub(b, d);
+    a = cadd(s02, s13);
+    c = csub(s02, s13);
+    b = make_double2(d02.x + d13.y, d02.y - d13.x);   // d02 - i d13
+    d = make_double2(d02.x - d13.y, d02.y + d13.x);   // d02 + i d13
+}
+
+// forward 16-point DFT in registers; output s ends in u[R16_OUT(s)]
+__device__ __forceinline__ void dft16(cplx (&u)[16])
+{
+    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(u[b], u[4 + b], u[8 + b], u[12 + b]);
+    // u[4c + b] *= W16^(b c)
+    u[5] = cmul(u[5], make_double2(c1, -s1));          // W^1
+    u[6] = cmul(u[6], make_double2(h, -h));            // W^2
+    u[7] = cmul(u[7], make_double2(s1, -c1));          // W^3
+    u[9] = cmul(u[9], make_double2(h, -h));            // W^2
+    u[10] = make_double2(u[10].y, -u[10].x);           // W^4 = -i
+    u[11] = cmul(u[11], make_double2(-h, -h));         // W^6
+    u[13] = cmul(u[13], make_double2(s1, -c1));        // W^3
+    u[14] = cmul(u[14], make_double2(-h, -h));         // W^6
+    u[15] = cmul(u[15], make_double2(-c1, s1));        // W^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(u[4 * c], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);
+}
+
+// u[r] *= tw[r q], r = 1..15, from four table entries (products of at most three factors)
+__device__ __forceinline__ void twiddle16(cplx (&u)[16], const cplx* __restrict__ tw, int q)
+{
+    const cplx w1 = tw[q], w2 = tw[2 * q], w4 = tw[4 * q], w8 = tw[8 * q];
+    const cplx w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
+    const cplx w7 = cmul(w4, w3);
+    u[1] = cmul(u[1], w1); u[2] = cmul(u[2], w2); u[3] = cmul(u[3], w3); u[4] = cmul(u[4], w4);
+    u[5] = cmul(u[5], w5); u[6] = cmul(u[6], w6); u[7] = cmul(u[7], w7); u[8] = cmul(u[8], w8);
+    u[9] = cmul(u[9], cmul(w8, w1)); u[10] = cmul(u[10], cmul(w8, w2)); u[11] = cmul(u[11], cmul(w8, w3));
+    u[12] = cmul(u[12], cmul(w8, w4)); u[13] = cmul(u[13], cmul(w8, w5)); u[14] = cmul(u[14], cmul(w8, w6));
+    u[15] = cmul(u[15], cmul(w8, w7));
+}
+
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+
+// 4096-point forward FFT.  In: u[r] = x[j + 256 r].  Out: u[R16_OUT(s)] = X[j + 256 s].  j in [0, 256).
+// `lds` = this transform's F4K_LDS-element scratch.  Every thread of the block must call (barriers inside).
+__device__ __forceinline__ void fft4096_core(cplx (&u)[16], int j, cplx* lds, const cplx* __restrict__ tw)
+{
+    dft16(u);
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) lds[17 * j + sx] = u[R16_OUT(sx)];            // pad16(16 j + s)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r] = lds[pad16(j + 256 * r)];
+    __syncthreads();
+    const int k = j & 15;
+    twiddle16(u, tw, 16 * k);
+    dft16(u);
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) lds[pad16((j - k) * 16 + k + 16 * sx)] = u[R16_OUT(sx)];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r] = lds[pad16(j + 256 * r)];
+    twiddle16(u, tw, j);
+    dft16(u);
+}
+
+// rows, real -> half complex (N1 = 4096), two image rows per transform, spatial factors fused.  Planes [first, first +
+// count) of a launch group share their source image: the workgroup reads its two rows once and produces every plane.
+struct RowGroups { int ngroups; int first[SFFT_MAX_PLANES]; int count[SFFT_MAX_PLANES]; };
+
+__global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp,
+                                                     const cplx* __restrict__ tw, double scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
+    const int N1 = 4096;
+    const int j = threadIdx.x;
+    const int pfirst = grp.first[blockIdx.y], pcount = grp.count[blockIdx.y];
+    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const bool has1 = l1 < N0;
+    const double* __restrict__ src = a.src[pfirst];
+    const double* r0p = src + (size_t)l0 * N1;
+    const double* r1p = src + (size_t)(has1 ? l1 : l0) * N1;
+    double x0[16], x1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = j + 256 * r;
+        x0[r] = r0p[n];
+        x1[r] = has1 ? r1p[n] : 0.0;
+    }
+    const double hs = 0.5 * scale;
+    for (int pp = 0; pp < pcount; ++pp) {
+        const int plane = pfirst + pp;
+        const double* __restrict__ wx = a.wx[plane];
+        const double* __restrict__ wy = a.wy[plane];
+        const double cx0 = wx ? wx[l0] : 1.0;
+        const double cx1 = (wx && has1) ? wx[l1] : 1.0;
+        cplx u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double cyp = wy ? wy[j + 256 * r] : 1.0;
+            u[r] = make_double2(x0[r] * (cx0 * cyp), x1[r] * (cx1 * cyp));
+        }
+        if (pp > 0) __syncthreads();            // the previous plane's partner reads are done
+        fft4096_core(u, j, lds, tw);
+        __syncthreads();
+#pragma unroll
+        for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)];
+        __syncthreads();
+        cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
+        cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
+#pragma unroll
+        for (int sx = 0; sx <= 8; ++sx) {
+            const int m = j + 256 * sx;
+            if (sx < 8 || j == 0) {
+                const cplx z = u[R16_OUT(sx)];
+                const cplx zp = lds[(N1 - m) & (N1 - 1)];
+                const cplx zc = make_double2(zp.x, -zp.y);
+                o0[m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
+                if (has1) o1[m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+            }
+        }
+    }
+}
+
+// columns, complex -> complex in place (N0 = 4096), two adjacent columns per workgroup (512 threads).
+// Blocks that share 128-byte lines are mapped to the same XCD (block b runs on XCD b % 8) so its L2 merges them.
+__global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, int ncols, int Nhp, const cplx* __restrict__ tw,
+                                                     int inverse, double scale, int pairs_per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
+    const int N0 = 4096;
+    const int c = threadIdx.x & 1, j = threadIdx.x >> 1;
+    const int cp = (blockIdx.x & 7) * pairs_per_xcd + (blockIdx.x >> 3);
+    const int col = 2 * cp + c;
+    const bool ok = (blockIdx.x >> 3) < pairs_per_xcd && col < ncols;
+    cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp + (ok ? col : 0);
+    cplx u[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        cplx z = ok ? base[(size_t)(j + 256 * r) * Nhp] : make_double2(0.0, 0.0);
+        if (inverse) z.y = -z.y;
+        u[r] = z;
+    }
+    fft4096_core(u, j, lds + c * (F4K_LDS + 4), tw);     // +4: the two columns' regions sit half a bank row apart
+    if (!ok) return;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) {
+        cplx z = u[R16_OUT(sx)];
+        if (inverse) z.y = -z.y;
+        base[(size_t)(j + 256 * sx) * Nhp] = make_double2(z.x * scale, z.y * scale);
+    }
+}
+
+// rows, half complex -> real (N1 = 4096), two rows per transform, DIFF epilogue (see rows_c2r_diff)
+template <int NQ>
+__global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict__ FD, const double* __restrict__ J,
+                                                          const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
+                                                          int N0, int Nhp, const cplx* __restrict__ tw)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
+    const int N1 = 4096;
+    const int j = threadIdx.x;
+    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const bool has1 = l1 < N0;
+    const cplx* f0 = FD + (size_t)l0 * Nhp;
+    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * Nhp;
+    cplx u[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = j + 256 * r;
+        const bool mir = m > N1 / 2;
+        const int mm = mir ? N1 - m : m;
+        cplx x0 = f0[mm];
+        cplx x1 = has1 ? f1[mm] : make_double2(0.0, 0.0);
+        if (mm == 0 || mm == N1 / 2) { x0.y = 0.0; x1.y = 0.0; }
+        if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
+        u[r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
+    }
+    fft4096_core(u, j, lds, tw);
+    double c0[NQ], c1[NQ];
+    bkg_row_coeffs<NQ>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<NQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
+    const double* j0 = J + (size_t)l0 * N1;
+    const double* j1 = J + (size_t)(has1 ? l1 : l0) * N1;
+    double* d0 = DIFF + (size_t)l0 * N1;
+    double* d1 = DIFF + (size_t)(has1 ? l1 : l0) * N1;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) {
+        const int n = j + 256 * sx;
+        const cplx z = u[R16_OUT(sx)];
+        d0[n] = j0[n] - bkg_eval<NQ>(bk, c0, n, N1) - z.x;
+        if (has1) d1[n] = j1[n] - bkg_eval<NQ>(bk, c1, n, N1) + z.y;
+    }
+}
+
+#endif

@@ -1,0 +1,224 @@
+// greek.hpp -- Greek stage: pruned column/row transforms of the Hadamard products, Delta moments.
+// Part of libsfft_amd (MI355X / gfx950); included by sfft_amd.hip only.
+#ifndef SFFT_AMD_GREEK_HPP
+#define SFFT_AMD_GREEK_HPP
+
+// ------------------------------------------------------------------------------------------------
+// Greek stage 1: for every listed pass (A, B) and column m of the half spectrum
+//      G[r][m] = sum_l A[l][m] * conj(B[l][m]) * W0^(l r),   |r| <= h          (pruned column DFT of the
+// Hadamard product; only these lags are ever read by FillLS_*, SFFTConfigure.py:251-269, 364-371, 621-628).
+// r and -r share their four real products.  B is a stored plane (Omega, Theta) or, for Gamma, the column
+// factor Xp[l] = DFT(cx^p)[l] of the rank-1 spectrum FT_pq = SCALE * Xp (x) Yq -- the row factor Yq[m] does not
+// depend on l and is applied in stage 2, so one pass serves every q.
+// One wave per 64 columns; RS waves of a workgroup split the lags; rows are loaded U at a time ahead of use.
+// ------------------------------------------------------------------------------------------------
+struct G1Pass {
+    int a_plane;      // plane index into spec
+    int b_plane;      // plane index, or -1: B[l][m] = Xp[bp][l]
+    int bp;
+    int h;            // lag half width
+    long long gp_off; // offset (cplx) of this pass's [S][2h+1][Nhp] partial buffer
+};
+
+struct PatchJob {
+    int pass;         // G1 pass that produced G
+    int yq;           // -1, or q: G[r][m] is multiplied by conj(tscale * Yq[q][m])
+    int h;
+    int patch_off;    // offset (doubles) of this job's [(2h+1)][(2h+1)] patch
+    double scale;
+};
+
+template <int HBW, int RS>
+__global__ void __launch_bounds__(64 * RS) greek_g1(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+                                                    cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
+                                                    int r_base, const cplx* __restrict__ W0tab, int HM, const cplx* __restrict__ Xp)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x * 64 + lane;
+    const int chunk = blockIdx.y;
+    const G1Pass pr = passes[pass0 + blockIdx.z];
+    const int h = pr.h;
+    const int PH = 2 * h + 1;
+    const int lb = chunk * rows_per_chunk;
+    const int le = min(N0, lb + rows_per_chunk);
+    const bool active = m < Nh;
+    const int mc = active ? m : 0;
+    const size_t plane_sz = (size_t)N0 * Nhp;
+    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz + mc;
+    const bool colfac = pr.b_plane < 0;
+    const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz + mc;
+    const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
+    const int rfirst = r_base + 1 + wv * HBW;       // this wave's lags: rfirst .. rfirst + HBW - 1 (wave-uniform)
+    int nact = h - (rfirst - 1);
+    if (nact > HBW) nact = HBW;
+    if (nact < 0) nact = 0;
+    double S1[HBW], S2[HBW], S3[HBW], S4[HBW];
+#pragma unroll
+    for (int t = 0; t < HBW; ++t) { S1[t] = S2[t] = S3[t] = S4[t] = 0.0; }
+    double g0x = 0.0, g0y = 0.0;
+    const bool do_g0 = (r_base == 0 && wv == 0);
+    // W0tab[l][r] = W0^(l r), r = 0..HM-1: one contiguous, wave-uniform row of twiddles per image row (scalar loads)
+    const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + rfirst;
+    for (int l = lb; l < le; ++l, trow += HM) {
+        const cplx av = A[(size_t)l * Nhp];
+        const cplx bv = colfac ? xp[l] : B[(size_t)l * Nhp];
+        const cplx H = cmulc(av, bv);
+        if (do_g0) { g0x += H.x; g0y += H.y; }
+#pragma unroll
+        for (int t = 0; t < HBW; ++t) {
+            if (t < nact) {
+                const cplx w = trow[t];
+                S1[t] = fma(H.x, w.x, S1[t]);
+                S2[t] = fma(H.y, w.y, S2[t]);
+                S3[t] = fma(H.x, w.y, S3[t]);
+                S4[t] = fma(H.y, w.x, S4[t]);
+            }
+        }
+    }
+    if (!active) return;
+    cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp + m;
+    if (do_g0) g[(size_t)h * Nhp] = make_double2(g0x, g0y);
+#pragma unroll
+    for (int t = 0; t < HBW; ++t) {
+        if (t < nact) {
+            const int r = rfirst + t;
+            g[(size_t)(h + r) * Nhp] = make_double2(S1[t] - S2[t], S3[t] + S4[t]);
+            g[(size_t)(h - r) * Nhp] = make_double2(S1[t] + S2[t], S4[t] - S3[t]);
+        }
+    }
+}
+
+// W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)
+__global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N0 * HM) return;
+    const int l = e / HM, r = e - l * HM;
+    W0tab[e] = root0[(int)(((long long)l * r) % N0)];
+}
+
+// Gamma passes with p = 0: Xp = N0 * delta[l], so G[r][m] = N0 * A[0][m] for every lag (chunk 0; other chunks zero)
+__global__ void __launch_bounds__(256) greek_g1_row0(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+                                                     cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int S)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= Nh) return;
+    const G1Pass pr = passes[pass0 + blockIdx.y];
+    const int PH = 2 * pr.h + 1;
+    const cplx a0 = spec[(size_t)pr.a_plane * N0 * Nhp + m];
+    const cplx v = make_double2(a0.x * (double)N0, a0.y * (double)N0);
+    cplx* g = Gp + pr.gp_off + m;
+    for (int c = 0; c < S; ++c)
+        for (int r = 0; r < PH; ++r) g[((size_t)c * PH + r) * Nhp] = (c == 0) ? v : make_double2(0.0, 0.0);
+}
+
+// Greek stage 2: patch[r][e] = scale * sum_{m < Nh} wgt[m] * Re( W1^(m e) * y[m] * sum_chunks G[r][m] ),  |e| <= h.
+// wgt = 1 for the self-conjugate columns (m = 0, and m = N1/2 when N1 is even), 2 otherwise;
+// y[m] = conj(tscale * Yq[q][m]) for Gamma jobs, 1 otherwise.
+__global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, const G1Pass* __restrict__ passes,
+                                                const PatchJob* __restrict__ jobs, int job0,
+                                                double* __restrict__ patches, int Nh, int Nhp, int N1, int S,
+                                                const cplx* __restrict__ root1, const cplx* __restrict__ Yq, double tscale)
+{
+    const PatchJob jb = jobs[job0 + blockIdx.y];
+    const int h = jb.h, PH = 2 * h + 1;
+    const int r = blockIdx.x;
+    if (r >= PH) return;
+    const int tid = threadIdx.x;
+    __shared__ double red[2][4][17];
+    const cplx* g = Gp + passes[jb.pass].gp_off + (size_t)r * Nhp;
+    const cplx* yq = jb.yq >= 0 ? Yq + (size_t)jb.yq * Nhp : nullptr;
+    const bool even = (N1 & 1) == 0;
+    double* out = patches + jb.patch_off + (size_t)r * PH + h;
+    for (int e0 = 0; e0 == 0 || e0 < h; e0 += 16) {
+        double U[17], V[17];
+#pragma unroll
+        for (int t = 0; t < 17; ++t) { U[t] = 0.0; V[t] = 0.0; }
+        const int ne = min(16, h - e0);   // lags e0+1 .. e0+ne, plus lag 0 when e0 == 0
+        for (int m = tid; m < Nh; m += 256) {
+            double gx = 0.0, gy = 0.0;
+            for (int c = 0; c < S; ++c) {
+                const cplx v = g[(size_t)c * PH * Nhp + m];
+                gx += v.x; gy += v.y;
+            }
+            if (yq) {
+                const cplx y = yq[m];
+                const cplx t = cmulc(make_double2(gx, gy), make_double2(y.x * tscale, y.y * tscale));
+                gx = t.x; gy = t.y;
+            }
+            const double wgt = (m == 0 || (even && m == N1 / 2)) ? 1.0 : 2.0;
+            gx *= wgt; gy *= wgt;
+            if (e0 == 0) U[0] += gx;
+            int idx = (int)(((long long)m * e0) % N1);
+#pragma unroll
+            for (int t = 1; t <= 16; ++t) {
+                if (t <= ne) {
+                    idx += m; if (idx >= N1) idx -= N1;
+                    const cplx w = root1[idx];
+                    U[t] = fma(gx, w.x, U[t]);
+                    V[t] = fma(gy, w.y, V[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 17; ++t) {
+            double u = U[t], v = V[t];
+            for (int off = 32; off > 0; off >>= 1) { u += __shfl_down(u, off); v += __shfl_down(v, off); }
+            if ((tid & 63) == 0) { red[0][tid >> 6][t] = u; red[1][tid >> 6][t] = v; }
+        }
+        __syncthreads();
+        if (tid < 17) {
+            const double u = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
+            const double v = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
+            if (tid == 0) { if (e0 == 0) out[0] = jb.scale * u; }
+            else if (tid <= ne) {
+                out[e0 + tid] = jb.scale * (u - v);
+                out[-(e0 + tid)] = jb.scale * (u + v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Delta: rowmom[l][q] = sum_n J[l][n] tby[q][n], then delta[t] = SCALE * sum_l tbx[p[t]][l] rowmom[l][q[t]]
+// (= PreDEL[pq][0][0], SFFTSubtract.py:706-729, evaluated in real space: only element [0][0] is ever read).
+template <int NQ>
+__global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J, double* __restrict__ rowmom, int N0, int N1,
+                                                   const double* __restrict__ tby, int nq)
+{
+    const int l = blockIdx.x, tid = threadIdx.x;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    for (int n = tid; n < N1; n += 256) {
+        const double v = J[(size_t)l * N1 + n];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = fma(v, tby[(size_t)min(q, nq - 1) * N1 + n], acc[q]);   // q >= nq: unused copies
+    }
+    __shared__ double red[4][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double u = acc[q];
+        for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
+        if ((tid & 63) == 0) red[tid >> 6][q] = u;
+    }
+    __syncthreads();
+    if (tid < NQ) rowmom[(size_t)l * SFFT_MAX_BQ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ void __launch_bounds__(256) delta_finish(const double* __restrict__ rowmom, double* __restrict__ delta, int N0,
+                                                    BkgArgs bk, double scale)
+{
+    const int pq = blockIdx.x, tid = threadIdx.x;
+    const int pi = bk.p[pq], q = bk.q[pq];
+    double acc = 0.0;
+    for (int l = tid; l < N0; l += 256) acc = fma(bk.tbx[(size_t)pi * N0 + l], rowmom[(size_t)l * SFFT_MAX_BQ + q], acc);
+    __shared__ double red[4];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) delta[pq] = scale * (red[0] + red[1] + red[2] + red[3]);
+}
+
+#endif

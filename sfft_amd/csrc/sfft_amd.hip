@@ -44,1429 +44,14 @@ static int set_err(int code, const std::string& msg) { g_last_error = msg; retur
 extern "C" const char* sfft_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 
-// ------------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ cplx cmulc(cplx a, cplx b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
-__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double ipow(double x, int e) { double r = 1.0; for (int t = 0; t < e; ++t) r *= x; return r; }
-
-// In-place Stockham autosort FFT (forward, e^{-i}) of `nb` transforms of length M = 2^logM held in LDS at
-// s + f*stride.  Radix-4 stages (one leading radix-2 stage when logM is odd).  Every thread of the block
-// must call; requires nb*M <= 16*blockDim.x so that a thread owns at most 4 radix-4 butterflies per stage.
-// tw[k] = exp(-2*pi*i*k/M), k < M (global memory, cached).
-__device__ __forceinline__ void lds_fft(cplx* s, int M, int logM, int nb, int stride, const cplx* __restrict__ tw)
-{
-    const int tid = threadIdx.x, nt = blockDim.x;
-    int p = 1, logp = 0;
-    if (logM & 1) {
-        const int T = M >> 1, logT = logM - 1, total = nb * T;
-        cplx u[8][2];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int g = tid + it * nt;
-            if (g < total) {
-                const int f = g >> logT, i = g & (T - 1);
-                const cplx* b = s + f * stride;
-                u[it][0] = b[i];
-                u[it][1] = b[i + T];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int g = tid + it * nt;
-            if (g < total) {
-                const int f = g >> logT, i = g & (T - 1);
-                cplx* b = s + f * stride;
-                b[2 * i] = cadd(u[it][0], u[it][1]);
-                b[2 * i + 1] = csub(u[it][0], u[it][1]);
-            }
-        }
-        __syncthreads();
-        p = 2; logp = 1;
-    }
-    const int T = M >> 2, logT = logM - 2, total = nb * T;
-    for (; p < M; p <<= 2, logp += 2) {
-        cplx y[4][4];
-        const int tshift = logM - logp - 2;   // twiddle step M/(4p)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int g = tid + it * nt;
-            if (g < total) {
-                const int f = g >> logT, i = g & (T - 1);
-                const int k = i & (p - 1);
-                const cplx* b = s + f * stride;
-                cplx u0 = b[i], u1 = b[i + T], u2 = b[i + 2 * T], u3 = b[i + 3 * T];
-                if (p > 1) {
-                    const int q = k << tshift;
-                    u1 = cmul(u1, tw[q]);
-                    u2 = cmul(u2, tw[2 * q]);
-                    u3 = cmul(u3, tw[3 * q]);
-                }
-                const cplx a02 = cadd(u0, u2), s02 = csub(u0, u2);
-                const cplx a13 = cadd(u1, u3), s13 = csub(u1, u3);
-                y[it][0] = cadd(a02, a13);
-                y[it][2] = csub(a02, a13);
-                // -i*(u1-u3) = (s13.y, -s13.x)
-                y[it][1] = make_double2(s02.x + s13.y, s02.y - s13.x);
-                y[it][3] = make_double2(s02.x - s13.y, s02.y + s13.x);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int g = tid + it * nt;
-            if (g < total) {
-                const int f = g >> logT, i = g & (T - 1);
-                const int k = i & (p - 1);
-                cplx* b = s + f * stride + (((i - k) << 2) + k);
-                b[0] = y[it][0];
-                b[p] = y[it][1];
-                b[2 * p] = y[it][2];
-                b[3 * p] = y[it][3];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// One 1-D axis: length N transformed either directly (N = M power of two) or by Bluestein's chirp-z
-// (M = power of two >= 2N-1).  All tables live in device memory.
-struct AxisDev {
-    int N, M, logM, blue;
-    const cplx* tw;     // [M]   exp(-2 pi i k / M)
-    const cplx* chirp;  // [N]   exp(-i pi n^2 / N)            (Bluestein only)
-    const cplx* bf;     // [M]   FFT_M(conj-chirp filter) / M  (Bluestein only)
-    const cplx* root;   // [N]   exp(-2 pi i k / N)
-};
-
-// forward length-N DFT of nb sequences already resident in LDS (entries n >= N must be zero when blue).
-// On return entries [0, N) of each sequence hold the DFT.
-__device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int stride)
-{
-    const int tid = threadIdx.x, nt = blockDim.x;
-    if (!ax.blue) { lds_fft(s, ax.M, ax.logM, nb, stride, ax.tw); return; }
-    const int M = ax.M;
-    for (int e = tid; e < nb * M; e += nt) {           // a[n] = x[n] * chirp[n]
-        const int f = e / M, n = e - f * M;
-        if (n < ax.N) s[f * stride + n] = cmul(s[f * stride + n], ax.chirp[n]);
-    }
-    __syncthreads();
-    lds_fft(s, M, ax.logM, nb, stride, ax.tw);
-    for (int e = tid; e < nb * M; e += nt) {           // conj(A * Bf): second forward FFT then acts as inverse
-        const int f = e / M, k = e - f * M;
-        s[f * stride + k] = cconj(cmul(s[f * stride + k], ax.bf[k]));
-    }
-    __syncthreads();
-    lds_fft(s, M, ax.logM, nb, stride, ax.tw);
-    for (int e = tid; e < nb * M; e += nt) {
-        const int f = e / M, k = e - f * M;
-        if (k < ax.N) s[f * stride + k] = cmul(ax.chirp[k], cconj(s[f * stride + k]));
-    }
-    __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward pass 1: rows, real -> half complex, two image rows per complex transform, SpatialPoly fused
-// ------------------------------------------------------------------------------------------------
-#define SFFT_MAX_PLANES 12
-struct RowsArgs {                           // plane k = src[k] * wx[k][row] * wy[k][col]   (null weight = 1)
-    const double* src[SFFT_MAX_PLANES];
-    const double* wx[SFFT_MAX_PLANES];      // [N0] factor of the spatial basis along axis 0 (cx^i or a B-spline basis function)
-    const double* wy[SFFT_MAX_PLANES];      // [N1] factor along axis 1
-};
-
-__global__ void __launch_bounds__(1024) rows_r2c(RowsArgs a, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
-                                                  AxisDev ax, double scale)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* s = reinterpret_cast<cplx*>(smem_raw);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int plane = blockIdx.y;
-    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
-    const double* __restrict__ src = a.src[plane];
-    const double* __restrict__ wx = a.wx[plane];
-    const double* __restrict__ wy = a.wy[plane];
-    const bool has1 = l1 < N0;
-    const double cx0 = wx ? wx[l0] : 1.0;
-    const double cx1 = (wx && has1) ? wx[l1] : 1.0;
-    for (int n = tid; n < ax.M; n += nt) {
-        cplx z = make_double2(0.0, 0.0);
-        if (n < N1) {
-            const double cyp = wy ? wy[n] : 1.0;
-            z.x = src[(size_t)l0 * N1 + n] * (cx0 * cyp);
-            if (has1) z.y = src[(size_t)l1 * N1 + n] * (cx1 * cyp);
-        }
-        s[n] = z;
-    }
-    __syncthreads();
-    lds_dft(s, ax, 1, ax.M);
-    cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
-    cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
-    for (int m = tid; m < Nh; m += nt) {
-        const cplx z = s[m];
-        const cplx zc = cconj(s[m == 0 ? 0 : N1 - m]);
-        o0[m] = make_double2(0.5 * scale * (z.x + zc.x), 0.5 * scale * (z.y + zc.y));
-        if (has1) {
-            const double dx = z.x - zc.x, dy = z.y - zc.y;   // (Z - Zc) / (2i) = (dy, -dx)/2
-            o1[m] = make_double2(0.5 * scale * dy, -0.5 * scale * dx);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// pass 2: columns, complex -> complex in place, TC adjacent columns per workgroup
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) cols_c2c(cplx* __restrict__ data, int N0, int ncols, int Nhp, int TC, int MS,
-                                                  AxisDev ax, int inverse, double scale)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* s = reinterpret_cast<cplx*>(smem_raw);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int c0 = blockIdx.x * TC;
-    cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp;
-    for (int e = tid; e < TC * ax.M; e += nt) {
-        const int l = e / TC, c = e - l * TC;
-        cplx z = make_double2(0.0, 0.0);
-        if (l < N0 && c0 + c < ncols) {
-            z = base[(size_t)l * Nhp + c0 + c];
-            if (inverse) z.y = -z.y;
-        }
-        s[c * MS + l] = z;
-    }
-    __syncthreads();
-    lds_dft(s, ax, TC, MS);
-    for (int e = tid; e < TC * N0; e += nt) {
-        const int l = e / TC, c = e - l * TC;
-        if (c0 + c < ncols) {
-            cplx z = s[c * MS + l];
-            if (inverse) z.y = -z.y;
-            base[(size_t)l * Nhp + c0 + c] = make_double2(z.x * scale, z.y * scale);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// inverse pass 2: rows, half complex -> real, two rows per transform, DIFF epilogue fused:
-//   DIFF = J - sum_pq b_pq cx^p cy^q - conv          (SFFTSubtract.py:452-461 with the J and T terms kept in real space)
-// ------------------------------------------------------------------------------------------------
-#define SFFT_MAX_PQ 64
-#define SFFT_MAX_BQ 16
-// differential background B(row, col) = sum_t b[t] * tbx[p[t]][row] * tby[q[t]][col]  (tables of the 1-D basis factors)
-struct BkgArgs {
-    int npq, nq;                    // terms, distinct column factors
-    const double* tbx;              // [nbx][N0]
-    const double* tby;              // [nby][N1]
-    int p[SFFT_MAX_PQ], q[SFFT_MAX_PQ];
-};
-
-// per-row coefficients of the column factors: c[q] = sum_{t: q[t] = q} b[t] * tbx[p[t]][row]
-// (NQ = compile-time bound on the number of column factors: 4 covers polynomial backgrounds, 16 the general case)
-template <int NQ>
-__device__ __forceinline__ void bkg_row_coeffs(const BkgArgs& bk, const double* __restrict__ bpq, int row, int N0, double (&c)[NQ])
-{
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) c[q] = 0.0;
-    for (int t = 0; t < bk.npq; ++t) {
-        const double v = bpq[t] * bk.tbx[(size_t)bk.p[t] * N0 + row];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) c[q] += (bk.q[t] == q) ? v : 0.0;
-    }
-}
-template <int NQ>
-__device__ __forceinline__ double bkg_eval(const BkgArgs& bk, const double (&c)[NQ], int col, int N1)
-{
-    double B = 0.0;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double t = bk.tby[(size_t)min(q, bk.nq - 1) * N1 + col];      // clamped: always a valid, branch-free load
-        B = fma((q < bk.nq) ? c[q] : 0.0, t, B);
-    }
-    return B;
-}
-
-__global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ FD, const double* __restrict__ J,
-                                                       const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
-                                                       int N0, int N1, int Nh, int Nhp, AxisDev ax)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* s = reinterpret_cast<cplx*>(smem_raw);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
-    const bool has1 = l1 < N0;
-    const cplx* f0 = FD + (size_t)l0 * Nhp;
-    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * Nhp;
-    const bool even = (N1 & 1) == 0;
-    for (int m = tid; m < ax.M; m += nt) {
-        cplx z = make_double2(0.0, 0.0);
-        if (m < N1) {
-            const bool mir = m >= Nh;
-            const int mm = mir ? N1 - m : m;
-            cplx x0 = f0[mm];
-            cplx x1 = has1 ? f1[mm] : make_double2(0.0, 0.0);
-            if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
-            if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
-            // Z = X0 + i X1, conjugated on input so that the forward transform acts as the inverse
-            z = make_double2(x0.x - x1.y, -(x0.y + x1.x));
-        }
-        s[m] = z;
-    }
-    __syncthreads();
-    lds_dft(s, ax, 1, ax.M);
-    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
-    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, l0, N0, c0);
-    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
-    for (int n = tid; n < N1; n += nt) {
-        const cplx z = s[n];                 // conj(result): row0 = z.x, row1 = -z.y
-        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c0, n, N1) - z.x;
-        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
-    }
-}
-
-// ================================================================================================
-// Axes too long for one on-chip transform (e.g. 6144, 9216, 9232): four-step decomposition N = A * B,
-//     X[ka + A kb] = sum_nb W_N^(nb ka) [ sum_na x[B na + nb] W_A^(na ka) ] W_B^(nb kb),
-// as two passes of batched strided sub-transforms (lengths A and B, each power of two or Bluestein on chip)
-// through global memory.  Correctness path for the large BASELINE configs; not tuned.
-// ================================================================================================
-struct PassDesc {
-    int len, J, nlines, mode;              // mode: which index runs fastest over threads (0: element, 1: j, 2: line)
-    long long js_in, es_in, lst_in;        // strides in complex elements: sequence j, element e, line
-    long long js_out, es_out, lst_out;
-    int twiddle, N;                        // multiply output k of sequence j by rootN[(j k) mod N]
-    int conj_in, conj_out;
-    double scale;
-};
-
-__global__ void __launch_bounds__(1024) strided_dft(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax,
-                                                     const cplx* __restrict__ rootN, int TC, int MS)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* s = reinterpret_cast<cplx*>(smem_raw);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int M = ax.M;
-    for (int x = tid; x < TC * M; x += nt) {
-        int c, e;
-        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
-        const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
-        const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
-        cplx z = make_double2(0.0, 0.0);
-        if (e < d.len && j < d.J && line < d.nlines) {
-            z = in[(long long)line * d.lst_in + (long long)j * d.js_in + (long long)e * d.es_in];
-            if (d.conj_in) z.y = -z.y;
-        }
-        s[c * MS + e] = z;
-    }
-    __syncthreads();
-    lds_dft(s, ax, TC, MS);
-    for (int x = tid; x < TC * M; x += nt) {
-        int c, e;
-        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
-        const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
-        const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
-        if (e < d.len && j < d.J && line < d.nlines) {
-            cplx z = s[c * MS + e];
-            if (d.twiddle) z = cmul(z, rootN[(int)(((long long)j * e) % d.N)]);
-            if (d.conj_out) z.y = -z.y;
-            out[(long long)line * d.lst_out + (long long)j * d.js_out + (long long)e * d.es_out] = make_double2(z.x * d.scale, z.y * d.scale);
-        }
-    }
-}
-
-// Z[pair][n] = (I[2 pair][n] w, I[2 pair + 1][n] w'): two real rows per complex sequence, SpatialPoly fused
-__global__ void __launch_bounds__(256) pack_rows(const double* __restrict__ src, const double* __restrict__ wx,
-                                                 const double* __restrict__ wy, cplx* __restrict__ Z, int N0, int N1)
-{
-    const int n = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
-    if (n >= N1) return;
-    const int l0 = 2 * pr, l1 = l0 + 1;
-    const double cyp = wy ? wy[n] : 1.0;
-    const double v0 = src[(size_t)l0 * N1 + n] * ((wx ? wx[l0] : 1.0) * cyp);
-    const double v1 = (l1 < N0) ? src[(size_t)l1 * N1 + n] * ((wx ? wx[l1] : 1.0) * cyp) : 0.0;
-    Z[(size_t)pr * N1 + n] = make_double2(v0, v1);
-}
-
-// half spectra of the two real rows from the transform of their packed sequence (same algebra as rows_r2c)
-__global__ void __launch_bounds__(256) untangle_rows(const cplx* __restrict__ Zf, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
-                                                     double scale)
-{
-    const int m = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
-    if (m >= Nh) return;
-    const int l0 = 2 * pr, l1 = l0 + 1;
-    const cplx z = Zf[(size_t)pr * N1 + m];
-    const cplx zp = Zf[(size_t)pr * N1 + (m == 0 ? 0 : N1 - m)];
-    const cplx zc = make_double2(zp.x, -zp.y);
-    const double hs = 0.5 * scale;
-    out[(size_t)l0 * Nhp + m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
-    if (l1 < N0) out[(size_t)l1 * Nhp + m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
-}
-
-// conj(X0 + i X1) on the full length from the half spectra of two rows (input of the inverse row transform)
-__global__ void __launch_bounds__(256) retangle_rows(const cplx* __restrict__ FD, cplx* __restrict__ Z, int N0, int N1, int Nh, int Nhp)
-{
-    const int m = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
-    if (m >= N1) return;
-    const int l0 = 2 * pr, l1 = l0 + 1;
-    const bool has1 = l1 < N0, even = (N1 & 1) == 0;
-    const bool mir = m >= Nh;
-    const int mm = mir ? N1 - m : m;
-    cplx x0 = FD[(size_t)l0 * Nhp + mm];
-    cplx x1 = has1 ? FD[(size_t)l1 * Nhp + mm] : make_double2(0.0, 0.0);
-    if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
-    if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
-    Z[(size_t)pr * N1 + m] = make_double2(x0.x - x1.y, -(x0.y + x1.x));
-}
-
-// DIFF = J - sum_pq b_pq cx^p cy^q - conv from the transformed packed rows (see rows_c2r_diff)
-__global__ void __launch_bounds__(256) finish_diff(const cplx* __restrict__ Zf, const double* __restrict__ J, const double* __restrict__ bpq,
-                                                   BkgArgs bk, double* __restrict__ DIFF, int N0, int N1)
-{
-    const int n = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
-    if (n >= N1) return;
-    const int l0 = 2 * pr, l1 = l0 + 1;
-    const cplx z = Zf[(size_t)pr * N1 + n];
-    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
-    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, l0, N0, c0);
-    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, (l1 < N0) ? l1 : l0, N0, c1);
-    DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c0, n, N1) - z.x;
-    if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
-}
-
-// ================================================================================================
-// Fast path for 4096-point axes: register-resident radix-16 FFT.  256 threads own 16 points each through
-// three radix-16 stages (4096 = 16^3); LDS is used only for the two inter-stage exchanges (padded by one
-// element per 16 so that the stride-16 writes of stage 1 are conflict free), not as the working array.
-// ================================================================================================
-#define R16_OUT(s) (4 * ((s) & 3) + ((s) >> 2))      // register holding output s of dft16()
-#define F4K_LDS 4352                                 // 4096 + 4096/16 complex per transform
-
-__device__ __forceinline__ void dft4(cplx& a, cplx& b, cplx& c, cplx& d)
-{
-    const cplx s02 = cadd(a, c), d02 = csub(a, c), s13 = cadd(b, d), d13 = csub(b, d);
-    a = cadd(s02, s13);
-    c = csub(s02, s13);
-    b = make_double2(d02.x + d13.y, d02.y - d13.x);   // d02 - i d13
-    d = make_double2(d02.x - d13.y, d02.y + d13.x);   // d02 + i d13
-}
-
-// forward 16-point DFT in registers; output s ends in u[R16_OUT(s)]
-__device__ __forceinline__ void dft16(cplx (&u)[16])
-{
-    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(u[b], u[4 + b], u[8 + b], u[12 + b]);
-    // u[4c + b] *= W16^(b c)
-    u[5] = cmul(u[5], make_double2(c1, -s1));          // W^1
-    u[6] = cmul(u[6], make_double2(h, -h));            // W^2
-    u[7] = cmul(u[7], make_double2(s1, -c1));          // W^3
-    u[9] = cmul(u[9], make_double2(h, -h));            // W^2
-    u[10] = make_double2(u[10].y, -u[10].x);           // W^4 = -i
-    u[11] = cmul(u[11], make_double2(-h, -h));         // W^6
-    u[13] = cmul(u[13], make_double2(s1, -c1));        // W^3
-    u[14] = cmul(u[14], make_double2(-h, -h));         // W^6
-    u[15] = cmul(u[15], make_double2(-c1, s1));        // W^9
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dft4(u[4 * c], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);
-}
-
-// u[r] *= tw[r q], r = 1..15, from four table entries (products of at most three factors)
-__device__ __forceinline__ void twiddle16(cplx (&u)[16], const cplx* __restrict__ tw, int q)
-{
-    const cplx w1 = tw[q], w2 = tw[2 * q], w4 = tw[4 * q], w8 = tw[8 * q];
-    const cplx w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
-    const cplx w7 = cmul(w4, w3);
-    u[1] = cmul(u[1], w1); u[2] = cmul(u[2], w2); u[3] = cmul(u[3], w3); u[4] = cmul(u[4], w4);
-    u[5] = cmul(u[5], w5); u[6] = cmul(u[6], w6); u[7] = cmul(u[7], w7); u[8] = cmul(u[8], w8);
-    u[9] = cmul(u[9], cmul(w8, w1)); u[10] = cmul(u[10], cmul(w8, w2)); u[11] = cmul(u[11], cmul(w8, w3));
-    u[12] = cmul(u[12], cmul(w8, w4)); u[13] = cmul(u[13], cmul(w8, w5)); u[14] = cmul(u[14], cmul(w8, w6));
-    u[15] = cmul(u[15], cmul(w8, w7));
-}
-
-__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
-
-// 4096-point forward FFT.  In: u[r] = x[j + 256 r].  Out: u[R16_OUT(s)] = X[j + 256 s].  j in [0, 256).
-// `lds` = this transform's F4K_LDS-element scratch.  Every thread of the block must call (barriers inside).
-__device__ __forceinline__ void fft4096_core(cplx (&u)[16], int j, cplx* lds, const cplx* __restrict__ tw)
-{
-    dft16(u);
-#pragma unroll
-    for (int sx = 0; sx < 16; ++sx) lds[17 * j + sx] = u[R16_OUT(sx)];            // pad16(16 j + s)
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) u[r] = lds[pad16(j + 256 * r)];
-    __syncthreads();
-    const int k = j & 15;
-    twiddle16(u, tw, 16 * k);
-    dft16(u);
-#pragma unroll
-    for (int sx = 0; sx < 16; ++sx) lds[pad16((j - k) * 16 + k + 16 * sx)] = u[R16_OUT(sx)];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) u[r] = lds[pad16(j + 256 * r)];
-    twiddle16(u, tw, j);
-    dft16(u);
-}
-
-// rows, real -> half complex (N1 = 4096), two image rows per transform, spatial factors fused.  Planes [first, first +
-// count) of a launch group share their source image: the workgroup reads its two rows once and produces every plane.
-struct RowGroups { int ngroups; int first[SFFT_MAX_PLANES]; int count[SFFT_MAX_PLANES]; };
-
-__global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp,
-                                                     const cplx* __restrict__ tw, double scale)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
-    const int N1 = 4096;
-    const int j = threadIdx.x;
-    const int pfirst = grp.first[blockIdx.y], pcount = grp.count[blockIdx.y];
-    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
-    const bool has1 = l1 < N0;
-    const double* __restrict__ src = a.src[pfirst];
-    const double* r0p = src + (size_t)l0 * N1;
-    const double* r1p = src + (size_t)(has1 ? l1 : l0) * N1;
-    double x0[16], x1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = j + 256 * r;
-        x0[r] = r0p[n];
-        x1[r] = has1 ? r1p[n] : 0.0;
-    }
-    const double hs = 0.5 * scale;
-    for (int pp = 0; pp < pcount; ++pp) {
-        const int plane = pfirst + pp;
-        const double* __restrict__ wx = a.wx[plane];
-        const double* __restrict__ wy = a.wy[plane];
-        const double cx0 = wx ? wx[l0] : 1.0;
-        const double cx1 = (wx && has1) ? wx[l1] : 1.0;
-        cplx u[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double cyp = wy ? wy[j + 256 * r] : 1.0;
-            u[r] = make_double2(x0[r] * (cx0 * cyp), x1[r] * (cx1 * cyp));
-        }
-        if (pp > 0) __syncthreads();            // the previous plane's partner reads are done
-        fft4096_core(u, j, lds, tw);
-        __syncthreads();
-#pragma unroll
-        for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)];
-        __syncthreads();
-        cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
-        cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
-#pragma unroll
-        for (int sx = 0; sx <= 8; ++sx) {
-            const int m = j + 256 * sx;
-            if (sx < 8 || j == 0) {
-                const cplx z = u[R16_OUT(sx)];
-                const cplx zp = lds[(N1 - m) & (N1 - 1)];
-                const cplx zc = make_double2(zp.x, -zp.y);
-                o0[m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
-                if (has1) o1[m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
-            }
-        }
-    }
-}
-
-// columns, complex -> complex in place (N0 = 4096), two adjacent columns per workgroup (512 threads).
-// Blocks that share 128-byte lines are mapped to the same XCD (block b runs on XCD b % 8) so its L2 merges them.
-__global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, int ncols, int Nhp, const cplx* __restrict__ tw,
-                                                     int inverse, double scale, int pairs_per_xcd)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
-    const int N0 = 4096;
-    const int c = threadIdx.x & 1, j = threadIdx.x >> 1;
-    const int cp = (blockIdx.x & 7) * pairs_per_xcd + (blockIdx.x >> 3);
-    const int col = 2 * cp + c;
-    const bool ok = (blockIdx.x >> 3) < pairs_per_xcd && col < ncols;
-    cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp + (ok ? col : 0);
-    cplx u[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        cplx z = ok ? base[(size_t)(j + 256 * r) * Nhp] : make_double2(0.0, 0.0);
-        if (inverse) z.y = -z.y;
-        u[r] = z;
-    }
-    fft4096_core(u, j, lds + c * (F4K_LDS + 4), tw);     // +4: the two columns' regions sit half a bank row apart
-    if (!ok) return;
-#pragma unroll
-    for (int sx = 0; sx < 16; ++sx) {
-        cplx z = u[R16_OUT(sx)];
-        if (inverse) z.y = -z.y;
-        base[(size_t)(j + 256 * sx) * Nhp] = make_double2(z.x * scale, z.y * scale);
-    }
-}
-
-// rows, half complex -> real (N1 = 4096), two rows per transform, DIFF epilogue (see rows_c2r_diff)
-template <int NQ>
-__global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict__ FD, const double* __restrict__ J,
-                                                          const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
-                                                          int N0, int Nhp, const cplx* __restrict__ tw)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
-    const int N1 = 4096;
-    const int j = threadIdx.x;
-    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
-    const bool has1 = l1 < N0;
-    const cplx* f0 = FD + (size_t)l0 * Nhp;
-    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * Nhp;
-    cplx u[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = j + 256 * r;
-        const bool mir = m > N1 / 2;
-        const int mm = mir ? N1 - m : m;
-        cplx x0 = f0[mm];
-        cplx x1 = has1 ? f1[mm] : make_double2(0.0, 0.0);
-        if (mm == 0 || mm == N1 / 2) { x0.y = 0.0; x1.y = 0.0; }
-        if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
-        u[r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
-    }
-    fft4096_core(u, j, lds, tw);
-    double c0[NQ], c1[NQ];
-    bkg_row_coeffs<NQ>(bk, bpq, l0, N0, c0);
-    bkg_row_coeffs<NQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
-    const double* j0 = J + (size_t)l0 * N1;
-    const double* j1 = J + (size_t)(has1 ? l1 : l0) * N1;
-    double* d0 = DIFF + (size_t)l0 * N1;
-    double* d1 = DIFF + (size_t)(has1 ? l1 : l0) * N1;
-#pragma unroll
-    for (int sx = 0; sx < 16; ++sx) {
-        const int n = j + 256 * sx;
-        const cplx z = u[R16_OUT(sx)];
-        d0[n] = j0[n] - bkg_eval<NQ>(bk, c0, n, N1) - z.x;
-        if (has1) d1[n] = j1[n] - bkg_eval<NQ>(bk, c1, n, N1) + z.y;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Greek stage 1: for every listed pass (A, B) and column m of the half spectrum
-//      G[r][m] = sum_l A[l][m] * conj(B[l][m]) * W0^(l r),   |r| <= h          (pruned column DFT of the
-// Hadamard product; only these lags are ever read by FillLS_*, SFFTConfigure.py:251-269, 364-371, 621-628).
-// r and -r share their four real products.  B is a stored plane (Omega, Theta) or, for Gamma, the column
-// factor Xp[l] = DFT(cx^p)[l] of the rank-1 spectrum FT_pq = SCALE * Xp (x) Yq -- the row factor Yq[m] does not
-// depend on l and is applied in stage 2, so one pass serves every q.
-// One wave per 64 columns; RS waves of a workgroup split the lags; rows are loaded U at a time ahead of use.
-// ------------------------------------------------------------------------------------------------
-struct G1Pass {
-    int a_plane;      // plane index into spec
-    int b_plane;      // plane index, or -1: B[l][m] = Xp[bp][l]
-    int bp;
-    int h;            // lag half width
-    long long gp_off; // offset (cplx) of this pass's [S][2h+1][Nhp] partial buffer
-};
-
-struct PatchJob {
-    int pass;         // G1 pass that produced G
-    int yq;           // -1, or q: G[r][m] is multiplied by conj(tscale * Yq[q][m])
-    int h;
-    int patch_off;    // offset (doubles) of this job's [(2h+1)][(2h+1)] patch
-    double scale;
-};
-
-template <int HBW, int RS>
-__global__ void __launch_bounds__(64 * RS) greek_g1(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
-                                                    cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
-                                                    int r_base, const cplx* __restrict__ W0tab, int HM, const cplx* __restrict__ Xp)
-{
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = blockIdx.x * 64 + lane;
-    const int chunk = blockIdx.y;
-    const G1Pass pr = passes[pass0 + blockIdx.z];
-    const int h = pr.h;
-    const int PH = 2 * h + 1;
-    const int lb = chunk * rows_per_chunk;
-    const int le = min(N0, lb + rows_per_chunk);
-    const bool active = m < Nh;
-    const int mc = active ? m : 0;
-    const size_t plane_sz = (size_t)N0 * Nhp;
-    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz + mc;
-    const bool colfac = pr.b_plane < 0;
-    const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz + mc;
-    const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
-    const int rfirst = r_base + 1 + wv * HBW;       // this wave's lags: rfirst .. rfirst + HBW - 1 (wave-uniform)
-    int nact = h - (rfirst - 1);
-    if (nact > HBW) nact = HBW;
-    if (nact < 0) nact = 0;
-    double S1[HBW], S2[HBW], S3[HBW], S4[HBW];
-#pragma unroll
-    for (int t = 0; t < HBW; ++t) { S1[t] = S2[t] = S3[t] = S4[t] = 0.0; }
-    double g0x = 0.0, g0y = 0.0;
-    const bool do_g0 = (r_base == 0 && wv == 0);
-    // W0tab[l][r] = W0^(l r), r = 0..HM-1: one contiguous, wave-uniform row of twiddles per image row (scalar loads)
-    const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + rfirst;
-    for (int l = lb; l < le; ++l, trow += HM) {
-        const cplx av = A[(size_t)l * Nhp];
-        const cplx bv = colfac ? xp[l] : B[(size_t)l * Nhp];
-        const cplx H = cmulc(av, bv);
-        if (do_g0) { g0x += H.x; g0y += H.y; }
-#pragma unroll
-        for (int t = 0; t < HBW; ++t) {
-            if (t < nact) {
-                const cplx w = trow[t];
-                S1[t] = fma(H.x, w.x, S1[t]);
-                S2[t] = fma(H.y, w.y, S2[t]);
-                S3[t] = fma(H.x, w.y, S3[t]);
-                S4[t] = fma(H.y, w.x, S4[t]);
-            }
-        }
-    }
-    if (!active) return;
-    cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp + m;
-    if (do_g0) g[(size_t)h * Nhp] = make_double2(g0x, g0y);
-#pragma unroll
-    for (int t = 0; t < HBW; ++t) {
-        if (t < nact) {
-            const int r = rfirst + t;
-            g[(size_t)(h + r) * Nhp] = make_double2(S1[t] - S2[t], S3[t] + S4[t]);
-            g[(size_t)(h - r) * Nhp] = make_double2(S1[t] + S2[t], S4[t] - S3[t]);
-        }
-    }
-}
-
-// W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)
-__global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= N0 * HM) return;
-    const int l = e / HM, r = e - l * HM;
-    W0tab[e] = root0[(int)(((long long)l * r) % N0)];
-}
-
-// Gamma passes with p = 0: Xp = N0 * delta[l], so G[r][m] = N0 * A[0][m] for every lag (chunk 0; other chunks zero)
-__global__ void __launch_bounds__(256) greek_g1_row0(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
-                                                     cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int S)
-{
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= Nh) return;
-    const G1Pass pr = passes[pass0 + blockIdx.y];
-    const int PH = 2 * pr.h + 1;
-    const cplx a0 = spec[(size_t)pr.a_plane * N0 * Nhp + m];
-    const cplx v = make_double2(a0.x * (double)N0, a0.y * (double)N0);
-    cplx* g = Gp + pr.gp_off + m;
-    for (int c = 0; c < S; ++c)
-        for (int r = 0; r < PH; ++r) g[((size_t)c * PH + r) * Nhp] = (c == 0) ? v : make_double2(0.0, 0.0);
-}
-
-// Greek stage 2: patch[r][e] = scale * sum_{m < Nh} wgt[m] * Re( W1^(m e) * y[m] * sum_chunks G[r][m] ),  |e| <= h.
-// wgt = 1 for the self-conjugate columns (m = 0, and m = N1/2 when N1 is even), 2 otherwise;
-// y[m] = conj(tscale * Yq[q][m]) for Gamma jobs, 1 otherwise.
-__global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, const G1Pass* __restrict__ passes,
-                                                const PatchJob* __restrict__ jobs, int job0,
-                                                double* __restrict__ patches, int Nh, int Nhp, int N1, int S,
-                                                const cplx* __restrict__ root1, const cplx* __restrict__ Yq, double tscale)
-{
-    const PatchJob jb = jobs[job0 + blockIdx.y];
-    const int h = jb.h, PH = 2 * h + 1;
-    const int r = blockIdx.x;
-    if (r >= PH) return;
-    const int tid = threadIdx.x;
-    __shared__ double red[2][4][17];
-    const cplx* g = Gp + passes[jb.pass].gp_off + (size_t)r * Nhp;
-    const cplx* yq = jb.yq >= 0 ? Yq + (size_t)jb.yq * Nhp : nullptr;
-    const bool even = (N1 & 1) == 0;
-    double* out = patches + jb.patch_off + (size_t)r * PH + h;
-    for (int e0 = 0; e0 == 0 || e0 < h; e0 += 16) {
-        double U[17], V[17];
-#pragma unroll
-        for (int t = 0; t < 17; ++t) { U[t] = 0.0; V[t] = 0.0; }
-        const int ne = min(16, h - e0);   // lags e0+1 .. e0+ne, plus lag 0 when e0 == 0
-        for (int m = tid; m < Nh; m += 256) {
-            double gx = 0.0, gy = 0.0;
-            for (int c = 0; c < S; ++c) {
-                const cplx v = g[(size_t)c * PH * Nhp + m];
-                gx += v.x; gy += v.y;
-            }
-            if (yq) {
-                const cplx y = yq[m];
-                const cplx t = cmulc(make_double2(gx, gy), make_double2(y.x * tscale, y.y * tscale));
-                gx = t.x; gy = t.y;
-            }
-            const double wgt = (m == 0 || (even && m == N1 / 2)) ? 1.0 : 2.0;
-            gx *= wgt; gy *= wgt;
-            if (e0 == 0) U[0] += gx;
-            int idx = (int)(((long long)m * e0) % N1);
-#pragma unroll
-            for (int t = 1; t <= 16; ++t) {
-                if (t <= ne) {
-                    idx += m; if (idx >= N1) idx -= N1;
-                    const cplx w = root1[idx];
-                    U[t] = fma(gx, w.x, U[t]);
-                    V[t] = fma(gy, w.y, V[t]);
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 17; ++t) {
-            double u = U[t], v = V[t];
-            for (int off = 32; off > 0; off >>= 1) { u += __shfl_down(u, off); v += __shfl_down(v, off); }
-            if ((tid & 63) == 0) { red[0][tid >> 6][t] = u; red[1][tid >> 6][t] = v; }
-        }
-        __syncthreads();
-        if (tid < 17) {
-            const double u = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
-            const double v = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
-            if (tid == 0) { if (e0 == 0) out[0] = jb.scale * u; }
-            else if (tid <= ne) {
-                out[e0 + tid] = jb.scale * (u - v);
-                out[-(e0 + tid)] = jb.scale * (u + v);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// Delta: rowmom[l][q] = sum_n J[l][n] tby[q][n], then delta[t] = SCALE * sum_l tbx[p[t]][l] rowmom[l][q[t]]
-// (= PreDEL[pq][0][0], SFFTSubtract.py:706-729, evaluated in real space: only element [0][0] is ever read).
-template <int NQ>
-__global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J, double* __restrict__ rowmom, int N0, int N1,
-                                                   const double* __restrict__ tby, int nq)
-{
-    const int l = blockIdx.x, tid = threadIdx.x;
-    double acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    for (int n = tid; n < N1; n += 256) {
-        const double v = J[(size_t)l * N1 + n];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = fma(v, tby[(size_t)min(q, nq - 1) * N1 + n], acc[q]);   // q >= nq: unused copies
-    }
-    __shared__ double red[4][NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        double u = acc[q];
-        for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
-        if ((tid & 63) == 0) red[tid >> 6][q] = u;
-    }
-    __syncthreads();
-    if (tid < NQ) rowmom[(size_t)l * SFFT_MAX_BQ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-}
-
-__global__ void __launch_bounds__(256) delta_finish(const double* __restrict__ rowmom, double* __restrict__ delta, int N0,
-                                                    BkgArgs bk, double scale)
-{
-    const int pq = blockIdx.x, tid = threadIdx.x;
-    const int pi = bk.p[pq], q = bk.q[pq];
-    double acc = 0.0;
-    for (int l = tid; l < N0; l += 256) acc = fma(bk.tbx[(size_t)pi * N0 + l], rowmom[(size_t)l * SFFT_MAX_BQ + q], acc);
-    __shared__ double red[4];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) delta[pq] = scale * (red[0] + red[1] + red[2] + red[3]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// FillLS_{OMG,GAM,PSI,PHI,THE,DEL} + Remove_LSFStripes, one thread per matrix element
-// (SFFTConfigure.py:957-1293).  PSI is filled from GAM through Psi[p'q',ij](-rho) == Gam[ij,p'q'](rho), and
-// Omega pairs with i'j' > ij from Omega[ij,i'j'](-rho); both identities are exact.
-// out is [(n+1)][ld]: rows/cols < n hold LHMAT (after the optional index map), row n and column n hold RHb.
-// ------------------------------------------------------------------------------------------------
-struct FillArgs {
-    int Fij, Fpq, Fab, Fijab, L1, w0, w1;
-    int h_omg;            // 2w
-    int h_gam;            // w
-    int omg_off;          // patches offset of Omega pair 0; pair (i'<=i) index = i'*Fij - i'(i'-1)/2 + (i - i')
-    int gam_off;          // Gam pair (ij, pq) at gam_off + (ij*Fpq+pq)*PHg*PHg
-    int the_off;          // Theta pair ij at the_off + ij*PHg*PHg
-    // tied scaling (B-spline constant photometric ratio, BSplineSFFT.py:2201-2272): the unknowns tie_first + k*tie_stride,
-    // k < tie_cnt, are one unknown; its row / column is the SUM of theirs.  tie_cnt = 0: no tie.
-    int tie_first, tie_cnt, tie_stride;
-};
-
-__device__ __forceinline__ double omg_at(const double* P, const FillArgs& f, int i8, int ij, int r0, int r1)
-{
-    const int PH = 2 * f.h_omg + 1;
-    int lo = i8, hi = ij;
-    if (i8 > ij) { lo = ij; hi = i8; r0 = -r0; r1 = -r1; }
-    const int pidx = lo * f.Fij - (lo * (lo - 1)) / 2 + (hi - lo);
-    return P[f.omg_off + (size_t)pidx * PH * PH + (size_t)(r0 + f.h_omg) * PH + (r1 + f.h_omg)];
-}
-
-__device__ double sys_element(const double* P, const double* phi, const double* delta, const FillArgs& f, int R, int C, int NEQ)
-{
-    const int PHg = 2 * f.h_gam + 1;
-    if (C == NEQ) {   // right hand side
-        if (R < f.Fijab) {
-            const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
-            const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
-            const double* T = P + f.the_off + (size_t)i8 * PHg * PHg;
-            const double t0 = T[(size_t)f.h_gam * PHg + f.h_gam];
-            if (a8 == 0 && b8 == 0) return t0;
-            return T[(size_t)(a8 + f.h_gam) * PHg + (b8 + f.h_gam)] - t0;
-        }
-        return delta[R - f.Fijab];
-    }
-    if (R < f.Fijab && C < f.Fijab) {
-        const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
-        const int ij = C / f.Fab, ab = C - ij * f.Fab;
-        const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
-        const int a = ab / f.L1 - f.w0, b = ab % f.L1 - f.w1;
-        const bool c8 = (a8 == 0 && b8 == 0), c = (a == 0 && b == 0);
-        const double o00 = omg_at(P, f, i8, ij, 0, 0);
-        if (c8 && c) return o00;
-        if (c8) return omg_at(P, f, i8, ij, -a, -b) - o00;
-        if (c) return omg_at(P, f, i8, ij, a8, b8) - o00;
-        return -omg_at(P, f, i8, ij, a8, b8) - omg_at(P, f, i8, ij, -a, -b) + omg_at(P, f, i8, ij, a8 - a, b8 - b) + o00;
-    }
-    if (R < f.Fijab) {          // GAM block
-        const int pq = C - f.Fijab;
-        const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
-        const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
-        const double* G = P + f.gam_off + (size_t)(i8 * f.Fpq + pq) * PHg * PHg;
-        const double g0 = G[(size_t)f.h_gam * PHg + f.h_gam];
-        if (a8 == 0 && b8 == 0) return g0;
-        return G[(size_t)(a8 + f.h_gam) * PHg + (b8 + f.h_gam)] - g0;
-    }
-    if (C < f.Fijab) {          // PSI block = GAM transposed
-        const int pq = R - f.Fijab;
-        const int ij = C / f.Fab, ab = C - ij * f.Fab;
-        const int a = ab / f.L1 - f.w0, b = ab % f.L1 - f.w1;
-        const double* G = P + f.gam_off + (size_t)(ij * f.Fpq + pq) * PHg * PHg;
-        const double g0 = G[(size_t)f.h_gam * PHg + f.h_gam];
-        if (a == 0 && b == 0) return g0;
-        return G[(size_t)(a + f.h_gam) * PHg + (b + f.h_gam)] - g0;
-    }
-    return phi[(R - f.Fijab) * f.Fpq + (C - f.Fijab)];
-}
-
-// element of the (possibly tied) system: sum over the members of the row group and of the column group
-__device__ double sys_group_element(const double* P, const double* phi, const double* delta, const FillArgs& f, int R, int C, int NEQ)
-{
-    const int nr = (f.tie_cnt && R == f.tie_first) ? f.tie_cnt : 1;
-    const int nc = (f.tie_cnt && C == f.tie_first) ? f.tie_cnt : 1;
-    double acc = 0.0;
-    for (int a = 0; a < nr; ++a)
-        for (int b = 0; b < nc; ++b) acc += sys_element(P, phi, delta, f, R + a * f.tie_stride, C + b * f.tie_stride, NEQ);
-    return acc;
-}
-
-__global__ void __launch_bounds__(256) fill_system(const double* __restrict__ P, const double* __restrict__ phi,
-                                                   const double* __restrict__ delta, FillArgs f, const int* __restrict__ idx,
-                                                   int n, int NEQ, double* __restrict__ out, int ld,
-                                                   double* __restrict__ rhs_vec)
-{
-    const int Cp = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int Rp = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (Rp > n || Cp > n) return;
-    if (Rp == n && Cp == n) { if (out) out[(size_t)n * ld + n] = 0.0; return; }
-    if (Rp == n) {   // rhs row (and optional separate vector)
-        const int C = idx ? idx[Cp] : Cp;
-        const double v = sys_group_element(P, phi, delta, f, C, NEQ, NEQ);
-        if (out) out[(size_t)n * ld + Cp] = v;
-        if (rhs_vec) rhs_vec[Cp] = v;
-        return;
-    }
-    if (!out) return;
-    const int R = idx ? idx[Rp] : Rp;
-    if (Cp == n) { out[(size_t)Rp * ld + n] = sys_group_element(P, phi, delta, f, R, NEQ, NEQ); return; }
-    const int C = idx ? idx[Cp] : Cp;
-    out[(size_t)Rp * ld + Cp] = sys_group_element(P, phi, delta, f, R, C, NEQ);
-}
-
-// plain LHMAT export for sfft_get_system (no border)
-__global__ void __launch_bounds__(256) fill_plain(const double* __restrict__ P, const double* __restrict__ phi,
-                                                  const double* __restrict__ delta, FillArgs f, int NEQ,
-                                                  double* __restrict__ LH, double* __restrict__ rhs)
-{
-    const int C = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int R = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (R >= NEQ || C >= NEQ) return;
-    if (LH) LH[(size_t)R * NEQ + C] = sys_element(P, phi, delta, f, R, C, NEQ);
-    if (rhs && C == 0) rhs[R] = sys_element(P, phi, delta, f, R, NEQ, NEQ);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Dense solve.  A is the bordered system [(n+1)][ld] (row n = right hand side), SPD in exact arithmetic
-// (it is a Gram matrix).  Right-looking blocked Cholesky on the lower triangle; the
-// border row rides along so that the forward substitution L y = b is a by-product (y = row n of L).
-// ------------------------------------------------------------------------------------------------
-#define CB 64
-#define BACK_SLICES 64
-// The diagonal block is read from Dsrc ([CB][CB], written by the previous step's trailing update) rather than
-// from A, because workgroup 0 overwrites A's diagonal block with the factor while the others may still start.
-__global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__ A, int ld, int nb, double* __restrict__ Dst)
-{
-    for (int e = threadIdx.x; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        Dst[i * CB + j] = A[(size_t)i * ld + j];
-    }
-}
-
-// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no IEEE division / sqrt sequences on the
-// critical path of the factorisation)
-__device__ __forceinline__ double rsqrt_nr(double d)
-{
-    double r = __builtin_amdgcn_rsq(d);
-    r = r * fma(-0.5 * d, r * r, 1.5);
-    r = r * fma(-0.5 * d, r * r, 1.5);
-    return r;
-}
-
-// One panel step.  Every workgroup factors the 64x64 diagonal block (right-looking; thread (i, cg) owns elements
-// (i, cg + 4q), q < 16, in registers; four columns per pair of barriers; fully unrolled so that all register
-// indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
-// b >= 1 then solve X L^T = A_panel for 64 rows below it (border row n included) without barriers (see below).
-__global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
-                                                  int* __restrict__ status, double* __restrict__ rd)
-{
-    __shared__ double Dl[CB][CB + 1];     // factor of the diagonal block
-    __shared__ double rdiag[CB];          // 1 / L[j][j]
-    __shared__ double Rw[CB][4];          // raw column block published in step 1
-    __shared__ double Fw[CB][4];          // final column block published in step 3
-    const int tid = threadIdx.x;
-    const int nb = min(CB, n - k);
-    const int i = tid >> 2, cg = tid & 3;
-    double a[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
-    }
-    // Four columns per step (16 steps, two barriers each).  Step jq eliminates columns 4 jq .. 4 jq + 3:
-    //   1. every thread publishes its raw element of that column block (the quad of a row holds the four of them);
-    //   2. all threads factor the 4x4 pivot block T redundantly (four reciprocal square roots in sequence);
-    //   3. thread (i, cg) forward-substitutes its row through T up to column cg -> final L[i][4 jq + cg], published;
-    //   4. rank-4 update of the columns to the right from the published finals.
-#pragma unroll
-    for (int jq = 0; jq < 16; ++jq) {
-        Rw[i][cg] = a[jq];
-        __syncthreads();
-        const int j0 = 4 * jq;
-        const double r00 = Rw[j0][0];
-        const double r10 = Rw[j0 + 1][0], r11 = Rw[j0 + 1][1];
-        const double r20 = Rw[j0 + 2][0], r21 = Rw[j0 + 2][1], r22 = Rw[j0 + 2][2];
-        const double r30 = Rw[j0 + 3][0], r31 = Rw[j0 + 3][1], r32 = Rw[j0 + 3][2], r33 = Rw[j0 + 3][3];
-        const double x0 = Rw[i][0], x1 = Rw[i][1], x2 = Rw[i][2], x3 = Rw[i][3];
-        const double rs0 = rsqrt_nr(r00);
-        const double t10 = r10 * rs0, t20 = r20 * rs0, t30 = r30 * rs0;
-        const double d1 = fma(-t10, t10, r11);
-        const double rs1 = rsqrt_nr(d1);
-        const double t21 = fma(-t20, t10, r21) * rs1, t31 = fma(-t30, t10, r31) * rs1;
-        const double d2 = fma(-t21, t21, fma(-t20, t20, r22));
-        const double rs2 = rsqrt_nr(d2);
-        const double t32 = fma(-t31, t21, fma(-t30, t20, r32)) * rs2;
-        const double d3 = fma(-t32, t32, fma(-t31, t31, fma(-t30, t30, r33)));
-        const double rs3 = rsqrt_nr(d3);
-        if (tid == 0 && blockIdx.x == 0 && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
-        const double l0 = x0 * rs0;
-        const double l1 = fma(-l0, t10, x1) * rs1;
-        const double l2 = fma(-l1, t21, fma(-l0, t20, x2)) * rs2;
-        const double l3 = fma(-l2, t32, fma(-l1, t31, fma(-l0, t30, x3))) * rs3;
-        const double lf = (cg == 0) ? l0 : (cg == 1) ? l1 : (cg == 2) ? l2 : l3;
-        a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
-        Fw[i][cg] = lf;
-        if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
-        __syncthreads();
-        if (jq < 15) {
-            const double f0 = Fw[i][0], f1 = Fw[i][1], f2 = Fw[i][2], f3 = Fw[i][3];
-#pragma unroll
-            for (int q = jq + 1; q < 16; ++q) {
-                const int c = cg + 4 * q;
-                a[q] = fma(-f3, Fw[c][3], fma(-f2, Fw[c][2], fma(-f1, Fw[c][1], fma(-f0, Fw[c][0], a[q]))));
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        Dl[i][c] = (c <= i) ? a[q] : 0.0;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int e = tid; e < nb * nb; e += 256) {
-            const int r = e / nb, c = e - r * nb;
-            if (c <= r) A[(size_t)(k + r) * ld + k + c] = Dl[r][c];
-        }
-        if (tid < nb) rd[k + tid] = rdiag[tid];
-        return;
-    }
-    const int r0 = k + nb + (blockIdx.x - 1) * CB;
-    const int nr = min(CB, n + 1 - r0);
-    if (nr <= 0) return;
-    double p[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
-    }
-    // X L^T = A_panel, row by row: x_j = (a_j - sum_{t<j} x_t L[j][t]) / L[j][j].  The four lanes of a row each hold
-    // the x_t with t = cg (mod 4); they form partial sums over their own t and combine them with two quad
-    // shuffles, so this phase needs no barrier at all (rows are independent).
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        const int jq = j >> 2, jr = j & 3;
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < jq; ++q) {
-            const double lv = Dl[j][cg + 4 * q];
-            if (q & 1) acc1 = fma(p[q], lv, acc1); else acc0 = fma(p[q], lv, acc0);
-        }
-        {   // columns 4 jq + cg < j only
-            const double lv = (cg < jr) ? Dl[j][cg + 4 * jq] : 0.0;
-            acc0 = fma(p[jq], lv, acc0);
-        }
-        double tot = acc0 + acc1;
-        tot += __shfl_xor(tot, 1);
-        tot += __shfl_xor(tot, 2);
-        const double xj = (p[jq] - tot) * rdiag[j];
-        p[jq] = (cg == jr) ? xj : p[jq];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        if (i < nr && c < nb) A[(size_t)(r0 + i) * ld + k + c] = p[q];
-    }
-}
-
-// trailing update A[i][j] -= sum_t L[i][k+t] L[j][k+t] for i >= j >= k+nb (j < n), 64x64 tiles, 4x4 per thread
-__global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int ld, int n, int k, double* __restrict__ Dnext)
-{
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti) return;
-    __shared__ double Li[CB][CB + 1];
-    __shared__ double Lj[CB][CB + 1];
-    const int tid = threadIdx.x;
-    const int nb = min(CB, n - k);
-    const int r0 = k + nb;
-    const int i0 = r0 + ti * CB, j0 = r0 + tj * CB;
-    const int ni = min(CB, n + 1 - i0), nj = min(CB, n - j0);
-    if (ni <= 0 || nj <= 0) return;
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {                 // 32 independent loads in flight per thread
-        const int e = tid + 256 * it;
-        const int i = e >> 6, t = e & 63;
-        Li[i][t] = (i < ni && t < nb) ? A[(size_t)(i0 + i) * ld + k + t] : 0.0;
-        Lj[i][t] = (i < nj && t < nb) ? A[(size_t)(j0 + i) * ld + k + t] : 0.0;
-    }
-    __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    double c[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) c[r][q] = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < CB; ++t) {                    // columns t >= nb are zero padded
-        double av[4], bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = Li[ty + 16 * r][t];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = Lj[tx + 16 * q][t];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[r][q] = fma(av[r], bv[q], c[r][q]);
-    }
-    // epilogue: all 16 loads first (independent), then the stores
-    double old[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = ty + 16 * r, j = tx + 16 * q;
-            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
-            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = ty + 16 * r, j = tx + 16 * q;
-            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);   // lower triangle only
-            if (ok) {
-                const double v = old[r][q] - c[r][q];
-                A[(size_t)(i0 + i) * ld + j0 + j] = v;
-                if (ti == 0 && tj == 0) Dnext[i * CB + j] = v;          // next step's diagonal block
-            }
-        }
-}
-
-// Back substitution L^T x = y (y = border row n of the factor), one launch per 64-row block, last block first.
-// x_b = L_bb^-T ( y_b - sum_{rows below} L[row][b]^T x[row] ).  The strip product is spread over gridDim.x
-// workgroups (64 rows each); the last one to arrive (device-scope counter) reduces the partials and solves the
-// 64x64 triangle.  xv is [n] (stripe-free ordering).
-__global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__ A, int ld, int n, int kb, double* __restrict__ xv,
-                                                      double* __restrict__ partial, unsigned int* __restrict__ counter,
-                                                      const double* __restrict__ rd)
-{
-    __shared__ double red[4][CB];
-    __shared__ double D[CB][CB + 1];
-    __shared__ int is_last;
-    const int tid = threadIdx.x;
-    const int nb = min(CB, n - kb);
-    const int c = tid & 63, rg = tid >> 6;
-    const int rows_below = n - (kb + nb);
-    const int nslice = gridDim.x;
-    if (rows_below > 0) {
-        const int per = (rows_below + nslice - 1) / nslice;
-        const int rb = kb + nb + blockIdx.x * per;
-        const int re = min(n, rb + per);
-        double acc = 0.0;
-        if (c < nb) {
-#pragma unroll 8
-            for (int row = rb + rg; row < re; row += 4) acc = fma(A[(size_t)row * ld + kb + c], xv[row], acc);
-        }
-        red[rg][c] = acc;
-        __syncthreads();
-        if (tid < CB) partial[(size_t)blockIdx.x * CB + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        __syncthreads();
-        if (tid == 0) {                                   // one lane releases for the workgroup
-            __threadfence();
-            const unsigned int prev = atomicAdd(counter, 1u);
-            is_last = (prev == (unsigned int)(nslice - 1));
-            if (is_last) __threadfence();                 // ... and acquires for the last arriver
-        }
-        __syncthreads();
-        if (!is_last) return;
-    } else if (blockIdx.x != 0) return;
-    // last arriver: y_b - strip product, then the triangle
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it;
-        const int r = e >> 6, q = e & 63;
-        D[r][q] = (r < nb && q < nb) ? A[(size_t)(kb + r) * ld + kb + q] : 0.0;
-    }
-    double ps = 0.0;
-    if (rows_below > 0 && c < nb)
-        for (int g = rg; g < nslice; g += 4) ps += __hip_atomic_load(&partial[(size_t)g * CB + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[rg][c] = ps;
-    __syncthreads();
-    if (tid < 64) {
-        double yt = 0.0, rdj = 1.0;
-        if (tid < nb) {
-            yt = A[(size_t)n * ld + kb + tid] - (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
-            rdj = rd[kb + tid];
-        }
-        for (int j = nb - 1; j >= 0; --j) {
-            const double xj = __shfl(yt, j) * __shfl(rdj, j);
-            if (tid == j) yt = xj;
-            else if (tid < j) yt = fma(-D[j][tid], xj, yt);
-        }
-        if (tid < nb) xv[kb + tid] = yt;
-        if (tid == 0) *counter = 0u;
-    }
-}
-
-// Extend_Solution / Restore_Solution scatter (SFFTConfigure.py:1299-1311; BSplineSFFT.py:2274-2338):
-// solution[idx[i]] = x[i]; removed entries stay zero, tied entries all receive the value of their representative
-__global__ void __launch_bounds__(256) scatter_solution(const double* __restrict__ xv, int n, const int* __restrict__ idx,
-                                                        double* __restrict__ solution, int NEQ, int tie_first, int tie_cnt, int tie_stride)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n) solution[idx ? idx[t] : t] = xv[t];
-    if (t >= 1 && t < tie_cnt) solution[tie_first + t * tie_stride] = xv[tie_first];   // position of tie_first in x equals its value
-}
-
-// ---- LU with partial pivoting (fallback; matches the reference's getrf/gesv semantics) --------------------
-// A is [(n+1)][ld]; rows < n, columns <= n (column n = rhs).  Unblocked right-looking elimination.
-__global__ void __launch_bounds__(1024) lu_pivot(double* __restrict__ A, int ld, int n, int k, int* __restrict__ status)
-{
-    __shared__ double bestv[16];
-    __shared__ int besti[16];
-    __shared__ int piv;
-    const int tid = threadIdx.x;
-    double bv = -1.0; int bi = k;
-    for (int i = k + tid; i < n; i += 1024) {
-        const double v = fabs(A[(size_t)i * ld + k]);
-        if (v > bv) { bv = v; bi = i; }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_down(bv, off); const int oi = __shfl_down(bi, off);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 16; ++w) if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
-        piv = bi;
-        if (!(bv > 0.0)) atomicOr(status, 2);
-    }
-    __syncthreads();
-    const int p = piv;
-    if (p != k) {
-        for (int c = tid; c <= n; c += 1024) {
-            const double t = A[(size_t)k * ld + c];
-            A[(size_t)k * ld + c] = A[(size_t)p * ld + c];
-            A[(size_t)p * ld + c] = t;
-        }
-    }
-    __syncthreads();
-    const double d = A[(size_t)k * ld + k];
-    for (int i = k + 1 + tid; i < n; i += 1024) A[(size_t)i * ld + k] /= d;
-}
-
-__global__ void __launch_bounds__(256) lu_rank1(double* __restrict__ A, int ld, int n, int k)
-{
-    const int j = k + 1 + blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ib = k + 1 + blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
-    if (j > n) return;
-    const double u = A[(size_t)k * ld + j];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = ib + r;
-        if (i < n) A[(size_t)i * ld + j] = fma(-A[(size_t)i * ld + k], u, A[(size_t)i * ld + j]);
-    }
-}
-
-__global__ void __launch_bounds__(1024) lu_backsolve(const double* __restrict__ A, int ld, int n, double* __restrict__ xv)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* yv = reinterpret_cast<double*>(smem_raw);
-    const int tid = threadIdx.x;
-    for (int c = tid; c < n; c += 1024) yv[c] = A[(size_t)c * ld + n];
-    __syncthreads();
-    for (int i = n - 1; i >= 0; --i) {
-        if (tid == 0) yv[i] = yv[i] / A[(size_t)i * ld + i];
-        __syncthreads();
-        const double xi = yv[i];
-        for (int c = tid; c < i; c += 1024) yv[c] = fma(-A[(size_t)c * ld + i], xi, yv[c]);
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 1024) xv[i] = yv[i];
-}
-
-// ------------------------------------------------------------------------------------------------
-// Subtraction: kernel transfer function tables + Construct_FDIFF (SFFTConfigure.py:737-809)
-//   Ctab[ij][a][m] = sum_b a_ijab W1^(m b);   Soff[ij] = sum_{ab != centre} a_ijab
-//   FD[l][m] = sum_ij FI_ij[l][m] * SCALE * ( sum_a W0^(l a) Ctab[ij][a][m] - Soff[ij] )
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) kernel_ctab(const double* __restrict__ sol, cplx* __restrict__ Ctab, double* __restrict__ Soff,
-                                                   int Fij, int L0, int L1, int w1, int Nh, int Nhp, int N1,
-                                                   const cplx* __restrict__ root1)
-{
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    const int ija = blockIdx.y;                   // ij*L0 + a
-    const int Fab = L0 * L1;
-    if (m == 0 && (ija % L0) == 0) {              // one thread per ij
-        const int ij = ija / L0;
-        double sacc = 0.0;
-        const int cen = (L0 / 2) * L1 + w1;
-        for (int ab = 0; ab < Fab; ++ab) if (ab != cen) sacc += sol[ij * Fab + ab];
-        Soff[ij] = sacc;
-    }
-    if (m >= Nh) return;
-    const double* arow = sol + (size_t)ija * L1;  // ij*Fab + a*L1
-    double cxr = 0.0, cyi = 0.0;
-    for (int bb = 0; bb < L1; ++bb) {
-        const int b = bb - w1;
-        long long q = ((long long)m * b) % N1; if (q < 0) q += N1;
-        const cplx w = root1[q];
-        cxr = fma(arow[bb], w.x, cxr);
-        cyi = fma(arow[bb], w.y, cyi);
-    }
-    Ctab[(size_t)ija * Nhp + m] = make_double2(cxr, cyi);
-}
-
-#define CRL 8
-__global__ void __launch_bounds__(256) construct_fd(const cplx* __restrict__ FI, cplx* __restrict__ FD, const cplx* __restrict__ Ctab,
-                                                    const double* __restrict__ Soff, const cplx* __restrict__ root0,
-                                                    int N0, int Nh, int Nhp, int Fij, int L0, int w0, double scale)
-{
-    __shared__ cplx wl[CRL][72];
-    const int tid = threadIdx.x;
-    const int m = blockIdx.x * 256 + tid;
-    const int lbase = blockIdx.y * CRL;
-    for (int e = tid; e < CRL * L0; e += 256) {
-        const int r = e / L0, aa = e - r * L0;
-        const int l = lbase + r;
-        long long q = ((long long)l * (aa - w0)) % N0; if (q < 0) q += N0;
-        wl[r][aa] = root0[q];
-    }
-    __syncthreads();
-    if (m >= Nh) return;
-    cplx acc[CRL];
-#pragma unroll
-    for (int r = 0; r < CRL; ++r) acc[r] = make_double2(0.0, 0.0);
-    const size_t plane_sz = (size_t)N0 * Nhp;
-    for (int ij = 0; ij < Fij; ++ij) {
-        cplx kk[CRL];
-#pragma unroll
-        for (int r = 0; r < CRL; ++r) kk[r] = make_double2(0.0, 0.0);
-        for (int aa = 0; aa < L0; ++aa) {
-            const cplx c = Ctab[((size_t)ij * L0 + aa) * Nhp + m];
-#pragma unroll
-            for (int r = 0; r < CRL; ++r) {
-                const cplx w = wl[r][aa];
-                kk[r].x = fma(w.x, c.x, fma(-w.y, c.y, kk[r].x));
-                kk[r].y = fma(w.x, c.y, fma(w.y, c.x, kk[r].y));
-            }
-        }
-        const double so = Soff[ij];
-#pragma unroll
-        for (int r = 0; r < CRL; ++r) {
-            const int l = lbase + r;
-            if (l < N0) {
-                const cplx fi = FI[(size_t)ij * plane_sz + (size_t)l * Nhp + m];
-                const cplx kf = make_double2(scale * (kk[r].x - so), scale * kk[r].y);
-                acc[r] = cadd(acc[r], cmul(fi, kf));
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < CRL; ++r) {
-        const int l = lbase + r;
-        if (l < N0) FD[(size_t)l * Nhp + m] = acc[r];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Small spectrum-arithmetic kernels behind the FFT utilities (noise decorrelation, FFT convolution:
-// sfft/utils/PureCupyFFTKits.py, PureCupyDeCorrelationCalculator.py)
-// ------------------------------------------------------------------------------------------------
-__global__ void copy_spectrum_scaled(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, int src_ld, int dst_ld, double f)
-{
-    const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-    if (m < Nh) { const cplx v = src[(size_t)l * src_ld + m]; dst[(size_t)l * dst_ld + m] = make_double2(v.x * f, v.y * f); }
-}
-__global__ void scale_real(double* __restrict__ a, double f, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) a[i] *= f;
-}
-// acc[i] += coeff * |a[i]|^2 * (b ? |b[i]|^2 : 1)
-__global__ void spec_abs2_acc(const cplx* __restrict__ a, const cplx* __restrict__ b, double coeff, double* __restrict__ acc, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const cplx u = a[i];
-    double v = coeff * (u.x * u.x + u.y * u.y);
-    if (b) { const cplx w = b[i]; v *= (w.x * w.x + w.y * w.y); }
-    acc[i] += v;
-}
-__global__ void real_rsqrt(const double* __restrict__ acc, double* __restrict__ out, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = 1.0 / sqrt(acc[i]);
-}
-// out[i] = a[i] * (b is complex ? b[i] : breal[i])
-__global__ void spec_mul(const cplx* __restrict__ a, const cplx* __restrict__ b, const double* __restrict__ breal, cplx* __restrict__ out, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const cplx u = a[i];
-    if (b) out[i] = cmul(u, b[i]);
-    else { const double r = breal[i]; out[i] = make_double2(u.x * r, u.y * r); }
-}
-// full[l][m] of a real, conjugate-symmetric spectrum quantity from its half [N0][Nh]: full[l][N1-m] = half[(N0-l)%N0][m]
-__global__ void half_to_full_real(const double* __restrict__ half, double* __restrict__ full, int N0, int N1, int Nh)
-{
-    const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-    if (m >= N1) return;
-    full[(size_t)l * N1 + m] = (m < Nh) ? half[(size_t)l * Nh + m] : half[(size_t)((N0 - l) % N0) * Nh + (N1 - m)];
-}
-
-// debug: copy a padded half-spectrum plane to a dense [N0][Nh] array
-__global__ void copy_spectrum(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, int Nhp)
-{
-    const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-    if (m < Nh) dst[(size_t)l * Nh + m] = src[(size_t)l * Nhp + m];
-}
+#include "device_common.hpp"
+#include "fft_generic.hpp"
+#include "fft_fourstep.hpp"
+#include "fft_r16_4096.hpp"
+#include "greek.hpp"
+#include "fill.hpp"
+#include "solver.hpp"
+#include "construct.hpp"
 
 // ================================================================================================
 // host side

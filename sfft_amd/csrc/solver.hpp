@@ -1,0 +1,356 @@
+// solver.hpp -- dense solve: blocked Cholesky with border row, back substitution, LU fallback.
+// Part of libsfft_amd (MI355X / gfx950); included by sfft_amd.hip only.
+#ifndef SFFT_AMD_SOLVER_HPP
+#define SFFT_AMD_SOLVER_HPP
+
+// ------------------------------------------------------------------------------------------------
+// Dense solve.  A is the bordered system [(n+1)][ld] (row n = right hand side), SPD in exact arithmetic
+// (it is a Gram matrix).  Right-looking blocked Cholesky on the lower triangle; the
+// border row rides along so that the forward substitution L y = b is a by-product (y = row n of L).
+// ------------------------------------------------------------------------------------------------
+#define CB 64
+#define BACK_SLICES 64
+// The diagonal block is read from Dsrc ([CB][CB], written by the previous step's trailing update) rather than
+// from A, because workgroup 0 overwrites A's diagonal block with the factor while the others may still start.
+__global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__ A, int ld, int nb, double* __restrict__ Dst)
+{
+    for (int e = threadIdx.x; e < nb * nb; e += 256) {
+        const int i = e / nb, j = e - i * nb;
+        Dst[i * CB + j] = A[(size_t)i * ld + j];
+    }
+}
+
+// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no IEEE division / sqrt sequences on the
+// critical path of the factorisation)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * fma(-0.5 * d, r * r, 1.5);
+    r = r * fma(-0.5 * d, r * r, 1.5);
+    return r;
+}
+
+// One panel step.  Every workgroup factors the 64x64 diagonal block (right-looking; thread (i, cg) owns elements
+// (i, cg + 4q), q < 16, in registers; four columns per pair of barriers; fully unrolled so that all register
+// indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
+// b >= 1 then solve X L^T = A_panel for 64 rows below it (border row n included) without barriers (see below).
+__global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
+                                                  int* __restrict__ status, double* __restrict__ rd)
+{
+    __shared__ double Dl[CB][CB + 1];     // factor of the diagonal block
+    __shared__ double rdiag[CB];          // 1 / L[j][j]
+    __shared__ double Rw[CB][4];          // raw column block published in step 1
+    __shared__ double Fw[CB][4];          // final column block published in step 3
+    const int tid = threadIdx.x;
+    const int nb = min(CB, n - k);
+    const int i = tid >> 2, cg = tid & 3;
+    double a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
+    }
+    // Four columns per step (16 steps, two barriers each).  Step jq eliminates columns 4 jq .. 4 jq + 3:
+    //   1. every thread publishes its raw element of that column block (the quad of a row holds the four of them);
+    //   2. all threads factor the 4x4 pivot block T redundantly (four reciprocal square roots in sequence);
+    //   3. thread (i, cg) forward-substitutes its row through T up to column cg -> final L[i][4 jq + cg], published;
+    //   4. rank-4 update of the columns to the right from the published finals.
+#pragma unroll
+    for (int jq = 0; jq < 16; ++jq) {
+        Rw[i][cg] = a[jq];
+        __syncthreads();
+        const int j0 = 4 * jq;
+        const double r00 = Rw[j0][0];
+        const double r10 = Rw[j0 + 1][0], r11 = Rw[j0 + 1][1];
+        const double r20 = Rw[j0 + 2][0], r21 = Rw[j0 + 2][1], r22 = Rw[j0 + 2][2];
+        const double r30 = Rw[j0 + 3][0], r31 = Rw[j0 + 3][1], r32 = Rw[j0 + 3][2], r33 = Rw[j0 + 3][3];
+        const double x0 = Rw[i][0], x1 = Rw[i][1], x2 = Rw[i][2], x3 = Rw[i][3];
+        const double rs0 = rsqrt_nr(r00);
+        const double t10 = r10 * rs0, t20 = r20 * rs0, t30 = r30 * rs0;
+        const double d1 = fma(-t10, t10, r11);
+        const double rs1 = rsqrt_nr(d1);
+        const double t21 = fma(-t20, t10, r21) * rs1, t31 = fma(-t30, t10, r31) * rs1;
+        const double d2 = fma(-t21, t21, fma(-t20, t20, r22));
+        const double rs2 = rsqrt_nr(d2);
+        const double t32 = fma(-t31, t21, fma(-t30, t20, r32)) * rs2;
+        const double d3 = fma(-t32, t32, fma(-t31, t31, fma(-t30, t30, r33)));
+        const double rs3 = rsqrt_nr(d3);
+        if (tid == 0 && blockIdx.x == 0 && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
+        const double l0 = x0 * rs0;
+        const double l1 = fma(-l0, t10, x1) * rs1;
+        const double l2 = fma(-l1, t21, fma(-l0, t20, x2)) * rs2;
+        const double l3 = fma(-l2, t32, fma(-l1, t31, fma(-l0, t30, x3))) * rs3;
+        const double lf = (cg == 0) ? l0 : (cg == 1) ? l1 : (cg == 2) ? l2 : l3;
+        a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
+        Fw[i][cg] = lf;
+        if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
+        __syncthreads();
+        if (jq < 15) {
+            const double f0 = Fw[i][0], f1 = Fw[i][1], f2 = Fw[i][2], f3 = Fw[i][3];
+#pragma unroll
+            for (int q = jq + 1; q < 16; ++q) {
+                const int c = cg + 4 * q;
+                a[q] = fma(-f3, Fw[c][3], fma(-f2, Fw[c][2], fma(-f1, Fw[c][1], fma(-f0, Fw[c][0], a[q]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        Dl[i][c] = (c <= i) ? a[q] : 0.0;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e / nb, c = e - r * nb;
+            if (c <= r) A[(size_t)(k + r) * ld + k + c] = Dl[r][c];
+        }
+        if (tid < nb) rd[k + tid] = rdiag[tid];
+        return;
+    }
+    const int r0 = k + nb + (blockIdx.x - 1) * CB;
+    const int nr = min(CB, n + 1 - r0);
+    if (nr <= 0) return;
+    double p[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
+    }
+    // X L^T = A_panel, row by row: x_j = (a_j - sum_{t<j} x_t L[j][t]) / L[j][j].  The four lanes of a row each hold
+    // the x_t with t = cg (mod 4); they form partial sums over their own t and combine them with two quad
+    // shuffles, so this phase needs no barrier at all (rows are independent).
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int jq = j >> 2, jr = j & 3;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < jq; ++q) {
+            const double lv = Dl[j][cg + 4 * q];
+            if (q & 1) acc1 = fma(p[q], lv, acc1); else acc0 = fma(p[q], lv, acc0);
+        }
+        {   // columns 4 jq + cg < j only
+            const double lv = (cg < jr) ? Dl[j][cg + 4 * jq] : 0.0;
+            acc0 = fma(p[jq], lv, acc0);
+        }
+        double tot = acc0 + acc1;
+        tot += __shfl_xor(tot, 1);
+        tot += __shfl_xor(tot, 2);
+        const double xj = (p[jq] - tot) * rdiag[j];
+        p[jq] = (cg == jr) ? xj : p[jq];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        if (i < nr && c < nb) A[(size_t)(r0 + i) * ld + k + c] = p[q];
+    }
+}
+
+// trailing update A[i][j] -= sum_t L[i][k+t] L[j][k+t] for i >= j >= k+nb (j < n), 64x64 tiles, 4x4 per thread
+__global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int ld, int n, int k, double* __restrict__ Dnext)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    __shared__ double Li[CB][CB + 1];
+    __shared__ double Lj[CB][CB + 1];
+    const int tid = threadIdx.x;
+    const int nb = min(CB, n - k);
+    const int r0 = k + nb;
+    const int i0 = r0 + ti * CB, j0 = r0 + tj * CB;
+    const int ni = min(CB, n + 1 - i0), nj = min(CB, n - j0);
+    if (ni <= 0 || nj <= 0) return;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {                 // 32 independent loads in flight per thread
+        const int e = tid + 256 * it;
+        const int i = e >> 6, t = e & 63;
+        Li[i][t] = (i < ni && t < nb) ? A[(size_t)(i0 + i) * ld + k + t] : 0.0;
+        Lj[i][t] = (i < nj && t < nb) ? A[(size_t)(j0 + i) * ld + k + t] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    double c[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[r][q] = 0.0;
+#pragma unroll 8
+    for (int t = 0; t < CB; ++t) {                    // columns t >= nb are zero padded
+        double av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = Li[ty + 16 * r][t];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = Lj[tx + 16 * q][t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[r][q] = fma(av[r], bv[q], c[r][q]);
+    }
+    // epilogue: all 16 loads first (independent), then the stores
+    double old[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * r, j = tx + 16 * q;
+            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
+            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * r, j = tx + 16 * q;
+            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);   // lower triangle only
+            if (ok) {
+                const double v = old[r][q] - c[r][q];
+                A[(size_t)(i0 + i) * ld + j0 + j] = v;
+                if (ti == 0 && tj == 0) Dnext[i * CB + j] = v;          // next step's diagonal block
+            }
+        }
+}
+
+// Back substitution L^T x = y (y = border row n of the factor), one launch per 64-row block, last block first.
+// x_b = L_bb^-T ( y_b - sum_{rows below} L[row][b]^T x[row] ).  The strip product is spread over gridDim.x
+// workgroups (64 rows each); the last one to arrive (device-scope counter) reduces the partials and solves the
+// 64x64 triangle.  xv is [n] (stripe-free ordering).
+__global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__ A, int ld, int n, int kb, double* __restrict__ xv,
+                                                      double* __restrict__ partial, unsigned int* __restrict__ counter,
+                                                      const double* __restrict__ rd)
+{
+    __shared__ double red[4][CB];
+    __shared__ double D[CB][CB + 1];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int nb = min(CB, n - kb);
+    const int c = tid & 63, rg = tid >> 6;
+    const int rows_below = n - (kb + nb);
+    const int nslice = gridDim.x;
+    if (rows_below > 0) {
+        const int per = (rows_below + nslice - 1) / nslice;
+        const int rb = kb + nb + blockIdx.x * per;
+        const int re = min(n, rb + per);
+        double acc = 0.0;
+        if (c < nb) {
+#pragma unroll 8
+            for (int row = rb + rg; row < re; row += 4) acc = fma(A[(size_t)row * ld + kb + c], xv[row], acc);
+        }
+        red[rg][c] = acc;
+        __syncthreads();
+        if (tid < CB) partial[(size_t)blockIdx.x * CB + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        __syncthreads();
+        if (tid == 0) {                                   // one lane releases for the workgroup
+            __threadfence();
+            const unsigned int prev = atomicAdd(counter, 1u);
+            is_last = (prev == (unsigned int)(nslice - 1));
+            if (is_last) __threadfence();                 // ... and acquires for the last arriver
+        }
+        __syncthreads();
+        if (!is_last) return;
+    } else if (blockIdx.x != 0) return;
+    // last arriver: y_b - strip product, then the triangle
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it;
+        const int r = e >> 6, q = e & 63;
+        D[r][q] = (r < nb && q < nb) ? A[(size_t)(kb + r) * ld + kb + q] : 0.0;
+    }
+    double ps = 0.0;
+    if (rows_below > 0 && c < nb)
+        for (int g = rg; g < nslice; g += 4) ps += __hip_atomic_load(&partial[(size_t)g * CB + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[rg][c] = ps;
+    __syncthreads();
+    if (tid < 64) {
+        double yt = 0.0, rdj = 1.0;
+        if (tid < nb) {
+            yt = A[(size_t)n * ld + kb + tid] - (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+            rdj = rd[kb + tid];
+        }
+        for (int j = nb - 1; j >= 0; --j) {
+            const double xj = __shfl(yt, j) * __shfl(rdj, j);
+            if (tid == j) yt = xj;
+            else if (tid < j) yt = fma(-D[j][tid], xj, yt);
+        }
+        if (tid < nb) xv[kb + tid] = yt;
+        if (tid == 0) *counter = 0u;
+    }
+}
+
+// Extend_Solution / Restore_Solution scatter (SFFTConfigure.py:1299-1311; BSplineSFFT.py:2274-2338):
+// solution[idx[i]] = x[i]; removed entries stay zero, tied entries all receive the value of their representative
+__global__ void __launch_bounds__(256) scatter_solution(const double* __restrict__ xv, int n, const int* __restrict__ idx,
+                                                        double* __restrict__ solution, int NEQ, int tie_first, int tie_cnt, int tie_stride)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) solution[idx ? idx[t] : t] = xv[t];
+    if (t >= 1 && t < tie_cnt) solution[tie_first + t * tie_stride] = xv[tie_first];   // position of tie_first in x equals its value
+}
+
+// ---- LU with partial pivoting (fallback; matches the reference's getrf/gesv semantics) --------------------
+// A is [(n+1)][ld]; rows < n, columns <= n (column n = rhs).  Unblocked right-looking elimination.
+__global__ void __launch_bounds__(1024) lu_pivot(double* __restrict__ A, int ld, int n, int k, int* __restrict__ status)
+{
+    __shared__ double bestv[16];
+    __shared__ int besti[16];
+    __shared__ int piv;
+    const int tid = threadIdx.x;
+    double bv = -1.0; int bi = k;
+    for (int i = k + tid; i < n; i += 1024) {
+        const double v = fabs(A[(size_t)i * ld + k]);
+        if (v > bv) { bv = v; bi = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(bv, off); const int oi = __shfl_down(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
+        piv = bi;
+        if (!(bv > 0.0)) atomicOr(status, 2);
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k) {
+        for (int c = tid; c <= n; c += 1024) {
+            const double t = A[(size_t)k * ld + c];
+            A[(size_t)k * ld + c] = A[(size_t)p * ld + c];
+            A[(size_t)p * ld + c] = t;
+        }
+    }
+    __syncthreads();
+    const double d = A[(size_t)k * ld + k];
+    for (int i = k + 1 + tid; i < n; i += 1024) A[(size_t)i * ld + k] /= d;
+}
+
+__global__ void __launch_bounds__(256) lu_rank1(double* __restrict__ A, int ld, int n, int k)
+{
+    const int j = k + 1 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ib = k + 1 + blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (j > n) return;
+    const double u = A[(size_t)k * ld + j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ib + r;
+        if (i < n) A[(size_t)i * ld + j] = fma(-A[(size_t)i * ld + k], u, A[(size_t)i * ld + j]);
+    }
+}
+
+__global__ void __launch_bounds__(1024) lu_backsolve(const double* __restrict__ A, int ld, int n, double* __restrict__ xv)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* yv = reinterpret_cast<double*>(smem_raw);
+    const int tid = threadIdx.x;
+    for (int c = tid; c < n; c += 1024) yv[c] = A[(size_t)c * ld + n];
+    __syncthreads();
+    for (int i = n - 1; i >= 0; --i) {
+        if (tid == 0) yv[i] = yv[i] / A[(size_t)i * ld + i];
+        __syncthreads();
+        const double xi = yv[i];
+        for (int c = tid; c < i; c += 1024) yv[c] = fma(-A[(size_t)c * ld + i], xi, yv[c]);
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) xv[i] = yv[i];
+}
+
+#endif
