@@ -1,0 +1,335 @@
+"""CPU oracle for the parts of sfft/BSplineSFFT.py that have NO CPU implementation in the reference:
+SCALING_MODE 'SEPARATE-VARYING' and REGULARIZE_KERNEL -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+numpy restatement, by reading, of the CuPy-only code
+
+    sfft/BSplineSFFT.py:173-201, 226-228    ScaFij / NEQt
+    sfft/BSplineSFFT.py:334-397             ScaSpatial (scaling planes, zero place-holders for ScaREF_ij == (-1, -1))
+    sfft/BSplineSFFT.py:1348-2005           HadProd_OMG{11,01,10,00}, GAM{1,0}, PSI{1,0}, THE{1,0} and their FillLS rules
+    sfft/BSplineSFFT.py:2007-2168, 3570-3700   Laplacian regularisation matrix (all scaling modes)
+    sfft/BSplineSFFT.py:2293-2342, 3732-3785   TweakLS / Restore_Solution for NEQt < NEQ
+    sfft/BSplineSFFT.py:2429-2527           Construct_FDIFF with the separate scaling planes
+
+PARITY UNPINNED: the reference cannot run this code here (CuPy only, no CPU backend, no golden vectors), so nothing
+produced by the reference pins this file.  What does pin it (tests/test_oracle_sv.py):
+  * the linear system equals the normal equations of the stated model, built by brute force in real space;
+  * with the scaling basis equal to the kernel basis it reduces to the ENTANGLED system of oracle/bspline_oracle.py,
+    which IS pinned by reference-generated goldens;
+  * LAMBDA_REGULARIZE = 0 reproduces the unregularised solution; the regularisation matrix is symmetric PSD and
+    annihilates spatially constant, flat kernels as a discrete Laplacian must.
+
+Only tests/ and __graft_entry__.smoke() may import this module.
+"""
+import numpy as np
+from scipy import signal
+from scipy.interpolate import BSpline
+
+from .sfft_oracle import _fft2, _ifft2
+from .bspline_oracle import create_bspline_basis
+
+
+def create_bspline_basis_req(N, IntKnot, BSplineDegree, ReqCoord):
+    """BSplineSFFT.py:2636-2646: the basis functions at requested scaled coordinates."""
+    Knot = np.concatenate(([0.5] * (BSplineDegree + 1), list(IntKnot), [N + 0.5] * (BSplineDegree + 1))) / N
+    Nc = len(IntKnot) + BSplineDegree + 1
+    out = []
+    for idx in range(Nc):
+        Coeff = (np.arange(Nc) == idx).astype(float)
+        out.append(BSpline(t=Knot, c=Coeff, k=BSplineDegree, extrapolate=False)(ReqCoord))
+    return np.array(out)
+
+
+def make_scaling_basis(N0, N1, Fij, ScaSpType='Polynomial', ScaSpDegree=1, ScaIntKnotX=(), ScaIntKnotY=()):
+    """1-D factors of the scaling terms and ScaREF_ij padded with (-1, -1) to Fij entries (BSplineSFFT.py:2779-2793)."""
+    DS = int(ScaSpDegree)
+    if ScaSpType == 'Polynomial':
+        cx = (np.arange(N0, dtype=np.float64) + 1.0) / N0
+        cy = (np.arange(N1, dtype=np.float64) + 1.0) / N1
+        sbx = np.stack([np.power(cx, i) for i in range(DS + 1)])
+        sby = np.stack([np.power(cy, j) for j in range(DS + 1)])
+        pairs = [(i, j) for i in range(DS + 1) for j in range(DS + 1 - i)]
+    else:
+        sbx = create_bspline_basis(N0, list(ScaIntKnotX), DS)
+        sby = create_bspline_basis(N1, list(ScaIntKnotY), DS)
+        pairs = [(i, j) for i in range(sbx.shape[0]) for j in range(sby.shape[0])]
+    ScaFij = len(pairs)
+    assert ScaFij <= Fij                                                   # BSplineSFFT.py:190
+    pairs = pairs + [(-1, -1)] * (Fij - ScaFij)
+    return dict(sbx=sbx, sby=sby, sca_pairs=np.array(pairs, dtype=np.int32), ScaFij=ScaFij,
+                ScaSpType=ScaSpType, DS=DS, ScaIntKnotX=list(ScaIntKnotX), ScaIntKnotY=list(ScaIntKnotY))
+
+
+def SSC(NX, NY, KerHW, basis, sca=None, SCALING_MODE='SEPARATE-VARYING'):
+    """Parameter dictionary (BSplineSFFT.py:150-245).  `basis` from bspline_oracle.make_basis, `sca` from
+    make_scaling_basis (SEPARATE-VARYING only)."""
+    assert SCALING_MODE in ('ENTANGLED', 'SEPARATE-CONSTANT', 'SEPARATE-VARYING')
+    N0, N1, w = int(NX), int(NY), int(KerHW)
+    L = 2 * w + 1
+    Fab = L * L
+    Fij, Fpq = len(basis['ker_pairs']), len(basis['bkg_pairs'])
+    NEQ = Fij * Fab + Fpq
+    NEQt = NEQ
+    ScaFij = None
+    if SCALING_MODE == 'SEPARATE-CONSTANT':
+        NEQt = NEQ - Fij + 1
+    if SCALING_MODE == 'SEPARATE-VARYING':
+        ScaFij = sca['ScaFij']
+        NEQt = NEQ - (Fij - ScaFij)
+    return dict(N0=N0, N1=N1, w0=w, w1=w, L0=L, L1=L, Fab=Fab, Fij=Fij, Fpq=Fpq, Fijab=Fij * Fab, NEQ=NEQ, NEQt=NEQt,
+                ScaFij=ScaFij, SCALE=np.float64(1 / (N0 * N1)), SCALE_L=np.float64(N0 * N1), SCALING_MODE=SCALING_MODE,
+                KerSpType=basis['KerSpType'])
+
+
+def _kernel_planes(PixA_I, basis):
+    return np.stack([PixA_I * (basis['kbx'][i][:, None] * basis['kby'][j][None, :]) for i, j in basis['ker_pairs']])
+
+
+def _scaling_planes(PixA_I, sca):
+    """ScaSPixA_Iij (BSplineSFFT.py:334-397): zero planes for the place-holder terms."""
+    out = []
+    for i, j in sca['sca_pairs']:
+        if i < 0 or j < 0:
+            out.append(np.zeros_like(PixA_I))
+        else:
+            out.append(PixA_I * (sca['sbx'][i][:, None] * sca['sby'][j][None, :]))
+    return np.stack(out)
+
+
+def _bkg_planes(basis):
+    return np.stack([basis['tbx'][p][:, None] * basis['tby'][q][None, :] for p, q in basis['bkg_pairs']])
+
+
+def establish_system(PixA_I, PixA_J, p, basis, sca, workers=1):
+    """LHMAT[NEQ, NEQ], RHb[NEQ] of SEPARATE-VARYING scaling before regularisation and TweakLS
+    (BSplineSFFT.py:3293-3565 with the fill rules of :1480-1560, 1660-1700, 1775-1785, 1905-1950)."""
+    assert p['SCALING_MODE'] == 'SEPARATE-VARYING'
+    N0, N1 = p['N0'], p['N1']
+    Fij, Fpq, Fab, Fijab, NEQ = p['Fij'], p['Fpq'], p['Fab'], p['Fijab'], p['NEQ']
+    SCALE, SCALE_L = p['SCALE'], p['SCALE_L']
+    w0, w1, L0, L1 = p['w0'], p['w1'], p['L0'], p['L1']
+    f2 = lambda X: SCALE * _fft2(np.asarray(X, dtype=np.complex128), workers)
+    FJ = f2(PixA_J)
+    FI = np.stack([f2(X) for X in _kernel_planes(PixA_I, basis)])
+    FS = np.stack([f2(X) for X in _scaling_planes(PixA_I, sca)])
+    FT = np.stack([f2(X) for X in _bkg_planes(basis)])
+    CFJ, CFI, CFS, CFT = np.conj(FJ), np.conj(FI), np.conj(FS), np.conj(FT)
+    ab = np.array([(a - w0, b - w1) for a in range(L0) for b in range(L1)])
+    a_, b_ = ab[:, 0], ab[:, 1]
+    cen = (a_ == 0) & (b_ == 0)
+    MODa, MODb = np.mod(a_, N0), np.mod(b_, N1)
+    MOD_a, MOD_b = np.mod(-a_, N0), np.mod(-b_, N1)
+    MODda, MODdb = np.mod(a_[:, None] - a_[None, :], N0), np.mod(b_[:, None] - b_[None, :], N1)
+    pre = lambda H: f2(H).real
+    LHMAT = np.empty((NEQ, NEQ))
+    RHb = np.empty(NEQ)
+    for i8 in range(Fij):
+        for ij in range(Fij):
+            P11 = pre(FI[i8] * CFI[ij]) * SCALE
+            P01 = pre(FS[i8] * CFI[ij]) * SCALE
+            P10 = pre(FI[i8] * CFS[ij]) * SCALE
+            P00 = pre(FS[i8] * CFS[ij]) * SCALE
+            blk = -P11[MODa, MODb][:, None] - P11[MOD_a, MOD_b][None, :] + P11[MODda, MODdb] + P11[0, 0]
+            blk[cen, :] = (P01[MOD_a, MOD_b] - P01[0, 0])[None, :]
+            blk[:, cen] = (P10[MODa, MODb] - P10[0, 0])[:, None]
+            blk[np.ix_(cen, cen)] = P00[0, 0]
+            LHMAT[i8 * Fab:(i8 + 1) * Fab, ij * Fab:(ij + 1) * Fab] = blk
+        for pq in range(Fpq):
+            G1, G0 = pre(FI[i8] * CFT[pq]), pre(FS[i8] * CFT[pq])
+            col = G1[MODa, MODb] - G1[0, 0]
+            col[cen] = G0[0, 0]
+            LHMAT[i8 * Fab:(i8 + 1) * Fab, Fijab + pq] = col
+        T1, T0 = pre(CFJ * FI[i8]), pre(CFJ * FS[i8])
+        v = T1[MODa, MODb] - T1[0, 0]
+        v[cen] = T0[0, 0]
+        RHb[i8 * Fab:(i8 + 1) * Fab] = v
+    for p8 in range(Fpq):
+        for ij in range(Fij):
+            S1, S0 = pre(FT[p8] * CFI[ij]), pre(FT[p8] * CFS[ij])
+            row = S1[MOD_a, MOD_b] - S1[0, 0]
+            row[cen] = S0[0, 0]
+            LHMAT[Fijab + p8, ij * Fab:(ij + 1) * Fab] = row
+        for pq in range(Fpq):
+            LHMAT[Fijab + p8, Fijab + pq] = (pre(FT[p8] * CFT[pq]) * SCALE_L)[0, 0]
+        RHb[Fijab + p8] = (pre(CFJ * FT[p8]) * SCALE_L)[0, 0]
+    return LHMAT, RHb
+
+
+def laplacian_ireg(w0, w1, IGNORE_LAPLACIAN_KERCENT=True):
+    """iREGMAT[Fab, Fab] (integers) of the modified-delta basis from the 5-point Laplacian of the kernel stamp
+    (BSplineSFFT.py:3640-3686 with the kernels of :2009-2087)."""
+    L0, L1 = 2 * w0 + 1, 2 * w1 + 1
+    Fab = L0 * L1
+    LAPMAT = np.zeros((Fab, Fab), dtype=np.int64)
+    RR, CC = np.mgrid[0:L0, 0:L1]
+    RRF, CCF = RR.flatten(), CC.flatten()
+    AdCOUNT = signal.correlate2d(np.ones((L0, L1)), np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]]), mode='same',
+                                 boundary='fill', fillvalue=0).astype(np.int64)
+    LAPMAT[np.arange(Fab), np.arange(Fab)] = AdCOUNT.flatten()
+    for r in range(Fab):
+        for c in range(Fab):
+            if r != c and abs(RRF[r] - RRF[c]) + abs(CCF[r] - CCF[c]) == 1:
+                LAPMAT[r, c] = -1
+    if IGNORE_LAPLACIAN_KERCENT and w0 >= 1 and w1 >= 1:
+        for r in ((w0 - 1) * L1 + w1, w0 * L1 + w1 - 1, w0 * L1 + w1, w0 * L1 + w1 + 1, (w0 + 1) * L1 + w1):
+            LAPMAT[r, :] = 0
+    LTL = LAPMAT.T @ LAPMAT
+    c0 = w0 * L1 + w1
+    iREG = np.zeros((Fab, Fab), dtype=np.int64)
+    for r in range(Fab):
+        for c in range(Fab):
+            if r != c0 and c != c0:
+                iREG[r, c] = LTL[r, c] + LTL[c, r] - LTL[c0, r] - LTL[c0, c] - LTL[r, c0] - LTL[c, c0] + 2 * LTL[c0, c0]
+            elif r != c0 and c == c0:
+                iREG[r, c] = LTL[r, c0] + LTL[c0, r] - 2 * LTL[c0, c0]
+            elif r == c0 and c != c0:
+                iREG[r, c] = LTL[c, c0] + LTL[c0, c] - 2 * LTL[c0, c0]
+            else:
+                iREG[r, c] = 2 * LTL[c0, c0]
+    return iREG
+
+
+def spatial_gram(p, kerspec, sca, XY_REGULARIZE, WEIGHT_REGULARIZE=None):
+    """SSTMAT (and CSSTMAT, DSSTMAT for SEPARATE-VARYING) of BSplineSFFT.py:3572-3638.
+    kerspec = dict(KerSpType, DK, KerIntKnotX, KerIntKnotY)."""
+    N0, N1, Fij = p['N0'], p['N1'], p['Fij']
+    XY = np.asarray(XY_REGULARIZE, dtype=np.float64)
+    NREG = XY.shape[0]
+    CX, CY = XY[:, 0] / N0, XY[:, 1] / N1
+    DK = kerspec['DK']
+    if kerspec['KerSpType'] == 'Polynomial':
+        SP = np.array([CX ** i * CY ** j for i in range(DK + 1) for j in range(DK + 1 - i)])
+    else:
+        BX = create_bspline_basis_req(N0, kerspec['KerIntKnotX'], DK, CX)
+        BY = create_bspline_basis_req(N1, kerspec['KerIntKnotY'], DK, CY)
+        SP = np.array([BX[i] * BY[j] for i in range(BX.shape[0]) for j in range(BY.shape[0])])
+    ScaSP = None
+    if p['SCALING_MODE'] == 'SEPARATE-VARYING':
+        DS = sca['DS']
+        if sca['ScaSpType'] == 'Polynomial':
+            ScaSP = np.array([CX ** i * CY ** j for i in range(DS + 1) for j in range(DS + 1 - i)])
+        else:
+            BX = create_bspline_basis_req(N0, sca['ScaIntKnotX'], DS, CX)
+            BY = create_bspline_basis_req(N1, sca['ScaIntKnotY'], DS, CY)
+            ScaSP = np.array([BX[i] * BY[j] for i in range(BX.shape[0]) for j in range(BY.shape[0])])
+        if ScaSP.shape[0] < Fij:
+            ScaSP = np.concatenate((ScaSP, np.zeros((Fij - ScaSP.shape[0], NREG))), axis=0)
+    if WEIGHT_REGULARIZE is None:
+        W = np.eye(NREG) / NREG
+    else:
+        W = np.diag(np.asarray(WEIGHT_REGULARIZE, dtype=np.float64))
+        W = W / np.sum(WEIGHT_REGULARIZE)
+    SST = SP @ W @ SP.T
+    CSST = SP @ W @ ScaSP.T if ScaSP is not None else None
+    DSST = ScaSP @ W @ ScaSP.T if ScaSP is not None else None
+    return SST, CSST, DSST
+
+
+def regularization_matrix(p, iREG, SST, CSST=None, DSST=None):
+    """REGMAT[NEQ, NEQ] (BSplineSFFT.py:2090-2166): Kronecker-like product of the spatial Gram matrices with iREGMAT."""
+    Fij, Fab, Fijab, NEQ, SCALE = p['Fij'], p['Fab'], p['Fijab'], p['NEQ'], p['SCALE']
+    c0 = p['w0'] * p['L1'] + p['w1']
+    REG = np.zeros((NEQ, NEQ))
+    ir = iREG.astype(np.float64)
+    if p['SCALING_MODE'] != 'SEPARATE-VARYING':
+        REG[:Fijab, :Fijab] = SCALE ** 2 * np.kron(SST, ir)
+        return REG
+    for k in range(Fij):
+        for k8 in range(Fij):
+            blk = SCALE ** 2 * SST[k, k8] * ir
+            blk[:, c0] = SCALE ** 2 * CSST[k, k8] * ir[:, c0]
+            blk[c0, :] = SCALE ** 2 * CSST[k8, k] * ir[c0, :]
+            blk[c0, c0] = SCALE ** 2 * DSST[k, k8] * ir[c0, c0]
+            REG[k * Fab:(k + 1) * Fab, k8 * Fab:(k8 + 1) * Fab] = blk
+    return REG
+
+
+def solve_system(LHMAT, RHb, p):
+    """TweakLS + gesv + Restore_Solution (BSplineSFFT.py:3702-3785)."""
+    NEQ, Fijab, Fab, Fij = p['NEQ'], p['Fijab'], p['Fab'], p['Fij']
+    mode = p['SCALING_MODE']
+    ij00 = np.arange(p['w0'] * p['L1'] + p['w1'], Fijab, Fab)
+    if mode == 'ENTANGLED' or (mode == 'SEPARATE-VARYING' and p['NEQt'] == NEQ):
+        return np.linalg.solve(LHMAT, RHb)
+    if mode == 'SEPARATE-VARYING':
+        PresIDX = np.setdiff1d(np.arange(NEQ), ij00[p['ScaFij']:], assume_unique=True)
+        Solution = np.zeros(NEQ)
+        Solution[PresIDX] = np.linalg.solve(LHMAT[np.ix_(PresIDX, PresIDX)], RHb[PresIDX])
+        return Solution
+    PresIDX = np.setdiff1d(np.arange(NEQ), ij00[1:], assume_unique=True)
+    if p['KerSpType'] == 'Polynomial':
+        Solution = np.zeros(NEQ)
+        Solution[PresIDX] = np.linalg.solve(LHMAT[np.ix_(PresIDX, PresIDX)], RHb[PresIDX])
+        return Solution
+    P = np.zeros((NEQ, len(PresIDX)))
+    P[PresIDX, np.arange(len(PresIDX))] = 1.0
+    key = int(np.where(PresIDX == ij00[0])[0][0])
+    P[ij00[1:], key] = 1.0
+    return P @ np.linalg.solve(P.T @ LHMAT @ P, P.T @ RHb)
+
+
+def subtract(PixA_I, PixA_J, Solution, p, basis, sca, workers=1):
+    """Construct_FDIFF of SEPARATE-VARYING scaling (BSplineSFFT.py:2429-2527) + inverse DFT (:3846-3847): the centre
+    coefficient a_ij00 multiplies the SCALING plane, the others the kernel plane."""
+    N0, N1, w0, w1, L0, L1 = p['N0'], p['N1'], p['w0'], p['w1'], p['L0'], p['L1']
+    Fij, Fpq, Fab, Fijab, SCALE, SCALE_L = p['Fij'], p['Fpq'], p['Fab'], p['Fijab'], p['SCALE'], p['SCALE_L']
+    f2 = lambda X: SCALE * _fft2(np.asarray(X, dtype=np.complex128), workers)
+    FJ = f2(PixA_J)
+    Iij, Sij, Tpq = _kernel_planes(PixA_I, basis), _scaling_planes(PixA_I, sca), _bkg_planes(basis)
+    Wl = np.exp((-2j * np.pi / N0) * np.arange(N0))
+    Wm = np.exp((-2j * np.pi / N1) * np.arange(N1))
+    Wla = np.stack([Wl ** a for a in range(-w0, w0 + 1)])
+    Wmb = np.stack([Wm ** b for b in range(-w1, w1 + 1)])
+    a_ijab = np.asarray(Solution[:Fijab], dtype=np.complex128)
+    b_pq = np.asarray(Solution[Fijab:], dtype=np.complex128)
+    cen = w0 * L1 + w1
+    PVAL = np.zeros((N0, N1), dtype=np.complex128)
+    for ij in range(Fij):
+        A = a_ijab[ij * Fab:(ij + 1) * Fab].copy()
+        a00 = A[cen]
+        A[cen] = 0.0
+        A = A.reshape(L0, L1)
+        PVAL += f2(Iij[ij]) * (SCALE * ((Wla.T @ A) @ Wmb - A.sum()))
+        PVAL += a00 * f2(Sij[ij]) * SCALE
+    for pq in range(Fpq):
+        PVAL += b_pq[pq] * f2(Tpq[pq])
+    return np.ascontiguousarray((SCALE_L * _ifft2(FJ - PVAL, workers)).real)
+
+
+def design_matrix(PixA_I, p, basis, sca=None):
+    """Brute-force real-space model: column (ij, a, b) = SCALE * (I_ij rolled by (a, b) - I_ij),
+    centre column = SCALE * I_ij (ENTANGLED / SEPARATE-CONSTANT) or SCALE * ScaI_ij (SEPARATE-VARYING), then T_pq.
+    LHMAT == SCALE * A^T A and RHb == SCALE * A^T J.  Small images only."""
+    Fij, Fab, L0, L1, w0, w1, SCALE = p['Fij'], p['Fab'], p['L0'], p['L1'], p['w0'], p['w1'], p['SCALE']
+    Iij = _kernel_planes(PixA_I, basis)
+    Sij = _scaling_planes(PixA_I, sca) if p['SCALING_MODE'] == 'SEPARATE-VARYING' else Iij
+    cols = []
+    for ij in range(Fij):
+        for a in range(-w0, w0 + 1):
+            for b in range(-w1, w1 + 1):
+                if a == 0 and b == 0:
+                    cols.append(SCALE * Sij[ij])
+                else:
+                    cols.append(SCALE * (np.roll(Iij[ij], (a, b), axis=(0, 1)) - Iij[ij]))
+    for T in _bkg_planes(basis):
+        cols.append(T)
+    return np.stack([c.reshape(-1) for c in cols], axis=1)
+
+
+def ESS(PixA_I, PixA_J, p, basis, sca, SFFTSolution=None, Subtract=False, REGMAT=None, LAMBDA_REGULARIZE=0.0, workers=1):
+    PixA_I = np.ascontiguousarray(PixA_I, np.float64)
+    PixA_J = np.ascontiguousarray(PixA_J, np.float64)
+    if SFFTSolution is None:
+        LHMAT, RHb = establish_system(PixA_I, PixA_J, p, basis, sca, workers)
+        if REGMAT is not None:
+            LHMAT = LHMAT + LAMBDA_REGULARIZE * REGMAT
+        Solution = solve_system(LHMAT, RHb, p)
+    else:
+        Solution = np.asarray(SFFTSolution, dtype=np.float64)
+    DIFF = subtract(PixA_I, PixA_J, Solution, p, basis, sca, workers) if Subtract else None
+    return Solution, DIFF
+
+
+def GSS(PixA_I, PixA_J, PixA_mI, PixA_mJ, p, basis, sca, REGMAT=None, LAMBDA_REGULARIZE=0.0, workers=1):
+    Solution = ESS(PixA_mI, PixA_mJ, p, basis, sca, None, False, REGMAT, LAMBDA_REGULARIZE, workers)[0]
+    DIFF = ESS(PixA_I, PixA_J, p, basis, sca, Solution, True, workers=workers)[1]
+    return Solution, DIFF
