@@ -45,6 +45,7 @@ enum {
     SFFT_Q_WORKSPACE_BYTES,         /* device memory owned by the plan */
     SFFT_Q_LAST_SOLVER,             /* 1 = Cholesky, 2 = LU fallback, for the most recent solve */
     SFFT_Q_NUM_GREEK_PAIRS,         /* spectral products actually transformed per solve */
+    SFFT_Q_SCAFIJ,                  /* scaling terms of a plan made by sfft_plan_create_varscale (0 otherwise) */
     SFFT_Q_COUNT
 };
 
@@ -81,6 +82,27 @@ int sfft_plan_create_basis(sfft_plan** plan, int N0, int N1, int KerHW,
                            int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
                            int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
                            int scaling_mode, int device);
+
+/* The B-spline form with SEPARATELY VARYING flux scaling (sfft/BSplineSFFT.py SCALING_MODE 'SEPARATE-VARYING':
+ * parameters :173-201, scaling planes :334-397, linear system :1348-2005, TweakLS :2293-2342, Construct_FDIFF :2429-2527).
+ * As sfft_plan_create_basis, plus the spatial basis of the scaling: term s (s < ScaFij <= Fij) is
+ * sbx[sca_pairs[2 s]][row] * sby[sca_pairs[2 s + 1]][col].  The unknown (ij, ab = kernel centre) is the coefficient of
+ * scaling term ij for ij < ScaFij; for ij >= ScaFij it leaves the system and is returned as 0 (the reference's zero
+ * place-holder terms, ScaREF_ij == (-1, -1)). */
+int sfft_plan_create_varscale(sfft_plan** plan, int N0, int N1, int KerHW,
+                              int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
+                              int nsx, int nsy, const double* sbx, const double* sby, int ScaFij, const int* sca_pairs,
+                              int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
+                              int device);
+
+/* Kernel regularisation (sfft/BSplineSFFT.py REGULARIZE_KERNEL: matrices :3570-3686, fill_regmat :2090-2166, update :3700):
+ * every later solve on this plan adds  lambda * SCALE^2 * S[k][k8] * ireg[c][c8]  to LHMAT[(k, c), (k8, c8)] before the
+ * scaling constraint is applied.  ireg [Fab][Fab] = the reference's iREGMAT (integer valued), sst [Fij][Fij] = SSTMAT;
+ * csst / dsst [Fij][Fij] = CSSTMAT / DSSTMAT, required only by plans from sfft_plan_create_varscale (S = csst when exactly
+ * one of c, c8 is the kernel centre -- indexed [kernel term][scaling term] -- and dsst when both are).  HOST pointers,
+ * copied.  lambda == 0 or ireg == NULL switches regularisation off. */
+int sfft_plan_set_regularization(sfft_plan* plan, double lambda, const double* ireg, const double* sst,
+                                 const double* csst, const double* dsst);
 
 int sfft_plan_destroy(sfft_plan* plan);
 

@@ -6,8 +6,11 @@ The kernel's and the background's spatial variation are separable per term (a fu
 the column), for polynomials and B-splines alike; this module tabulates those 1-D factors on the host exactly like the
 reference (scipy.interpolate.BSpline, BSplineSFFT.py:2624-2645) and hands them to `sfft_plan_create_basis`.
 
-Supported scaling modes (BSplineSFFT.py:47-60): 'ENTANGLED' (SEPARATE_SCALING=False) and 'SEPARATE-CONSTANT'
-(SEPARATE_SCALING=True, ScaSpDegree=0).  'SEPARATE-VARYING' scaling and REGULARIZE_KERNEL are not built yet and raise.
+All three scaling modes of the reference (BSplineSFFT.py:47-60) are served: 'ENTANGLED' (SEPARATE_SCALING=False),
+'SEPARATE-CONSTANT' (SEPARATE_SCALING=True, ScaSpDegree=0) and 'SEPARATE-VARYING' (ScaSpDegree > 0, the scaling has its
+own polynomial / B-spline basis -> `sfft_plan_create_varscale`), each with optional REGULARIZE_KERNEL: the small
+matrices of the Laplacian penalty (iREGMAT, SSTMAT, CSSTMAT, DSSTMAT, BSplineSFFT.py:3570-3686) are built here on the
+host like the reference does and handed to `sfft_plan_set_regularization`; the device adds them while filling LHMAT.
 """
 import os.path as pa
 import time
@@ -22,7 +25,7 @@ from .sfftcore.SFFTSubtract import (ElementalSFFTSubtract, ElementalSFFTSubtract
 from .utils import minifits
 
 __all__ = ["SingleSFFTConfigure", "ElementalSFFTSubtract", "GeneralSFFTSubtract", "GeneralSFFTSubtract_PureCupy",
-           "BSpline_Packet", "Create_BSplineBasis"]
+           "BSpline_Packet", "Create_BSplineBasis", "Create_BSplineBasis_Req"]
 
 try:  # pragma: no cover - astropy is absent from the target image
     from astropy.io import fits as _afits
@@ -42,6 +45,51 @@ def Create_BSplineBasis(N, IntKnot, BSplineDegree):
         Coeff = (np.arange(Nc) == idx).astype(float)
         out.append(BSpline(t=Knot, c=Coeff, k=BSplineDegree, extrapolate=False)(PixCoord))
     return np.array(out).astype(np.float64)
+
+
+def Create_BSplineBasis_Req(N, IntKnot, BSplineDegree, ReqCoord):
+    """The same basis functions at requested scaled coordinates (BSplineSFFT.py:2636-2646)."""
+    from scipy.interpolate import BSpline
+    Knot = np.concatenate(([0.5] * (BSplineDegree + 1), list(IntKnot), [N + 0.5] * (BSplineDegree + 1))) / N
+    Nc = len(IntKnot) + BSplineDegree + 1
+    out = []
+    for idx in range(Nc):
+        Coeff = (np.arange(Nc) == idx).astype(float)
+        out.append(BSpline(t=Knot, c=Coeff, k=BSplineDegree, extrapolate=False)(ReqCoord))
+    return np.array(out)
+
+
+def _spatial_at(N0, N1, SpType, Degree, IntKnotX, IntKnotY, CX, CY):
+    """[number of terms][len(CX)]: every spatial term of a basis evaluated at scaled coordinates (CX, CY)."""
+    if SpType == 'Polynomial':
+        return np.array([CX ** i * CY ** j for i in range(Degree + 1) for j in range(Degree + 1 - i)])
+    BX = Create_BSplineBasis_Req(N0, IntKnotX, Degree, CX)
+    BY = Create_BSplineBasis_Req(N1, IntKnotY, Degree, CY)
+    return np.array([BX[i] * BY[j] for i in range(BX.shape[0]) for j in range(BY.shape[0])])
+
+
+def _laplacian_iregmat(w0, w1, IGNORE_LAPLACIAN_KERCENT):
+    """iREGMAT [Fab][Fab]: the squared 5-point Laplacian of the kernel stamp expressed in the modified-delta basis
+    (LAPMAT / LTLMAT / fill_iregmat, BSplineSFFT.py:3640-3686 and :2009-2087), vectorised."""
+    L0, L1 = 2 * w0 + 1, 2 * w1 + 1
+    Fab = L0 * L1
+    rr, cc = np.divmod(np.arange(Fab), L1)
+    dist = np.abs(rr[:, None] - rr[None, :]) + np.abs(cc[:, None] - cc[None, :])
+    LAP = -(dist == 1).astype(np.int64)
+    LAP[np.arange(Fab), np.arange(Fab)] = (dist == 1).sum(axis=1)        # number of 4-neighbours inside the stamp
+    if IGNORE_LAPLACIAN_KERCENT:
+        for r in ((w0 - 1) * L1 + w1, w0 * L1 + w1 - 1, w0 * L1 + w1, w0 * L1 + w1 + 1, (w0 + 1) * L1 + w1):
+            LAP[r, :] = 0
+    LTL = LAP.T @ LAP
+    c0 = w0 * L1 + w1
+    sym = LTL + LTL.T
+    colc, rowc = LTL[:, c0], LTL[c0, :]
+    ireg = sym - rowc[:, None] - rowc[None, :] - colc[:, None] - colc[None, :] + 2 * LTL[c0, c0]
+    edge = colc + rowc - 2 * LTL[c0, c0]
+    ireg[:, c0] = edge
+    ireg[c0, :] = edge
+    ireg[c0, c0] = 2 * LTL[c0, c0]
+    return ireg.astype(np.float64)
 
 
 def _axis_tables(N0, N1, SpType, Degree, IntKnotX, IntKnotY):
@@ -95,29 +143,52 @@ class SingleSFFTConfigure:
             SCALING_MODE = 'SEPARATE-VARYING'
         if SCALING_MODE == 'SEPARATE-CONSTANT':
             assert DK != 0   # otherwise, reduced to ENTANGLED
+        DS = None
+        if SEPARATE_SCALING:
+            DS = int(ScaSpDegree)
+            assert DS >= 0
+            assert ScaSpType in ['Polynomial', 'B-Spline']
+            if ScaSpType == 'B-Spline' and DS == 0:
+                assert len(ScaIntKnotX) == 0 and len(ScaIntKnotY) == 0   # otherwise, discontinuity
         if SCALING_MODE == 'SEPARATE-VARYING':
-            raise NotImplementedError("MeLOn ERROR: SCALING_MODE 'SEPARATE-VARYING' (ScaSpDegree > 0) is not built in sfft_amd yet")
+            # (the reference also insists on MINIMIZE_GPU_MEMORY_USAGE here, :68; Greek planes are always streamed in this build)
+            if KerSpType == 'Polynomial' and ScaSpType == 'Polynomial':
+                assert DS != DK   # otherwise, reduced to ENTANGLED
+            if KerSpType == 'B-Spline' and ScaSpType == 'B-Spline':
+                if np.array_equal(np.asarray(KerIntKnotX), np.asarray(ScaIntKnotX)) and \
+                        np.array_equal(np.asarray(KerIntKnotY), np.asarray(ScaIntKnotY)):
+                    assert DS != DK   # otherwise, reduced to ENTANGLED
         if REGULARIZE_KERNEL:
-            raise NotImplementedError("MeLOn ERROR: REGULARIZE_KERNEL is not built in sfft_amd yet")
+            assert XY_REGULARIZE is not None
+            XY_REGULARIZE = np.asarray(XY_REGULARIZE, dtype=np.float64)
+            assert len(XY_REGULARIZE.shape) == 2 and XY_REGULARIZE.shape[1] == 2
 
         kbx, kby, kpairs = _axis_tables(N0, N1, KerSpType, DK, KerIntKnotX, KerIntKnotY)
         tbx, tby, bpairs = _axis_tables(N0, N1, BkgSpType, DB, BkgIntKnotX, BkgIntKnotY)
+        sbx = sby = spairs = None
         if SCALING_MODE == 'ENTANGLED':
             mode = 0
-        else:
+        elif SCALING_MODE == 'SEPARATE-CONSTANT':
             mode = 1 if KerSpType == 'Polynomial' else 2    # TweakLS: delete vs. sum the ij00 rows/columns (:2171-2272)
+        else:
+            mode = 3
+            sbx, sby, spairs = _axis_tables(N0, N1, ScaSpType, DS, ScaIntKnotX, ScaIntKnotY)
+            assert len(spairs) <= len(kpairs)               # ScaFij <= Fij (:190)
         if CUDA_DEVICE_4SUBTRACT is None:
             device = torch.cuda.current_device()
         else:
             device = int(CUDA_DEVICE_4SUBTRACT)
         key = (device, N0, N1, w0, KerSpType, DK, tuple(KerIntKnotX), tuple(KerIntKnotY), BkgSpType, DB,
-               tuple(BkgIntKnotX), tuple(BkgIntKnotY), mode)
+               tuple(BkgIntKnotX), tuple(BkgIntKnotY), mode,
+               (ScaSpType, DS, tuple(ScaIntKnotX), tuple(ScaIntKnotY)) if mode == 3 else None)
         plan = _PLANS.get(key)
         if plan is None:
             if VERBOSE_LEVEL in [1, 2]:
                 print('\n --//--//--//--//-- TRIGGER SFFT COMPILATION [HIP] --//--//--//--//-- ')
-            plan = Plan(N0, N1, w0, device=device, basis=dict(kbx=kbx, kby=kby, ker_pairs=kpairs, tbx=tbx, tby=tby,
-                                                              bkg_pairs=bpairs, scaling_mode=mode))
+            bdict = dict(kbx=kbx, kby=kby, ker_pairs=kpairs, tbx=tbx, tby=tby, bkg_pairs=bpairs, scaling_mode=mode)
+            if mode == 3:
+                bdict.update(sbx=sbx, sby=sby, sca_pairs=spairs)
+            plan = Plan(N0, N1, w0, device=device, basis=bdict)
             if len(_PLANS) >= 3:
                 _PLANS.pop(next(iter(_PLANS)))
             _PLANS[key] = plan
@@ -125,10 +196,35 @@ class SingleSFFTConfigure:
         L0 = L1 = 2 * w0 + 1
         Fab = L0 * L1
         Fij, Fpq = len(kpairs), len(bpairs)
+
+        # kernel regularisation: the plan is shared by later calls, so it is (re)set on every SSC
+        if REGULARIZE_KERNEL:
+            NREG = XY_REGULARIZE.shape[0]
+            CX_REG, CY_REG = XY_REGULARIZE[:, 0] / N0, XY_REGULARIZE[:, 1] / N1
+            SPMAT = _spatial_at(N0, N1, KerSpType, DK, KerIntKnotX, KerIntKnotY, CX_REG, CY_REG)
+            if WEIGHT_REGULARIZE is None:
+                WS = np.full(NREG, 1.0 / NREG)
+            else:
+                WS = np.asarray(WEIGHT_REGULARIZE, dtype=np.float64) / np.sum(WEIGHT_REGULARIZE)   # unit sum
+            SST = (SPMAT * WS) @ SPMAT.T
+            CSST = DSST = None
+            if mode == 3:
+                ScaSPMAT = _spatial_at(N0, N1, ScaSpType, DS, ScaIntKnotX, ScaIntKnotY, CX_REG, CY_REG)
+                if ScaSPMAT.shape[0] < Fij:     # zero place-holders
+                    ScaSPMAT = np.concatenate((ScaSPMAT, np.zeros((Fij - ScaSPMAT.shape[0], NREG))), axis=0)
+                CSST = (SPMAT * WS) @ ScaSPMAT.T
+                DSST = (ScaSPMAT * WS) @ ScaSPMAT.T
+            plan.set_regularization(float(LAMBDA_REGULARIZE), _laplacian_iregmat(w0, w0, IGNORE_LAPLACIAN_KERCENT), SST, CSST, DSST)
+        else:
+            plan.set_regularization(0.0)
         P = {}
         P['KerHW'], P['KerSpType'], P['KerSpDegree'] = KerHW, KerSpType, KerSpDegree
         P['KerIntKnotX'], P['KerIntKnotY'] = KerIntKnotX, KerIntKnotY
         P['SEPARATE_SCALING'], P['SCALING_MODE'] = SEPARATE_SCALING, SCALING_MODE
+        if SEPARATE_SCALING:
+            P['ScaSpType'], P['ScaSpDegree'], P['ScaIntKnotX'], P['ScaIntKnotY'], P['DS'] = ScaSpType, ScaSpDegree, ScaIntKnotX, ScaIntKnotY, DS
+        P['REGULARIZE_KERNEL'], P['IGNORE_LAPLACIAN_KERCENT'] = REGULARIZE_KERNEL, IGNORE_LAPLACIAN_KERCENT
+        P['XY_REGULARIZE'], P['WEIGHT_REGULARIZE'], P['LAMBDA_REGULARIZE'] = XY_REGULARIZE, WEIGHT_REGULARIZE, LAMBDA_REGULARIZE
         P['BkgSpType'], P['BkgSpDegree'], P['BkgIntKnotX'], P['BkgIntKnotY'] = BkgSpType, BkgSpDegree, BkgIntKnotX, BkgIntKnotY
         P['N0'], P['N1'], P['w0'], P['w1'], P['DK'], P['DB'] = N0, N1, w0, w0, DK, DB
         P['SCALE'], P['SCALE_L'] = np.float64(1 / (N0 * N1)), np.float64(N0 * N1)
@@ -141,8 +237,15 @@ class SingleSFFTConfigure:
         P['FOMG'], P['FGAM'], P['FTHE'] = Fij ** 2, Fij * Fpq, Fij
         P['FPSI'], P['FPHI'], P['FDEL'] = Fpq * Fij, Fpq ** 2, Fpq
         P['NEQ'] = Fij * Fab + Fpq
-        P['NEQt'] = P['NEQ'] - Fij + 1 if mode != 0 else P['NEQ']
-        P['ConstPhotRatio'] = (mode != 0)
+        P['NEQt'] = P['NEQ']
+        if mode in (1, 2):
+            P['NEQt'] = P['NEQ'] - Fij + 1
+        if mode == 3:
+            P['ScaFi'] = sbx.shape[0] if ScaSpType == 'B-Spline' else -1
+            P['ScaFj'] = sby.shape[0] if ScaSpType == 'B-Spline' else -1
+            P['ScaFij'] = len(spairs)
+            P['NEQt'] = P['NEQ'] - (Fij - P['ScaFij'])
+        P['ConstPhotRatio'] = mode in (1, 2)
         return (P, {'plan': plan, 'backend': 'HIP'})
 
 
@@ -200,7 +303,10 @@ class BSpline_Packet:
                   [('SIKY%d' % i, k) for i, k in enumerate(ScaIntKnotY)]
         kw += [('BSPTYPE', str(BkgSpType)), ('BSPDEG', BkgSpDegree), ('NBIKX', len(BkgIntKnotX))] + \
               [('BIKX%d' % i, k) for i, k in enumerate(BkgIntKnotX)] + [('NBIKY', len(BkgIntKnotY))] + \
-              [('BIKY%d' % i, k) for i, k in enumerate(BkgIntKnotY)] + [('REGKER', str(REGULARIZE_KERNEL))]
+              [('BIKY%d' % i, k) for i, k in enumerate(BkgIntKnotY)] + \
+              [('REGKER', str(REGULARIZE_KERNEL)), ('ILKC', str(IGNORE_LAPLACIAN_KERCENT)),
+               ('NREG', -1 if XY_REGULARIZE is None else int(np.asarray(XY_REGULARIZE).shape[0])),
+               ('REGW', 'UNIFORM' if WEIGHT_REGULARIZE is None else 'SPECIFIED'), ('REGLAMB', LAMBDA_REGULARIZE)]
         if FITS_DIFF is not None:
             if _afits is not None:
                 with _afits.open(FITS_SCI) as hdl:
@@ -218,8 +324,15 @@ class BSpline_Packet:
                 minifits.writeto(FITS_DIFF, np.ascontiguousarray(out), cards)
         if FITS_Solution is not None:
             P = SFFTConfig[0]
-            skw = [('N0', P['N0']), ('N1', P['N1']), ('W0', P['w0']), ('W1', P['w1']), ('DK', P['DK']), ('DB', P['DB']),
-                   ('L0', P['L0']), ('L1', P['L1']), ('FIJ', P['Fij']), ('FAB', P['Fab']), ('FPQ', P['Fpq']), ('FIJAB', P['Fijab'])] + kw[5:]
+            # key set and order of BSplineSFFT.py:4282-4351
+            skw = kw[:2] + kw[2:] + [('N0', P['N0']), ('N1', P['N1']), ('W0', P['w0']), ('W1', P['w1']), ('DK', P['DK']), ('DB', P['DB'])]
+            if SEPARATE_SCALING:
+                skw += [('DS', P['DS'])]
+            skw += [('L0', P['L0']), ('L1', P['L1']), ('FAB', P['Fab']), ('FI', P['Fi']), ('FJ', P['Fj']), ('FIJ', P['Fij']),
+                    ('FP', P['Fp']), ('FQ', P['Fq']), ('FPQ', P['Fpq'])]
+            if SEPARATE_SCALING and ScaSpDegree > 0:
+                skw += [('SCAFI', P['ScaFi']), ('SCAFJ', P['ScaFj']), ('SCAFIJ', P['ScaFij'])]
+            skw += [('FIJAB', P['Fijab']), ('NEQ', P['NEQ']), ('NEQT', P['NEQt'])]
             if _afits is not None:
                 phdu = _afits.PrimaryHDU()
                 for k, v in skw:

@@ -19,10 +19,10 @@ SFFT_ERR_NOMEM = -5
 
 QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1", "Fab", "Fij", "Fpq", "NEQ", "Fijab",
                 "NEQ_FSfree", "FOMG", "FGAM", "FTHE", "FPSI", "FPHI", "FDEL", "WORKSPACE_BYTES", "LAST_SOLVER",
-                "NUM_GREEK_PAIRS"]
+                "NUM_GREEK_PAIRS", "ScaFij"]
 STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b"]
 
-EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
+EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_create_varscale", "sfft_plan_set_regularization", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
            "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",
            "sfft_spec_abs2_accumulate", "sfft_real_rsqrt", "sfft_spec_multiply", "sfft_half_to_full_real", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",
            "sfft_last_error", "sfft_version"]
@@ -41,6 +41,9 @@ def _load():
     vp, dp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int
     lib.sfft_plan_create.argtypes = [ctypes.POINTER(vp), ip, ip, ip, ip, ip, ip, ip]
     lib.sfft_plan_create_basis.argtypes = [ctypes.POINTER(vp), ip, ip, ip, ip, ip, dp, dp, ip, dp, ip, ip, dp, dp, ip, dp, ip, ip]
+    lib.sfft_plan_create_varscale.argtypes = [ctypes.POINTER(vp), ip, ip, ip, ip, ip, dp, dp, ip, dp, ip, ip, dp, dp, ip, dp,
+                                              ip, ip, dp, dp, ip, dp, ip]
+    lib.sfft_plan_set_regularization.argtypes = [vp, ctypes.c_double, dp, dp, dp, dp]
     lib.sfft_plan_destroy.argtypes = [vp]
     lib.sfft_plan_query.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_longlong)]
     lib.sfft_solve.argtypes = [vp, dp, dp, dp, vp]

@@ -10,8 +10,10 @@
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) kernel_ctab(const double* __restrict__ sol, cplx* __restrict__ Ctab, double* __restrict__ Soff,
                                                    int Fij, int L0, int L1, int w1, int Nh, int Nhp, int N1,
-                                                   const cplx* __restrict__ root1)
+                                                   const cplx* __restrict__ root1, int skip_centre)
 {
+    // skip_centre: separately varying scaling -- the centre coefficient a_ij00 does not multiply kernel plane ij
+    // (BSplineSFFT.py:2489-2497); its term is applied in real space by scaling_term()
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int ija = blockIdx.y;                   // ij*L0 + a
     const int Fab = L0 * L1;
@@ -25,14 +27,37 @@ __global__ void __launch_bounds__(256) kernel_ctab(const double* __restrict__ so
     if (m >= Nh) return;
     const double* arow = sol + (size_t)ija * L1;  // ij*Fab + a*L1
     double cxr = 0.0, cyi = 0.0;
+    const bool centre_row = skip_centre && (ija % L0) == L0 / 2;
     for (int bb = 0; bb < L1; ++bb) {
         const int b = bb - w1;
         long long q = ((long long)m * b) % N1; if (q < 0) q += N1;
         const cplx w = root1[q];
-        cxr = fma(arow[bb], w.x, cxr);
-        cyi = fma(arow[bb], w.y, cyi);
+        const double av = (centre_row && b == 0) ? 0.0 : arow[bb];
+        cxr = fma(av, w.x, cxr);
+        cyi = fma(av, w.y, cyi);
     }
     Ctab[(size_t)ija * Nhp + m] = make_double2(cxr, cyi);
+}
+
+// separately varying scaling: DIFF -= SCALE * I * sum_s a_s00 * sbx[sp[s]][row] * sby[sq[s]][col]  (the centre term of
+// Construct_FDIFF, BSplineSFFT.py:2489-2497, taken in real space: it is a plain product there)
+struct ScaArgs {
+    int nsca, Fab, cen;
+    const double* sbx;              // [nsx][N0]
+    const double* sby;              // [nsy][N1]
+    int sp[SFFT_MAX_PQ], sq[SFFT_MAX_PQ];
+};
+__global__ void __launch_bounds__(256) scaling_term(const double* __restrict__ I, const double* __restrict__ sol, ScaArgs sa,
+                                                    double* __restrict__ DIFF, int N0, int N1, double scale)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int row = blockIdx.y;
+    if (col >= N1) return;
+    double acc = 0.0;
+    for (int s = 0; s < sa.nsca; ++s)
+        acc = fma(sol[(size_t)s * sa.Fab + sa.cen] * sa.sbx[(size_t)sa.sp[s] * N0 + row], sa.sby[(size_t)sa.sq[s] * N1 + col], acc);
+    const size_t o = (size_t)row * N1 + col;
+    DIFF[o] -= scale * I[o] * acc;
 }
 
 #define CRL 8

@@ -19,6 +19,16 @@ struct FillArgs {
     // tied scaling (B-spline constant photometric ratio, BSplineSFFT.py:2201-2272): the unknowns tie_first + k*tie_stride,
     // k < tie_cnt, are one unknown; its row / column is the SUM of theirs.  tie_cnt = 0: no tie.
     int tie_first, tie_cnt, tie_stride;
+    // separately varying scaling (BSplineSFFT.py SCALING_MODE 'SEPARATE-VARYING', :1348-2005): the centre unknown
+    // (ij, 00) belongs to SCALING plane ij (a zero place-holder for ij >= nsca) instead of kernel plane ij.  Patches of
+    // half width h_gam: sk (s, ij) = ScaI_s x I_ij, ss (s <= t) = ScaI_s x ScaI_t, sg (s, pq), st (s) = ScaI_s x J.
+    int sv, nsca;
+    int sk_off, ss_off, sg_off, st_off;
+    // kernel regularisation (BSplineSFFT.py:2007-2168, 3570-3700): LHMAT += reg_coef * S[k][k8] * ireg[c][c8], with
+    // S = sst, or for separately varying scaling csst / dsst when one / both of c, c8 are the kernel centre.
+    double reg_coef;                 // LAMBDA_REGULARIZE * SCALE^2; 0 = off
+    const double* ireg;              // [Fab][Fab]
+    const double *sst, *csst, *dsst; // [Fij][Fij]
 };
 
 __device__ __forceinline__ double omg_at(const double* P, const FillArgs& f, int i8, int ij, int r0, int r1)
@@ -30,6 +40,33 @@ __device__ __forceinline__ double omg_at(const double* P, const FillArgs& f, int
     return P[f.omg_off + (size_t)pidx * PH * PH + (size_t)(r0 + f.h_omg) * PH + (r1 + f.h_omg)];
 }
 
+// lag patches of the scaling planes (h_gam wide)
+__device__ __forceinline__ double sk_at(const double* P, const FillArgs& f, int s, int ij, int r0, int r1)
+{
+    if (s >= f.nsca) return 0.0;
+    const int PHg = 2 * f.h_gam + 1;
+    return P[f.sk_off + (size_t)(s * f.Fij + ij) * PHg * PHg + (size_t)(r0 + f.h_gam) * PHg + (r1 + f.h_gam)];
+}
+__device__ __forceinline__ double ss_at0(const double* P, const FillArgs& f, int s, int t)
+{
+    if (s >= f.nsca || t >= f.nsca) return 0.0;
+    const int PHg = 2 * f.h_gam + 1;
+    const int lo = min(s, t), hi = max(s, t);
+    const int pidx = lo * f.nsca - (lo * (lo - 1)) / 2 + (hi - lo);
+    return P[f.ss_off + (size_t)pidx * PHg * PHg + (size_t)f.h_gam * PHg + f.h_gam];     // lag 0 is symmetric in (s, t)
+}
+
+__device__ double reg_element(const FillArgs& f, int i8, int ab8, bool c8, int ij, int ab, bool c)
+{
+    const double* S = f.sst;
+    if (f.sv) {
+        if (c8 && c) S = f.dsst;
+        else if (c) return f.reg_coef * f.csst[i8 * f.Fij + ij] * f.ireg[(size_t)ab8 * f.Fab + ab];
+        else if (c8) return f.reg_coef * f.csst[ij * f.Fij + i8] * f.ireg[(size_t)ab8 * f.Fab + ab];
+    }
+    return f.reg_coef * S[i8 * f.Fij + ij] * f.ireg[(size_t)ab8 * f.Fab + ab];
+}
+
 __device__ double sys_element(const double* P, const double* phi, const double* delta, const FillArgs& f, int R, int C, int NEQ)
 {
     const int PHg = 2 * f.h_gam + 1;
@@ -37,6 +74,8 @@ __device__ double sys_element(const double* P, const double* phi, const double* 
         if (R < f.Fijab) {
             const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
             const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
+            if (f.sv && a8 == 0 && b8 == 0)
+                return i8 < f.nsca ? P[f.st_off + (size_t)i8 * PHg * PHg + (size_t)f.h_gam * PHg + f.h_gam] : 0.0;
             const double* T = P + f.the_off + (size_t)i8 * PHg * PHg;
             const double t0 = T[(size_t)f.h_gam * PHg + f.h_gam];
             if (a8 == 0 && b8 == 0) return t0;
@@ -50,16 +89,25 @@ __device__ double sys_element(const double* P, const double* phi, const double* 
         const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
         const int a = ab / f.L1 - f.w0, b = ab % f.L1 - f.w1;
         const bool c8 = (a8 == 0 && b8 == 0), c = (a == 0 && b == 0);
+        const double reg = (f.reg_coef != 0.0) ? reg_element(f, i8, ab8, c8, ij, ab, c) : 0.0;
+        if (f.sv && (c8 || c)) {
+            // OMG01 = ScaI_i8 x I_ij read at (-a, -b); OMG10 = I_i8 x ScaI_ij at (a8, b8) == ScaI_ij x I_i8 at (-a8, -b8)
+            if (c8 && c) return ss_at0(P, f, i8, ij) + reg;
+            if (c8) return sk_at(P, f, i8, ij, -a, -b) - sk_at(P, f, i8, ij, 0, 0) + reg;
+            return sk_at(P, f, ij, i8, -a8, -b8) - sk_at(P, f, ij, i8, 0, 0) + reg;
+        }
         const double o00 = omg_at(P, f, i8, ij, 0, 0);
-        if (c8 && c) return o00;
-        if (c8) return omg_at(P, f, i8, ij, -a, -b) - o00;
-        if (c) return omg_at(P, f, i8, ij, a8, b8) - o00;
-        return -omg_at(P, f, i8, ij, a8, b8) - omg_at(P, f, i8, ij, -a, -b) + omg_at(P, f, i8, ij, a8 - a, b8 - b) + o00;
+        if (c8 && c) return o00 + reg;
+        if (c8) return omg_at(P, f, i8, ij, -a, -b) - o00 + reg;
+        if (c) return omg_at(P, f, i8, ij, a8, b8) - o00 + reg;
+        return -omg_at(P, f, i8, ij, a8, b8) - omg_at(P, f, i8, ij, -a, -b) + omg_at(P, f, i8, ij, a8 - a, b8 - b) + o00 + reg;
     }
     if (R < f.Fijab) {          // GAM block
         const int pq = C - f.Fijab;
         const int i8 = R / f.Fab, ab8 = R - i8 * f.Fab;
         const int a8 = ab8 / f.L1 - f.w0, b8 = ab8 % f.L1 - f.w1;
+        if (f.sv && a8 == 0 && b8 == 0)
+            return i8 < f.nsca ? P[f.sg_off + (size_t)(i8 * f.Fpq + pq) * PHg * PHg + (size_t)f.h_gam * PHg + f.h_gam] : 0.0;
         const double* G = P + f.gam_off + (size_t)(i8 * f.Fpq + pq) * PHg * PHg;
         const double g0 = G[(size_t)f.h_gam * PHg + f.h_gam];
         if (a8 == 0 && b8 == 0) return g0;
@@ -69,6 +117,8 @@ __device__ double sys_element(const double* P, const double* phi, const double* 
         const int pq = R - f.Fijab;
         const int ij = C / f.Fab, ab = C - ij * f.Fab;
         const int a = ab / f.L1 - f.w0, b = ab % f.L1 - f.w1;
+        if (f.sv && a == 0 && b == 0)
+            return ij < f.nsca ? P[f.sg_off + (size_t)(ij * f.Fpq + pq) * PHg * PHg + (size_t)f.h_gam * PHg + f.h_gam] : 0.0;
         const double* G = P + f.gam_off + (size_t)(ij * f.Fpq + pq) * PHg * PHg;
         const double g0 = G[(size_t)f.h_gam * PHg + f.h_gam];
         if (a == 0 && b == 0) return g0;

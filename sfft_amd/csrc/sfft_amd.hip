@@ -81,7 +81,16 @@ struct sfft_plan {
     int nkx = 0, nky = 0, nbx = 0, nby = 0;
     std::vector<int> kpair, bpair;      // [Fij][2] / [Fpq][2]: (x-factor, y-factor) of kernel term ij / background term pq
     double *d_kbx = nullptr, *d_kby = nullptr, *d_tbx = nullptr, *d_tby = nullptr;   // [nkx][N0], [nky][N1], [nbx][N0], [nby][N1]
-    int mode = 0;                       // 0: free scaling, 1: unknowns ij00[1:] removed, 2: unknowns ij00 tied together
+    int mode = 0;                       // 0: free scaling, 1: unknowns ij00[1:] removed, 2: unknowns ij00 tied together,
+                                        // 3: centre unknowns carry their own (scaling) spatial basis, ij00[nsca:] removed
+    // scaling basis of mode 3 (BSplineSFFT.py 'SEPARATE-VARYING'): scaling plane s = I * sbx[spair[2s]] (x) sby[spair[2s+1]]
+    int nsx = 0, nsy = 0, nsca = 0;
+    std::vector<int> spair;
+    double *d_sbx = nullptr, *d_sby = nullptr;
+    ScaArgs sa;
+    bool has_idx = false;               // a row/column selection (d_idx) precedes the solve
+    // kernel regularisation tables (device copies; see FillArgs)
+    double *d_ireg = nullptr, *d_sst = nullptr, *d_csst = nullptr, *d_dsst = nullptr;
     BkgArgs bk;
     // device tables
     int* d_idx = nullptr;               // [NEQfs] (only when mode != 0)
@@ -94,6 +103,7 @@ struct sfft_plan {
     std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
     std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
+    int n_dense_w = 0, n_row0 = 0;      // passes of half width w through greek_g1 / through greek_g1_row0
 
     int S = 1, rows_per_chunk = 0;
     FillArgs fa;
@@ -258,6 +268,10 @@ struct BasisSpec {
     int nkx = 0, nky = 0, nbx = 0, nby = 0, Fij = 0, Fpq = 0, mode = 0;
     std::vector<double> kbx, kby, tbx, tby;   // [nkx][N0], [nky][N1], [nbx][N0], [nby][N1]
     std::vector<int> kpair, bpair;            // [Fij][2], [Fpq][2]
+    // mode 3 only: scaling factors and the (x-factor, y-factor) pair of each of the ScaFij <= Fij scaling terms
+    int nsx = 0, nsy = 0, ScaFij = 0;
+    std::vector<double> sbx, sby;             // [nsx][N0], [nsy][N1]
+    std::vector<int> spair;                   // [ScaFij][2]
 };
 
 // DFT of a tabulated 1-D factor, direct O(N^2) in extended precision; an all-ones factor gives exactly N * delta
@@ -296,13 +310,21 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_G1_VARIANT")) p->g1_variant = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
-    p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = BS.mode != 0;
+    p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
+    if (BS.mode == 3) {
+        if (BS.ScaFij < 1 || BS.ScaFij > BS.Fij || BS.nsx < 1 || BS.nsx > 16 || BS.nsy < 1 || BS.nsy > 16) {
+            delete p;
+            return set_err(SFFT_ERR_INVALID_ARG, "scaling basis: 1 <= ScaFij <= Fij and at most 16 factors per axis");
+        }
+        p->nsca = BS.ScaFij; p->nsx = BS.nsx; p->nsy = BS.nsy; p->spair = BS.spair;
+    }
+    p->has_idx = p->cpr || (BS.mode == 3 && p->nsca < BS.Fij);
     p->L = 2 * KerHW + 1; p->Fab = p->L * p->L;
     p->Fij = BS.Fij; p->Fpq = BS.Fpq;
     p->nkx = BS.nkx; p->nky = BS.nky; p->nbx = BS.nbx; p->nby = BS.nby;
     p->kpair = BS.kpair; p->bpair = BS.bpair;
     p->Fijab = p->Fij * p->Fab; p->NEQ = p->Fijab + p->Fpq;
-    p->NEQfs = p->cpr ? p->NEQ - (p->Fij - 1) : p->NEQ;
+    p->NEQfs = p->cpr ? p->NEQ - (p->Fij - 1) : (p->mode == 3 ? p->NEQ - (p->Fij - p->nsca) : p->NEQ);
     p->scale = 1.0 / ((double)N0 * (double)N1);
     p->Nh = N1 / 2 + 1;
     p->Nhp = (p->Nh + 3) & ~3;
@@ -340,6 +362,15 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_HIP(hipMemcpy(p->d_kby, BS.kby.data(), (size_t)BS.nky * N1 * sizeof(double), hipMemcpyHostToDevice));
         PLAN_HIP(hipMemcpy(p->d_tbx, BS.tbx.data(), (size_t)BS.nbx * N0 * sizeof(double), hipMemcpyHostToDevice));
         PLAN_HIP(hipMemcpy(p->d_tby, BS.tby.data(), (size_t)BS.nby * N1 * sizeof(double), hipMemcpyHostToDevice));
+        memset(&p->sa, 0, sizeof(p->sa));
+        if (p->mode == 3) {
+            PLAN_TRY(dev_alloc(p, &p->d_sbx, (size_t)BS.nsx * N0));
+            PLAN_TRY(dev_alloc(p, &p->d_sby, (size_t)BS.nsy * N1));
+            PLAN_HIP(hipMemcpy(p->d_sbx, BS.sbx.data(), (size_t)BS.nsx * N0 * sizeof(double), hipMemcpyHostToDevice));
+            PLAN_HIP(hipMemcpy(p->d_sby, BS.sby.data(), (size_t)BS.nsy * N1 * sizeof(double), hipMemcpyHostToDevice));
+            p->sa.nsca = p->nsca; p->sa.Fab = p->Fab; p->sa.cen = KerHW * p->L + KerHW; p->sa.sbx = p->d_sbx; p->sa.sby = p->d_sby;
+            for (int t = 0; t < p->nsca; ++t) { p->sa.sp[t] = BS.spair[2 * t]; p->sa.sq[t] = BS.spair[2 * t + 1]; }
+        }
         memset(&p->bk, 0, sizeof(p->bk));
         p->bk.npq = p->Fpq; p->bk.nq = BS.nby; p->bk.tbx = p->d_tbx; p->bk.tby = p->d_tby;
         for (int t = 0; t < p->Fpq; ++t) { p->bk.p[t] = BS.bpair[2 * t]; p->bk.q[t] = BS.bpair[2 * t + 1]; }
@@ -379,11 +410,12 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
 
     // index map of Remove_LSFStripes (SFFTSubtract.py:83-90); with tied scaling (mode 2) the kept entry ij00[0]
     // stands for the whole tied group
-    if (p->cpr) {
+    if (p->has_idx) {
         std::vector<int> idx;
         std::vector<char> forb(p->NEQ, 0);
         const int ij00_first = KerHW * p->L + KerHW;
-        for (int ij = 1; ij < p->Fij; ++ij) forb[ij00_first + ij * p->Fab] = 1;
+        // mode 3: the place-holder scaling terms ij00[ScaFij:] leave the system (BSplineSFFT.py:3732-3750)
+        for (int ij = (p->mode == 3 ? p->nsca : 1); ij < p->Fij; ++ij) forb[ij00_first + ij * p->Fab] = 1;
         for (int r = 0; r < p->NEQ; ++r) if (!forb[r]) idx.push_back(r);
         PLAN_TRY(dev_alloc(p, &p->d_idx, idx.size()));
         PLAN_HIP(hipMemcpy(p->d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -434,7 +466,11 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         const int PHo = 2 * hO + 1, PHg = 2 * hG + 1;
         int S = 1;
         const int colblocks = (p->Nh + 63) / 64;
-        const int npass_est = p->Fij * (p->Fij + 1) / 2 + p->Fij * BS.nbx + p->Fij;
+        const int nsca = p->nsca;
+        const int npass_est = p->Fij * (p->Fij + 1) / 2 + p->Fij * BS.nbx + p->Fij
+                              + nsca * p->Fij + nsca * (nsca + 1) / 2 + nsca * (BS.nbx + 1);
+        const int JP = p->Fij;                                  // plane of J
+        auto SP = [&](int s) { return p->Fij + 1 + s; };        // plane of scaling term s
         while (S < 16 && (long long)colblocks * S * npass_est < 6144 && N0 / (2 * S) >= 64) S *= 2;
         p->S = S;
         p->rows_per_chunk = (N0 + S - 1) / S;
@@ -445,14 +481,25 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             return (int)p->passes.size() - 1;
         };
         std::vector<int> omg_pass, the_pass, gam_pass((size_t)p->Fij * BS.nbx);
+        std::vector<int> sk_pass, ss_pass, st_pass, sg_pass((size_t)nsca * BS.nbx);
         for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) omg_pass.push_back(add_pass(a, b, 0, hO));
         p->n_omg = (int)omg_pass.size();
-        for (int a = 0; a < p->Fij; ++a) the_pass.push_back(add_pass(a, p->Fij, 0, hG));
+        // passes of half width w through greek_g1: Theta, dense Gamma column factors, then the scaling planes' passes
+        const int dense0 = (int)p->passes.size();
+        for (int a = 0; a < p->Fij; ++a) the_pass.push_back(add_pass(a, JP, 0, hG));
         p->n_the = p->Fij;
-        // Gamma column-factor passes: dense ones first, then those whose x-factor is the constant 1 (Xp = N0 * delta)
         p->n_gamp = 0; p->n_gam0 = 0;
         for (int a = 0; a < p->Fij; ++a) for (int e = 0; e < BS.nbx; ++e) if (!const_x[e]) { gam_pass[(size_t)a * BS.nbx + e] = add_pass(a, -1, e, hG); ++p->n_gamp; }
+        for (int sI = 0; sI < nsca; ++sI) for (int b = 0; b < p->Fij; ++b) sk_pass.push_back(add_pass(SP(sI), b, 0, hG));
+        for (int sI = 0; sI < nsca; ++sI) for (int t = sI; t < nsca; ++t) ss_pass.push_back(add_pass(SP(sI), SP(t), 0, hG));
+        for (int sI = 0; sI < nsca; ++sI) st_pass.push_back(add_pass(SP(sI), JP, 0, hG));
+        for (int sI = 0; sI < nsca; ++sI) for (int e = 0; e < BS.nbx; ++e) if (!const_x[e]) sg_pass[(size_t)sI * BS.nbx + e] = add_pass(SP(sI), -1, e, hG);
+        p->n_dense_w = (int)p->passes.size() - dense0;
+        // column factors that are the constant 1 (Xp = N0 * delta): only spectrum row 0 contributes (greek_g1_row0)
+        const int row0 = (int)p->passes.size();
         for (int a = 0; a < p->Fij; ++a) for (int e = 0; e < BS.nbx; ++e) if (const_x[e]) { gam_pass[(size_t)a * BS.nbx + e] = add_pass(a, -1, e, hG); ++p->n_gam0; }
+        for (int sI = 0; sI < nsca; ++sI) for (int e = 0; e < BS.nbx; ++e) if (const_x[e]) sg_pass[(size_t)sI * BS.nbx + e] = add_pass(SP(sI), -1, e, hG);
+        p->n_row0 = (int)p->passes.size() - row0;
         int poff = 0;
         auto add_job = [&](int pass, int yq, int h, double scale) {
             PatchJob j; j.pass = pass; j.yq = yq; j.h = h; j.patch_off = poff; j.scale = scale;
@@ -466,6 +513,18 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->n_gam = p->Fij * p->Fpq;
         p->fa.the_off = poff;
         for (int a = 0; a < p->Fij; ++a) add_job(the_pass[a], -1, hG, p->scale);                  // PreTHE = Re[SCALE*DFT] (:353-362)
+        // scaling planes (BSplineSFFT.py:3293-3565): OMG01/10 (scaling x kernel), OMG00, GAM0/PSI0, THE0
+        p->fa.sk_off = poff;
+        for (size_t k = 0; k < sk_pass.size(); ++k) add_job(sk_pass[k], -1, hG, p->scale * p->scale);
+        p->fa.ss_off = poff;
+        for (size_t k = 0; k < ss_pass.size(); ++k) add_job(ss_pass[k], -1, hG, p->scale * p->scale);
+        p->fa.sg_off = poff;
+        for (int sI = 0; sI < nsca; ++sI) for (int q = 0; q < p->Fpq; ++q)
+            add_job(sg_pass[(size_t)sI * BS.nbx + BS.bpair[2 * q]], BS.bpair[2 * q + 1], hG, p->scale);
+        p->fa.st_off = poff;
+        for (int sI = 0; sI < nsca; ++sI) add_job(st_pass[sI], -1, hG, p->scale);
+        p->fa.sv = (p->mode == 3) ? 1 : 0; p->fa.nsca = nsca;
+        p->fa.reg_coef = 0.0; p->fa.ireg = nullptr; p->fa.sst = p->fa.csst = p->fa.dsst = nullptr;
         p->n_patches = poff;
         (void)PHo; (void)PHg;
         PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
@@ -481,7 +540,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->fa.w0 = KerHW; p->fa.w1 = KerHW; p->fa.h_omg = hO; p->fa.h_gam = hG;
         p->fa.tie_first = KerHW * p->L + KerHW; p->fa.tie_stride = p->Fab; p->fa.tie_cnt = (p->mode == 2) ? p->Fij : 0;
     }
-    PLAN_TRY(dev_alloc(p, &p->d_spec, (size_t)(p->Fij + 1) * N0 * p->Nhp));
+    PLAN_TRY(dev_alloc(p, &p->d_spec, (size_t)(p->Fij + 1 + p->nsca) * N0 * p->Nhp));
     p->ld = (p->NEQfs + 1 + 3) & ~3;
     PLAN_TRY(dev_alloc(p, &p->d_A, (size_t)(p->NEQfs + 1) * p->ld));
     PLAN_TRY(dev_alloc(p, &p->d_dbuf, (size_t)2 * CB * CB));
@@ -526,13 +585,48 @@ extern "C" int sfft_plan_create(sfft_plan** out, int N0, int N1, int KerHW, int 
 
 // General separable spatial bases (B-spline SFFT, sfft/BSplineSFFT.py:2536-2607): the caller tabulates the 1-D basis
 // functions per axis (host pointers) and lists which (x-factor, y-factor) pair makes each kernel / background term.
+static int create_from_tables(sfft_plan** out, int N0, int N1, int KerHW,
+                              int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
+                              int nsx, int nsy, const double* sbx, const double* sby, int ScaFij, const int* sca_pairs,
+                              int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
+                              int scaling_mode, int device);
+
 extern "C" int sfft_plan_create_basis(sfft_plan** out, int N0, int N1, int KerHW,
                                       int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
                                       int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
                                       int scaling_mode, int device)
 {
-    if (!kbx || !kby || !tbx || !tby || !ker_pairs || !bkg_pairs) return set_err(SFFT_ERR_INVALID_ARG, "NULL basis table");
     if (scaling_mode < 0 || scaling_mode > 2) return set_err(SFFT_ERR_INVALID_ARG, "scaling_mode must be 0, 1 or 2");
+    return create_from_tables(out, N0, N1, KerHW, nkx, nky, kbx, kby, Fij, ker_pairs, 0, 0, nullptr, nullptr, 0, nullptr,
+                              nbx, nby, tbx, tby, Fpq, bkg_pairs, scaling_mode, device);
+}
+
+// Separately varying scaling (BSplineSFFT.py SCALING_MODE 'SEPARATE-VARYING', :173-201, 334-397): as
+// sfft_plan_create_basis, plus the spatial basis of the flux scaling -- ScaFij <= Fij terms
+// sbx[sca_pairs[2 s]][row] * sby[sca_pairs[2 s + 1]][col].  Unknown (ij, ab = centre) is the coefficient of scaling term
+// ij for ij < ScaFij and leaves the system for ij >= ScaFij (the reference's zero place-holders).
+extern "C" int sfft_plan_create_varscale(sfft_plan** out, int N0, int N1, int KerHW,
+                                         int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
+                                         int nsx, int nsy, const double* sbx, const double* sby, int ScaFij, const int* sca_pairs,
+                                         int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
+                                         int device)
+{
+    if (!sbx || !sby || !sca_pairs) return set_err(SFFT_ERR_INVALID_ARG, "NULL scaling basis table");
+    if (nsx < 1 || nsy < 1 || ScaFij < 1) return set_err(SFFT_ERR_INVALID_ARG, "empty scaling basis");
+    if (ScaFij > Fij) return set_err(SFFT_ERR_INVALID_ARG, "ScaFij must not exceed Fij");
+    for (int k = 0; k < ScaFij; ++k) if (sca_pairs[2 * k] < 0 || sca_pairs[2 * k] >= nsx || sca_pairs[2 * k + 1] < 0 || sca_pairs[2 * k + 1] >= nsy)
+        return set_err(SFFT_ERR_INVALID_ARG, "scaling term refers to a basis factor that does not exist");
+    return create_from_tables(out, N0, N1, KerHW, nkx, nky, kbx, kby, Fij, ker_pairs, nsx, nsy, sbx, sby, ScaFij, sca_pairs,
+                              nbx, nby, tbx, tby, Fpq, bkg_pairs, 3, device);
+}
+
+static int create_from_tables(sfft_plan** out, int N0, int N1, int KerHW,
+                              int nkx, int nky, const double* kbx, const double* kby, int Fij, const int* ker_pairs,
+                              int nsx, int nsy, const double* sbx, const double* sby, int ScaFij, const int* sca_pairs,
+                              int nbx, int nby, const double* tbx, const double* tby, int Fpq, const int* bkg_pairs,
+                              int scaling_mode, int device)
+{
+    if (!kbx || !kby || !tbx || !tby || !ker_pairs || !bkg_pairs) return set_err(SFFT_ERR_INVALID_ARG, "NULL basis table");
     if (N0 < 8 || N1 < 8) return set_err(SFFT_ERR_INVALID_ARG, "Input Image has dramatically small size!");
     if (nkx < 1 || nky < 1 || nbx < 1 || nby < 1 || Fij < 1 || Fpq < 1) return set_err(SFFT_ERR_INVALID_ARG, "empty basis");
     BasisSpec B;
@@ -540,11 +634,47 @@ extern "C" int sfft_plan_create_basis(sfft_plan** out, int N0, int N1, int KerHW
     B.kbx.assign(kbx, kbx + (size_t)nkx * N0); B.kby.assign(kby, kby + (size_t)nky * N1);
     B.tbx.assign(tbx, tbx + (size_t)nbx * N0); B.tby.assign(tby, tby + (size_t)nby * N1);
     B.kpair.assign(ker_pairs, ker_pairs + 2 * (size_t)Fij); B.bpair.assign(bkg_pairs, bkg_pairs + 2 * (size_t)Fpq);
+    if (scaling_mode == 3) {
+        B.nsx = nsx; B.nsy = nsy; B.ScaFij = ScaFij;
+        B.sbx.assign(sbx, sbx + (size_t)nsx * N0); B.sby.assign(sby, sby + (size_t)nsy * N1);
+        B.spair.assign(sca_pairs, sca_pairs + 2 * (size_t)ScaFij);
+    }
     for (int k = 0; k < Fij; ++k) if (B.kpair[2 * k] < 0 || B.kpair[2 * k] >= nkx || B.kpair[2 * k + 1] < 0 || B.kpair[2 * k + 1] >= nky)
         return set_err(SFFT_ERR_INVALID_ARG, "kernel term refers to a basis factor that does not exist");
     for (int k = 0; k < Fpq; ++k) if (B.bpair[2 * k] < 0 || B.bpair[2 * k] >= nbx || B.bpair[2 * k + 1] < 0 || B.bpair[2 * k + 1] >= nby)
         return set_err(SFFT_ERR_INVALID_ARG, "background term refers to a basis factor that does not exist");
     return plan_create_impl(out, N0, N1, KerHW, B, -1, -1, device);
+}
+
+// Kernel regularisation (BSplineSFFT.py REGULARIZE_KERNEL, :2007-2168, 3570-3700):
+//     LHMAT[(k, c), (k8, c8)] += lambda * SCALE^2 * S[k][k8] * ireg[c][c8]
+// for every later solve on this plan.  ireg [Fab][Fab] is the reference's iREGMAT (integers, passed as doubles), sst
+// [Fij][Fij] its SSTMAT; plans with separately varying scaling also take CSSTMAT (kernel x scaling) and DSSTMAT
+// (scaling x scaling), used when one / both of c, c8 are the kernel centre (:2121-2166).  HOST pointers, copied.
+// lambda == 0 (or ireg == NULL) switches regularisation off.
+extern "C" int sfft_plan_set_regularization(sfft_plan* p, double lambda, const double* ireg, const double* sst,
+                                            const double* csst, const double* dsst)
+{
+    if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan");
+    HIPCHK(hipSetDevice(p->dev));
+    if (lambda == 0.0 || !ireg) { p->fa.reg_coef = 0.0; return SFFT_OK; }
+    if (!sst) return set_err(SFFT_ERR_INVALID_ARG, "NULL SSTMAT");
+    if (p->mode == 3 && (!csst || !dsst)) return set_err(SFFT_ERR_INVALID_ARG, "separately varying scaling needs CSSTMAT and DSSTMAT");
+    const size_t nab = (size_t)p->Fab * p->Fab, nij = (size_t)p->Fij * p->Fij;
+    int rc;
+    if (!p->d_ireg) {
+        if ((rc = dev_alloc(p, &p->d_ireg, nab))) return rc;
+        if ((rc = dev_alloc(p, &p->d_sst, nij))) return rc;
+        if ((rc = dev_alloc(p, &p->d_csst, nij))) return rc;
+        if ((rc = dev_alloc(p, &p->d_dsst, nij))) return rc;
+    }
+    HIPCHK(hipMemcpy(p->d_ireg, ireg, nab * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_sst, sst, nij * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_csst, p->mode == 3 ? csst : sst, nij * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_dsst, p->mode == 3 ? dsst : sst, nij * sizeof(double), hipMemcpyHostToDevice));
+    p->fa.ireg = p->d_ireg; p->fa.sst = p->d_sst; p->fa.csst = p->d_csst; p->fa.dsst = p->d_dsst;
+    p->fa.reg_coef = lambda * p->scale * p->scale;
+    return SFFT_OK;
 }
 
 static void free_axis(AxisHost& a)
@@ -564,7 +694,8 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     hipSetDevice(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol};
+                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -590,7 +721,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_FPQ: *v = p->Fpq; break;
         case SFFT_Q_NEQ: *v = p->NEQ; break;
         case SFFT_Q_FIJAB: *v = p->Fijab; break;
-        case SFFT_Q_NEQ_FSFREE: *v = p->NEQ - (p->Fij - 1); break;
+        case SFFT_Q_NEQ_FSFREE: *v = (p->mode == 3) ? p->NEQfs : p->NEQ - (p->Fij - 1); break;
         case SFFT_Q_FOMG: *v = p->Fij * p->Fij; break;
         case SFFT_Q_FGAM: case SFFT_Q_FPSI: *v = p->Fij * p->Fpq; break;
         case SFFT_Q_FTHE: *v = p->Fij; break;
@@ -598,7 +729,8 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_FDEL: *v = p->Fpq; break;
         case SFFT_Q_WORKSPACE_BYTES: *v = (long long)p->ws_bytes; break;
         case SFFT_Q_LAST_SOLVER: *v = p->last_solver; break;
-        case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_the + p->n_gamp); break;
+        case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_dense_w); break;
+        case SFFT_Q_SCAFIJ: *v = p->nsca; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
     return SFFT_OK;
@@ -708,9 +840,10 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
 }
 
 // forward spectra of the Fij kernel-basis planes of image d_I (and, when d_J is given, of d_J itself as plane Fij)
-static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s)
+// and, with_sca, of the scaling planes (planes Fij + 1 ...)
+static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca = false)
 {
-    const int total = p->Fij + (d_J ? 1 : 0);
+    const int total = p->Fij + (d_J ? 1 : 0) + ((with_sca && d_J) ? p->nsca : 0);
     const size_t plane_sz = (size_t)p->N0 * p->Nhp;
     for (int k0 = 0; k0 < total; k0 += SFFT_MAX_PLANES) {
         const int n = std::min(SFFT_MAX_PLANES, total - k0);
@@ -722,7 +855,13 @@ static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d
                 ra.src[u] = d_I;
                 ra.wx[u] = p->d_kbx + (size_t)p->kpair[2 * k] * p->N0;
                 ra.wy[u] = p->d_kby + (size_t)p->kpair[2 * k + 1] * p->N1;
-            } else ra.src[u] = d_J;
+            } else if (k == p->Fij) ra.src[u] = d_J;
+            else {
+                const int sI = k - p->Fij - 1;
+                ra.src[u] = d_I;
+                ra.wx[u] = p->d_sbx + (size_t)p->spair[2 * sI] * p->N0;
+                ra.wy[u] = p->d_sby + (size_t)p->spair[2 * sI + 1] * p->N1;
+            }
         }
         int rc = forward_planes(p, ra, n, dst + (size_t)k0 * plane_sz, s);
         if (rc) return rc;
@@ -829,7 +968,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     int rc;
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
-        if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s))) return rc;
+        if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true))) return rc;
         if (p->nby <= 4) hipLaunchKernelGGL(row_moments<4>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
@@ -841,10 +980,10 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
-        if ((rc = greek_g1_group(p, p->n_omg, p->n_the + p->n_gamp, p->w, s))) return rc;
-        if (p->n_gam0 > 0) {
-            hipLaunchKernelGGL(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_gam0), dim3(256), 0, s, p->d_spec, p->d_passes,
-                               p->n_omg + p->n_the + p->n_gamp, p->d_gp, p->N0, p->Nh, p->Nhp, p->S);
+        if ((rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
+        if (p->n_row0 > 0) {
+            hipLaunchKernelGGL(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_row0), dim3(256), 0, s, p->d_spec, p->d_passes,
+                               p->n_omg + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->S);
             LAUNCH_CHECK();
         }
     }
@@ -852,7 +991,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
         StageTimer t(p, SFFT_ST_GREEK_G2, s);
         hipLaunchKernelGGL(greek_g2, dim3(4 * p->w + 1, p->n_omg), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
                            p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
-        hipLaunchKernelGGL(greek_g2, dim3(2 * p->w + 1, p->n_gam + p->n_the), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs,
+        hipLaunchKernelGGL(greek_g2, dim3(2 * p->w + 1, (int)p->jobs.size() - p->n_omg), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs,
                            p->n_omg, p->d_patches, p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
         LAUNCH_CHECK();
     }
@@ -898,13 +1037,13 @@ static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t 
 }
 
 // Construct_FDIFF + inverse transform + DIFF epilogue from the spectra FI; FD is a scratch plane
-static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_J, const double* d_solution, double* d_diff,
-                        hipStream_t s)
+static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_I, const double* d_J, const double* d_solution,
+                        double* d_diff, hipStream_t s)
 {
     {
         StageTimer t(p, SFFT_ST_CONSTRUCT, s);
         hipLaunchKernelGGL(kernel_ctab, dim3((p->Nh + 255) / 256, p->Fij * p->L), dim3(256), 0, s, d_solution, p->d_ctab, p->d_soff,
-                           p->Fij, p->L, p->L, p->w, p->Nh, p->Nhp, p->N1, p->ax1.root);
+                           p->Fij, p->L, p->L, p->w, p->Nh, p->Nhp, p->N1, p->ax1.root, p->mode == 3 ? 1 : 0);
         hipLaunchKernelGGL(construct_fd, dim3((p->Nh + 255) / 256, (p->N0 + CRL - 1) / CRL), dim3(256), 0, s, FI, FD, p->d_ctab,
                            p->d_soff, p->ax0.root, p->N0, p->Nh, p->Nhp, p->Fij, p->L, p->w, p->scale);
         LAUNCH_CHECK();
@@ -930,6 +1069,9 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         else
             hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
                                d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, axis_dev(p->ax1));
+        if (p->mode == 3)
+            hipLaunchKernelGGL(scaling_term, dim3((p->N1 + 255) / 256, p->N0), dim3(256), 0, s, d_I, d_solution, p->sa, d_diff,
+                               p->N0, p->N1, p->scale);
         LAUNCH_CHECK();
     }
     return SFFT_OK;
@@ -943,7 +1085,7 @@ extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, co
     HIPCHK(hipSetDevice(p->dev));
     int rc;
     if ((rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
-    return apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_J, d_solution, d_diff, s);
+    return apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s);
 }
 
 // GSS: the forward transforms of the full pair do not depend on the solution, and the dense solve leaves most
@@ -969,7 +1111,7 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
         // the caller passed the full image as its own mask ("'same' means it is identical with I",
         // SFFTSubtract.py:849): the spectra of the solve pass are the spectra of the apply pass
         if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
-        if ((rc = apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_J, d_solution, d_diff, s))) return rc;
+        if ((rc = apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
         HIPCHK(hipStreamSynchronize(s));
         return SFFT_OK;
     }
@@ -978,7 +1120,7 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
     p->overlap_I = nullptr;
     if (rc) { hipStreamSynchronize(p->s2); return rc; }
     HIPCHK(hipStreamWaitEvent(s, p->ev_pre, 0));
-    if ((rc = apply_finish(p, p->d_spec2, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_J, d_solution, d_diff, s))) return rc;
+    if ((rc = apply_finish(p, p->d_spec2, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;
 }

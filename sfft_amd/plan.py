@@ -11,7 +11,9 @@ class Plan:
     def __init__(self, N0, N1, KerHW, DK=None, DB=None, ConstPhotRatio=True, device=0, basis=None):
         """Polynomial plan (DK, DB, ConstPhotRatio) or, with `basis`, a plan over tabulated separable bases:
         basis = dict(kbx=[nkx,N0], kby=[nky,N1], ker_pairs=[Fij,2], tbx=[nbx,N0], tby=[nby,N1], bkg_pairs=[Fpq,2],
-                     scaling_mode=0|1|2)   (see sfft_plan_create_basis in include/sfft_amd.h)."""
+                     scaling_mode=0|1|2)   (see sfft_plan_create_basis in include/sfft_amd.h);
+        with the extra keys sbx=[nsx,N0], sby=[nsy,N1], sca_pairs=[ScaFij,2] the flux scaling varies on its own basis
+        (sfft_plan_create_varscale; scaling_mode is ignored)."""
         self._h = ctypes.c_void_p()
         self.device = int(device)
         if basis is None:
@@ -26,11 +28,20 @@ class Plan:
             assert kbx.shape[1] == N0 and tbx.shape[1] == N0 and kby.shape[1] == N1 and tby.shape[1] == N1
             assert kp.ndim == 2 and kp.shape[1] == 2 and bp.ndim == 2 and bp.shape[1] == 2
             self._keep = (kbx, kby, tbx, tby, kp, bp)
-            rc = _lib.lib().sfft_plan_create_basis(
-                ctypes.byref(self._h), int(N0), int(N1), int(KerHW),
-                kbx.shape[0], kby.shape[0], kbx.ctypes.data, kby.ctypes.data, kp.shape[0], kp.ctypes.data,
-                tbx.shape[0], tby.shape[0], tbx.ctypes.data, tby.ctypes.data, bp.shape[0], bp.ctypes.data,
-                int(basis.get("scaling_mode", 0)), int(device))
+            if "sca_pairs" in basis:
+                sbx, sby, sp = f8(basis["sbx"]), f8(basis["sby"]), i4(basis["sca_pairs"])
+                assert sbx.shape[1] == N0 and sby.shape[1] == N1 and sp.ndim == 2 and sp.shape[1] == 2
+                rc = _lib.lib().sfft_plan_create_varscale(
+                    ctypes.byref(self._h), int(N0), int(N1), int(KerHW),
+                    kbx.shape[0], kby.shape[0], kbx.ctypes.data, kby.ctypes.data, kp.shape[0], kp.ctypes.data,
+                    sbx.shape[0], sby.shape[0], sbx.ctypes.data, sby.ctypes.data, sp.shape[0], sp.ctypes.data,
+                    tbx.shape[0], tby.shape[0], tbx.ctypes.data, tby.ctypes.data, bp.shape[0], bp.ctypes.data, int(device))
+            else:
+                rc = _lib.lib().sfft_plan_create_basis(
+                    ctypes.byref(self._h), int(N0), int(N1), int(KerHW),
+                    kbx.shape[0], kby.shape[0], kbx.ctypes.data, kby.ctypes.data, kp.shape[0], kp.ctypes.data,
+                    tbx.shape[0], tby.shape[0], tbx.ctypes.data, tby.ctypes.data, bp.shape[0], bp.ctypes.data,
+                    int(basis.get("scaling_mode", 0)), int(device))
         _lib.check(rc)
         self.N0, self.N1 = int(N0), int(N1)
         self.NEQ = self.query("NEQ")
@@ -94,6 +105,14 @@ class Plan:
         _lib.check(_lib.lib().sfft_dbg_forward_spectrum(self._h, I.data_ptr(), int(i), int(j), out.data_ptr(),
                                                         self._stream_ptr(self._dev())))
         return out
+
+    def set_regularization(self, lam, ireg=None, sst=None, csst=None, dsst=None):
+        """LHMAT += lam * SCALE^2 * S (x) ireg on every later solve (sfft_plan_set_regularization); lam = 0 switches it off."""
+        import numpy as np
+        f8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        ireg, sst, csst, dsst = f8(ireg), f8(sst), f8(csst), f8(dsst)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        _lib.check(_lib.lib().sfft_plan_set_regularization(self._h, float(lam), ptr(ireg), ptr(sst), ptr(csst), ptr(dsst)))
 
     def set_timing(self, enable=True):
         _lib.check(_lib.lib().sfft_set_timing(self._h, 1 if enable else 0))

@@ -455,10 +455,155 @@ def test_bspline_packet_fits_and_unsupported_modes(dev, tmp_path):
     assert rel_rms_err(diff, g["DIFF"]) <= 1e-6
     h = minifits.header_dict(minifits.getdata(fdiff)[1])
     assert h["KSPTYPE"] == "B-Spline" and h["NKIKX"] == 2 and abs(h["KIKX1"] - 44.5) < 1e-12 and h["SEPSCA"] == "True"
-    with pytest.raises(NotImplementedError, match="SEPARATE-VARYING"):
-        BSSC.SSC(64, 48, 2, KerSpType="B-Spline", KerSpDegree=2, SEPARATE_SCALING=True, ScaSpDegree=1, VERBOSE_LEVEL=0)
-    with pytest.raises(NotImplementedError, match="REGULARIZE_KERNEL"):
+    with pytest.raises(AssertionError):     # polynomial scaling of the kernel's own degree "reduces to ENTANGLED" (BSplineSFFT.py:70-71)
+        BSSC.SSC(64, 48, 2, KerSpType="Polynomial", KerSpDegree=1, SEPARATE_SCALING=True, ScaSpDegree=1, VERBOSE_LEVEL=0)
+    with pytest.raises(AssertionError):     # REGULARIZE_KERNEL needs XY_REGULARIZE (:88-90)
         BSSC.SSC(64, 48, 2, KerSpType="B-Spline", KerSpDegree=2, REGULARIZE_KERNEL=True, VERBOSE_LEVEL=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# (e2) separately varying scaling + kernel regularisation (BSplineSFFT.py SCALING_MODE 'SEPARATE-VARYING', REGULARIZE_KERNEL).
+# The reference has no CPU code for these ("parity unpinned"): the comparison is oracle/bspline_sv_oracle.py, itself pinned
+# by tests/test_oracle_sv.py (brute-force normal equations, reduction to the golden-pinned ENTANGLED system).
+# ------------------------------------------------------------------------------------------------
+SV_CASES = [
+    dict(name="poly2_sca1", N0=96, N1=80, w=2, ker=("Polynomial", 2, [], []), sca=("Polynomial", 1, [], []), bkg=("Polynomial", 2, [], [])),
+    dict(name="bspl2_scabspl1", N0=128, N1=96, w=3, ker=("B-Spline", 2, [64.5], [48.5]), sca=("B-Spline", 1, [], []),
+         bkg=("Polynomial", 1, [], [])),
+    dict(name="bspl1_scapoly2_full", N0=100, N1=72, w=2, ker=("B-Spline", 1, [50.5], []), sca=("Polynomial", 2, [], []),
+         bkg=("B-Spline", 1, [], [36.5])),      # ScaFij == Fij == 6: nothing leaves the system
+]
+
+
+def _sv_setup(c, dev, reg=None):
+    from oracle import bspline_oracle as BO, bspline_sv_oracle as SV
+    from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1, w = c["N0"], c["N1"], c["w"]
+    ker, sca, bkg = c["ker"], c["sca"], c["bkg"]
+    pair = make_pair(N0, N1, seed=31, mask=True, density=400.0)
+    kw = dict(KerSpType=ker[0], KerSpDegree=ker[1], KerIntKnotX=ker[2], KerIntKnotY=ker[3],
+              SEPARATE_SCALING=True, ScaSpType=sca[0], ScaSpDegree=sca[1], ScaIntKnotX=sca[2], ScaIntKnotY=sca[3],
+              BkgSpType=bkg[0], BkgSpDegree=bkg[1], BkgIntKnotX=bkg[2], BkgIntKnotY=bkg[3])
+    if reg is not None:
+        kw.update(REGULARIZE_KERNEL=True, **reg)
+    cfg = BSSC.SSC(NX=N0, NY=N1, KerHW=w, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index, MINIMIZE_GPU_MEMORY_USAGE=True, **kw)
+    basis = BO.make_basis(N0, N1, ker[0], ker[1], ker[2], ker[3], bkg[0], bkg[1], bkg[2], bkg[3])
+    scab = SV.make_scaling_basis(N0, N1, len(basis["ker_pairs"]), sca[0], sca[1], sca[2], sca[3])
+    p = SV.SSC(N0, N1, w, basis, scab, "SEPARATE-VARYING")
+    return pair, cfg, basis, scab, p
+
+
+@pytest.mark.parametrize("c", SV_CASES, ids=[c["name"] for c in SV_CASES])
+def test_varying_scaling_matches_oracle(dev, c):
+    from oracle import bspline_sv_oracle as SV
+    from sfft_amd.BSplineSFFT import GeneralSFFTSubtract as BGSS, ElementalSFFTSubtract as BESS
+    pair, cfg, basis, scab, p = _sv_setup(c, dev)
+    P = cfg[0]
+    assert (P["NEQ"], P["NEQt"], P["ScaFij"], P["SCALING_MODE"]) == (p["NEQ"], p["NEQt"], p["ScaFij"], "SEPARATE-VARYING")
+    plan = cfg[1]["plan"]
+    assert plan.query("ScaFij") == p["ScaFij"]
+    plan.solve(_to(dev, pair["mREF"]), _to(dev, pair["mSCI"]))
+    LH, rhs = plan.get_system()
+    LH_o, rhs_o = SV.establish_system(pair["mREF"], pair["mSCI"], p, basis, scab, workers=8)
+    assert np.max(np.abs(LH.cpu().numpy() - LH_o)) <= 1e-11 * np.max(np.abs(LH_o))
+    assert np.max(np.abs(rhs.cpu().numpy() - rhs_o)) <= 1e-11 * np.max(np.abs(rhs_o))
+    # apply-only with the oracle's solution, then end to end
+    sol_o = SV.solve_system(LH_o, rhs_o, p)
+    D_o = SV.subtract(pair["REF"], pair["SCI"], sol_o, p, basis, scab, workers=8)
+    D = BESS.ESS(pair["REF"], pair["SCI"], cfg, SFFTSolution=sol_o, Subtract=True, VERBOSE_LEVEL=0)[1]
+    assert rms(D - D_o) <= 1e-10 * rms(pair["SCI"])
+    sol, D2, _ = BGSS.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)
+    assert rel_rms_err(D2, D_o) <= 1e-6
+    L = 2 * c["w"] + 1
+    ij00 = np.arange(c["w"] * L + c["w"], P["Fijab"], L * L)
+    assert np.all(sol[ij00[p["ScaFij"]:]] == 0.0)          # place-holder scaling terms come back as exact zeros
+    assert plan.query("LAST_SOLVER") == 1
+
+
+@pytest.mark.parametrize("mode", ["ENTANGLED", "SEPARATE-CONSTANT", "SEPARATE-VARYING"])
+def test_kernel_regularisation_matches_oracle(dev, mode):
+    from oracle import bspline_oracle as BO, bspline_sv_oracle as SV
+    from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC, GeneralSFFTSubtract as BGSS
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1, w = 96, 80, 3
+    pair = make_pair(N0, N1, seed=8, mask=True, density=400.0)
+    ker = ("B-Spline", 2, [48.5], [])
+    XY = np.array([[x, y] for x in (12.0, 48.0, 84.0) for y in (10.0, 40.0, 70.0)])
+    W = np.linspace(1.0, 3.0, XY.shape[0])
+    LAM = 200.0     # SCALE^2 makes REGMAT tiny: this lambda puts the penalty at the size of the kernel block of LHMAT
+    kw = dict(KerSpType=ker[0], KerSpDegree=ker[1], KerIntKnotX=ker[2], KerIntKnotY=ker[3], BkgSpType="Polynomial", BkgSpDegree=1,
+              REGULARIZE_KERNEL=True, IGNORE_LAPLACIAN_KERCENT=True, XY_REGULARIZE=XY, WEIGHT_REGULARIZE=W, LAMBDA_REGULARIZE=LAM)
+    if mode == "ENTANGLED":
+        kw.update(SEPARATE_SCALING=False)
+    elif mode == "SEPARATE-CONSTANT":
+        kw.update(SEPARATE_SCALING=True, ScaSpDegree=0)
+    else:
+        kw.update(SEPARATE_SCALING=True, ScaSpType="Polynomial", ScaSpDegree=1, MINIMIZE_GPU_MEMORY_USAGE=True)
+    cfg = BSSC.SSC(NX=N0, NY=N1, KerHW=w, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index, **kw)
+    plan = cfg[1]["plan"]
+    basis = BO.make_basis(N0, N1, ker[0], ker[1], ker[2], ker[3], "Polynomial", 1, [], [])
+    Fij = len(basis["ker_pairs"])
+    scab = SV.make_scaling_basis(N0, N1, Fij, "Polynomial", 1) if mode == "SEPARATE-VARYING" else None
+    p = SV.SSC(N0, N1, w, basis, scab, mode)
+    kerspec = dict(KerSpType=ker[0], DK=ker[1], KerIntKnotX=ker[2], KerIntKnotY=ker[3])
+    SST, CSST, DSST = SV.spatial_gram(p, kerspec, scab, XY, W)
+    REG = SV.regularization_matrix(p, SV.laplacian_ireg(w, w, True), SST, CSST, DSST)
+    if mode == "SEPARATE-VARYING":
+        LH_o, rhs_o = SV.establish_system(pair["mREF"], pair["mSCI"], p, basis, scab, workers=8)
+    else:
+        LH_o, rhs_o = BO.establish_system(pair["mREF"], pair["mSCI"], BO.SSC(N0, N1, w, basis, mode != "ENTANGLED"), basis, workers=8)
+    LH_o = LH_o + LAM * REG
+    sol, D, _ = BGSS.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)
+    LH, rhs = plan.get_system()
+    assert np.max(np.abs(LH.cpu().numpy() - LH_o)) <= 1e-11 * np.max(np.abs(LH_o))
+    assert np.max(np.abs(rhs.cpu().numpy() - rhs_o)) <= 1e-11 * np.max(np.abs(rhs_o))
+    nk = p["Fijab"]             # the penalty lives in the kernel block, whose entries are far smaller than the background block's
+    assert np.max(np.abs(LH.cpu().numpy()[:nk, :nk] - LH_o[:nk, :nk])) <= 1e-11 * np.max(np.abs(LH_o[:nk, :nk]))
+    assert np.max(np.abs(LAM * REG)) > 1e-2 * np.max(np.abs(LH_o[:nk, :nk]))
+    sol_o = SV.solve_system(LH_o, rhs_o, p)
+    if mode == "SEPARATE-VARYING":
+        D_o = SV.subtract(pair["REF"], pair["SCI"], sol_o, p, basis, scab, workers=8)
+    else:
+        D_o = BO.subtract(pair["REF"], pair["SCI"], sol_o, BO.SSC(N0, N1, w, basis, mode != "ENTANGLED"), basis, workers=8)
+    assert rel_rms_err(D, D_o) <= 1e-6
+    # switching the penalty off on the same (cached) plan restores the plain system
+    kw.update(REGULARIZE_KERNEL=False)
+    cfg2 = BSSC.SSC(NX=N0, NY=N1, KerHW=w, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index, **kw)
+    assert cfg2[1]["plan"] is plan
+    plan.solve(_to(dev, pair["mREF"]), _to(dev, pair["mSCI"]))
+    LH2, _ = plan.get_system()
+    assert np.max(np.abs(LH2.cpu().numpy()[:nk, :nk] - (LH_o - LAM * REG)[:nk, :nk])) <= 1e-11 * np.max(np.abs(LH_o[:nk, :nk]))
+
+
+def test_varying_scaling_large_shape_properties(dev):
+    """2048 x 2048, KerHW 6, B-spline kernel (Fij = 9) with polynomial scaling of degree 1: too big for the oracle;
+    the solution must satisfy its own (selected) linear system and DIFF must be the model residual of a second apply."""
+    from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC
+    from sfft_amd.utils.synthetic import make_pair
+    N0 = N1 = 2048
+    w = 6
+    pair = make_pair(N0, N1, seed=12, mask=False)
+    cfg = BSSC.SSC(NX=N0, NY=N1, KerHW=w, KerSpType="B-Spline", KerSpDegree=2, SEPARATE_SCALING=True, ScaSpType="Polynomial",
+                   ScaSpDegree=1, BkgSpType="Polynomial", BkgSpDegree=2, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+    plan = cfg[1]["plan"]
+    I, J = _to(dev, pair["REF"]), _to(dev, pair["SCI"])
+    sol, diff = plan.subtract(I, J, I, J)
+    LH, rhs = plan.get_system()
+    P = cfg[0]
+    L = 2 * w + 1
+    ij00 = np.arange(w * L + w, P["Fijab"], L * L)
+    keep = np.setdiff1d(np.arange(P["NEQ"]), ij00[P["ScaFij"]:])
+    it = torch.from_numpy(keep).to(dev)
+    r = LH[it][:, it] @ sol[it] - rhs[it]
+    assert float(r.abs().max()) <= 1e-6 * float(rhs.abs().max())
+    assert float(sol[torch.from_numpy(ij00[P["ScaFij"]:]).to(dev)].abs().max()) == 0.0
+    d = diff.cpu().numpy()
+    assert np.isfinite(d).all() and rms(d) < 2.0 * rms(pair["SCI"] - pair["REF"])
+    # scaling at the image centre ~ the synthetic photometric ratio
+    s = sol.cpu().numpy()[ij00[:3]] / (float(N0) * float(N1))
+    assert abs(s[0] + 0.5 * s[1] + 0.5 * s[2] - 1.3) < 0.06      # REF_ij of degree 1: (0,0), (0,1), (1,0)
+    del cfg, plan
 
 
 # ------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ from sfft_amd.utils.synthetic import make_pair
 
 
 def _case(N0=24, N1=20, w=1, ker=('Polynomial', 2, (), ()), sca=('Polynomial', 1, (), ()), bkg=('Polynomial', 1, (), ()), seed=3):
-    pair = make_pair(N0, N1, seed=seed, density=1 / 60.0)
+    pair = make_pair(N0, N1, seed=seed, density=60.0)
     I, J = pair['REF'], pair['SCI']
     basis = bo.make_basis(N0, N1, ker[0], ker[1], ker[2], ker[3], bkg[0], bkg[1], bkg[2], bkg[3])
     Fij = len(basis['ker_pairs'])
@@ -45,7 +45,7 @@ def test_system_is_the_normal_equations_of_the_model(kw):
 
 def test_reduces_to_entangled_when_scaling_basis_is_kernel_basis():
     N0, N1, w = 32, 24, 2
-    pair = make_pair(N0, N1, seed=5, density=1 / 60.0)
+    pair = make_pair(N0, N1, seed=5, density=60.0)
     I, J = pair['REF'], pair['SCI']
     basis = bo.make_basis(N0, N1, 'B-Spline', 2, (16.5,), (), 'Polynomial', 1, (), ())
     Fij = len(basis['ker_pairs'])
