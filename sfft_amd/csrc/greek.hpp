@@ -10,7 +10,6 @@
 // r and -r share their four real products.  B is a stored plane (Omega, Theta) or, for Gamma, the column
 // factor Xp[l] = DFT(cx^p)[l] of the rank-1 spectrum FT_pq = SCALE * Xp (x) Yq -- the row factor Yq[m] does not
 // depend on l and is applied in stage 2, so one pass serves every q.
-// One wave per 64 columns; RS waves of a workgroup split the lags; rows are loaded U at a time ahead of use.
 // ------------------------------------------------------------------------------------------------
 struct G1Pass {
     int a_plane;      // plane index into spec
@@ -28,16 +27,45 @@ struct PatchJob {
     double scale;
 };
 
-template <int HBW, int RS>
-__global__ void __launch_bounds__(64 * RS) greek_g1(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
-                                                    cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
-                                                    int r_base, const cplx* __restrict__ W0tab, int HM, const cplx* __restrict__ Xp)
+// One wave per workgroup owns 64 columns x one row chunk x ALL lags of the launch (HBW of them, 4 real FMAs per lag and
+// row), so no two waves load the same element.  Every wave issues the loads of U rows before it consumes any of them
+// (the first version of this kernel waited on two loads per row and was bound by ~1 us of loaded memory latency per
+// iteration, not by bandwidth); the body is branch free -- lags beyond h are computed on padded twiddle columns and
+// simply not stored -- and the HBW twiddles of a row are one scalar load.
+template <int HBW>
+__device__ __forceinline__ void g1_row(const cplx av, const cplx bv, const cplx* __restrict__ trow, double (&S1)[HBW],
+                                       double (&S2)[HBW], double (&S3)[HBW], double (&S4)[HBW], double& g0x, double& g0y)
 {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = blockIdx.x * 64 + lane;
-    const int chunk = blockIdx.y;
-    const G1Pass pr = passes[pass0 + blockIdx.z];
+    const cplx H = cmulc(av, bv);
+    g0x += H.x; g0y += H.y;
+#pragma unroll
+    for (int t = 0; t < HBW; ++t) {
+        const cplx w = trow[t];
+        S1[t] = fma(H.x, w.x, S1[t]);
+        S2[t] = fma(H.y, w.y, S2[t]);
+        S3[t] = fma(H.x, w.y, S3[t]);
+        S4[t] = fma(H.y, w.x, S4[t]);
+    }
+}
+
+template <int HBW, int U>
+__global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+                                               cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
+                                               int r_base, const cplx* __restrict__ W0tab, int HM, const cplx* __restrict__ Xp,
+                                               int ncb, int S, int npass)
+{
+    const int lane = threadIdx.x;
+    // 1-D grid over (tile = column block x row chunk, pass).  Workgroup ids go round-robin over the 8 XCDs, so XCD x is
+    // given the contiguous range [x * per, (x + 1) * per) of the logical order "pass fastest": all passes of one tile run
+    // on one XCD at about the same time and share that tile's slice of every plane through its L2.
+    const int total = ncb * S * npass;
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int tile = logical / npass;
+    const int chunk = tile / ncb;
+    const int m = (tile - chunk * ncb) * 64 + lane;
+    const G1Pass pr = passes[pass0 + (logical - tile * npass)];
     const int h = pr.h;
     const int PH = 2 * h + 1;
     const int lb = chunk * rows_per_chunk;
@@ -47,42 +75,44 @@ __global__ void __launch_bounds__(64 * RS) greek_g1(const cplx* __restrict__ spe
     const size_t plane_sz = (size_t)N0 * Nhp;
     const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz + mc;
     const bool colfac = pr.b_plane < 0;
-    const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz + mc;
-    const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
-    const int rfirst = r_base + 1 + wv * HBW;       // this wave's lags: rfirst .. rfirst + HBW - 1 (wave-uniform)
-    int nact = h - (rfirst - 1);
-    if (nact > HBW) nact = HBW;
-    if (nact < 0) nact = 0;
+    const int rfirst = r_base + 1;                  // lags rfirst .. rfirst + HBW - 1 (those beyond h are not stored)
     double S1[HBW], S2[HBW], S3[HBW], S4[HBW];
 #pragma unroll
     for (int t = 0; t < HBW; ++t) { S1[t] = S2[t] = S3[t] = S4[t] = 0.0; }
     double g0x = 0.0, g0y = 0.0;
-    const bool do_g0 = (r_base == 0 && wv == 0);
-    // W0tab[l][r] = W0^(l r), r = 0..HM-1: one contiguous, wave-uniform row of twiddles per image row (scalar loads)
+    // W0tab[l][r] = W0^(l r): one contiguous, wave-uniform row of twiddles per image row
     const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + rfirst;
-    for (int l = lb; l < le; ++l, trow += HM) {
-        const cplx av = A[(size_t)l * Nhp];
-        const cplx bv = colfac ? xp[l] : B[(size_t)l * Nhp];
-        const cplx H = cmulc(av, bv);
-        if (do_g0) { g0x += H.x; g0y += H.y; }
+    int l = lb;
+    if (!colfac) {
+        const cplx* __restrict__ B = spec + (size_t)pr.b_plane * plane_sz + mc;
+        for (; l + U <= le; l += U, trow += (size_t)U * HM) {
+            cplx av[U], bv[U];
 #pragma unroll
-        for (int t = 0; t < HBW; ++t) {
-            if (t < nact) {
-                const cplx w = trow[t];
-                S1[t] = fma(H.x, w.x, S1[t]);
-                S2[t] = fma(H.y, w.y, S2[t]);
-                S3[t] = fma(H.x, w.y, S3[t]);
-                S4[t] = fma(H.y, w.x, S4[t]);
-            }
+            for (int u = 0; u < U; ++u) av[u] = A[(size_t)(l + u) * Nhp];
+#pragma unroll
+            for (int u = 0; u < U; ++u) bv[u] = B[(size_t)(l + u) * Nhp];
+#pragma unroll
+            for (int u = 0; u < U; ++u) g1_row<HBW>(av[u], bv[u], trow + (size_t)u * HM, S1, S2, S3, S4, g0x, g0y);
         }
+        for (; l < le; ++l, trow += HM) g1_row<HBW>(A[(size_t)l * Nhp], B[(size_t)l * Nhp], trow, S1, S2, S3, S4, g0x, g0y);
+    } else {
+        const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;     // wave-uniform column factor
+        for (; l + U <= le; l += U, trow += (size_t)U * HM) {
+            cplx av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) av[u] = A[(size_t)(l + u) * Nhp];
+#pragma unroll
+            for (int u = 0; u < U; ++u) g1_row<HBW>(av[u], xp[l + u], trow + (size_t)u * HM, S1, S2, S3, S4, g0x, g0y);
+        }
+        for (; l < le; ++l, trow += HM) g1_row<HBW>(A[(size_t)l * Nhp], xp[l], trow, S1, S2, S3, S4, g0x, g0y);
     }
     if (!active) return;
     cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp + m;
-    if (do_g0) g[(size_t)h * Nhp] = make_double2(g0x, g0y);
+    if (r_base == 0) g[(size_t)h * Nhp] = make_double2(g0x, g0y);
 #pragma unroll
     for (int t = 0; t < HBW; ++t) {
-        if (t < nact) {
-            const int r = rfirst + t;
+        const int r = rfirst + t;
+        if (r <= h) {
             g[(size_t)(h + r) * Nhp] = make_double2(S1[t] - S2[t], S3[t] + S4[t]);
             g[(size_t)(h - r) * Nhp] = make_double2(S1[t] + S2[t], S4[t] - S3[t]);
         }

@@ -129,7 +129,6 @@ struct sfft_plan {
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
-    int g1_variant = 2;                 // tuning knob (env SFFT_G1_VARIANT): how the lags of a Greek pass are split over waves
     int timing = 0;
     hipEvent_t ev[SFFT_ST_COUNT][2];
     bool ev_valid[SFFT_ST_COUNT];
@@ -296,6 +295,8 @@ static void table_axis_dft(const double* v, int N, int nout, std::vector<cplx>& 
     }
 }
 
+static int g1_padded(int h);
+
 static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const BasisSpec& BS, int DK, int DB, int device)
 {
     if (!out) return set_err(SFFT_ERR_INVALID_ARG, "plan pointer is NULL");
@@ -307,7 +308,6 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     HIPCHK(hipSetDevice(device));
     sfft_plan* p = new sfft_plan();
     p->dev = device;
-    if (const char* ev = getenv("SFFT_G1_VARIANT")) p->g1_variant = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -532,7 +532,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_jobs, p->jobs.size()));
         PLAN_HIP(hipMemcpy(p->d_jobs, p->jobs.data(), p->jobs.size() * sizeof(PatchJob), hipMemcpyHostToDevice));
         PLAN_TRY(dev_alloc(p, &p->d_gp, (size_t)goff));
-        p->hm = hO + 1;
+        p->hm = std::max(g1_padded(hO), g1_padded(hG)) + 1;     // padded: a launch may compute (and drop) lags beyond h
         PLAN_TRY(dev_alloc(p, &p->d_w0tab, (size_t)N0 * p->hm));
         hipLaunchKernelGGL(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
@@ -869,30 +869,43 @@ static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d
     return SFFT_OK;
 }
 
-template <int HBW, int RS>
+template <int HBW, int U>
 static void launch_g1(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
 {
-    dim3 g((p->Nh + 63) / 64, p->S, npass);
-    const int per_launch = HBW * RS;
-    for (int rb = 0; rb < h || rb == 0; rb += per_launch) {
-        hipLaunchKernelGGL((greek_g1<HBW, RS>), g, dim3(64 * RS), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
-                               p->Nhp, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp);
-        if (h == 0) break;
-    }
+    const int ncb = (p->Nh + 63) / 64;
+    const int total = ncb * p->S * npass;
+    dim3 g(8 * ((total + 7) / 8));
+    for (int rb = 0; rb < h || rb == 0; rb += HBW)
+        hipLaunchKernelGGL((greek_g1<HBW, U>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
+                           p->Nhp, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
 }
+
+// lags per launch: the whole band in one launch up to 16 lags (64 accumulators per lane), else the split with the
+// least padding and fewest launches
+static int g1_band(int h)
+{
+    if (h <= 4) return 4;
+    if (h <= 8) return 8;
+    if (h <= 12) return 12;
+    if (h <= 16) return 16;
+    int best = 16, best_cost = 1 << 30;
+    for (int b = 16; b >= 8; b -= 4) {
+        const int launches = (h + b - 1) / b;
+        const int cost = launches * b * 4 + launches;      // computed lags dominate; ties go to fewer launches
+        if (cost < best_cost) { best_cost = cost; best = b; }
+    }
+    return best;
+}
+static int g1_padded(int h) { const int b = g1_band(h); return ((std::max(h, 1) + b - 1) / b) * b; }
 
 static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
 {
     if (npass <= 0) return SFFT_OK;
-    if (h <= 4) launch_g1<4, 1>(p, pass0, npass, h, s);
-    else if (h <= 8) launch_g1<8, 1>(p, pass0, npass, h, s);
-    else if (h <= 16) {
-        if (p->g1_variant == 1) launch_g1<8, 2>(p, pass0, npass, h, s);
-        else if (p->g1_variant == 2) launch_g1<4, 4>(p, pass0, npass, h, s);
-        else launch_g1<16, 1>(p, pass0, npass, h, s);
-    } else {
-        if (p->g1_variant == 2) launch_g1<4, 4>(p, pass0, npass, h, s);
-        else launch_g1<8, 2>(p, pass0, npass, h, s);
+    switch (g1_band(h)) {
+        case 4: launch_g1<4, 4>(p, pass0, npass, h, s); break;
+        case 8: launch_g1<8, 2>(p, pass0, npass, h, s); break;
+        case 12: launch_g1<12, 2>(p, pass0, npass, h, s); break;
+        default: launch_g1<16, 2>(p, pass0, npass, h, s); break;
     }
     LAUNCH_CHECK();
     return SFFT_OK;
