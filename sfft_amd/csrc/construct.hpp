@@ -4,39 +4,106 @@
 #define SFFT_AMD_CONSTRUCT_HPP
 
 // ------------------------------------------------------------------------------------------------
-// Subtraction: kernel transfer function tables + Construct_FDIFF (SFFTConfigure.py:737-809)
-//   Ctab[ij][a][m] = sum_b a_ijab W1^(m b);   Soff[ij] = sum_{ab != centre} a_ijab
-//   FD[l][m] = sum_ij FI_ij[l][m] * SCALE * ( sum_a W0^(l a) Ctab[ij][a][m] - Soff[ij] )
+// Subtraction: kernel transfer function + Construct_FDIFF (SFFTConfigure.py:737-809)
+//   FD[l][m] = sum_ij FI_ij[l][m] * SCALE * ( sum_ab a_ijab W0^(l a) W1^(m b)  -  Soff[ij] ),   Soff[ij] = sum_{ab != centre} a_ijab
+// The sum over a is done once per image ROW into a small table (kernel_rtab),
+//   R_b[ij][l] = sum_a a_ijab W0^(l a),        Kf[ij][l][m] = SCALE * ( sum_b R_b W1^(m b) - Soff ),
+// stored as  R_0 - Soff  and, for b = 1..w,  P_b = R_b + R_-b,  M_b = R_b - R_-b,  because with |W1| = 1
+//   R_b W1^(mb) + R_-b W1^(-mb) = (wx Px - wy My) + i (wx Py + wy Mx),     wx + i wy = W1^(m b):
+// four real FMAs per (ij, b, element).  In construct_fd a wave owns 64 columns and walks down the rows: its W1^(m b) live in
+// registers, the table row is wave-uniform (scalar loads), and the only vector memory traffic is the one streaming read
+// of the FI planes.  (The first version kept a [ij][a][m] table and re-read it per 8 rows: 3x the plane traffic in L2.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) kernel_ctab(const double* __restrict__ sol, cplx* __restrict__ Ctab, double* __restrict__ Soff,
-                                                   int Fij, int L0, int L1, int w1, int Nh, int Nhp, int N1,
-                                                   const cplx* __restrict__ root1, int skip_centre)
+__global__ void __launch_bounds__(256) kernel_rtab(const double* __restrict__ sol, cplx* __restrict__ Rtab, int Fij, int L0, int L1,
+                                                   int w0, int w1, int N0, int RS, const cplx* __restrict__ root0, int skip_centre)
 {
+    // one thread per (ij, l, b >= 0); RS = row stride of the table in complex elements (1 + 2 * padded w1)
     // skip_centre: separately varying scaling -- the centre coefficient a_ij00 does not multiply kernel plane ij
     // (BSplineSFFT.py:2489-2497); its term is applied in real space by scaling_term()
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    const int ija = blockIdx.y;                   // ij*L0 + a
+    const int b = blockIdx.y;                     // 0 .. w1
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int ij = blockIdx.z;
+    if (l >= N0) return;
     const int Fab = L0 * L1;
-    if (m == 0 && (ija % L0) == 0) {              // one thread per ij
-        const int ij = ija / L0;
-        double sacc = 0.0;
-        const int cen = (L0 / 2) * L1 + w1;
-        for (int ab = 0; ab < Fab; ++ab) if (ab != cen) sacc += sol[ij * Fab + ab];
-        Soff[ij] = sacc;
+    const double* a_ij = sol + (size_t)ij * Fab;
+    double rpx = 0.0, rpy = 0.0, rmx = 0.0, rmy = 0.0;      // R_b, R_-b
+    for (int aa = 0; aa < L0; ++aa) {
+        long long q = ((long long)l * (aa - w0)) % N0; if (q < 0) q += N0;
+        const cplx w = root0[q];
+        double cp = a_ij[aa * L1 + (w1 + b)], cm = a_ij[aa * L1 + (w1 - b)];
+        if (skip_centre && b == 0 && aa == w0) { cp = 0.0; cm = 0.0; }
+        rpx = fma(cp, w.x, rpx); rpy = fma(cp, w.y, rpy);
+        rmx = fma(cm, w.x, rmx); rmy = fma(cm, w.y, rmy);
     }
-    if (m >= Nh) return;
-    const double* arow = sol + (size_t)ija * L1;  // ij*Fab + a*L1
-    double cxr = 0.0, cyi = 0.0;
-    const bool centre_row = skip_centre && (ija % L0) == L0 / 2;
-    for (int bb = 0; bb < L1; ++bb) {
-        const int b = bb - w1;
-        long long q = ((long long)m * b) % N1; if (q < 0) q += N1;
-        const cplx w = root1[q];
-        const double av = (centre_row && b == 0) ? 0.0 : arow[bb];
-        cxr = fma(av, w.x, cxr);
-        cyi = fma(av, w.y, cyi);
+    cplx* row = Rtab + ((size_t)ij * N0 + l) * RS;
+    if (b == 0) {
+        double so = 0.0;
+        const int cen = w0 * L1 + w1;
+        for (int ab = 0; ab < Fab; ++ab) if (ab != cen) so += a_ij[ab];
+        row[0] = make_double2(rpx - so, rpy);
+    } else {
+        row[2 * b - 1] = make_double2(rpx + rmx, rpy + rmy);
+        row[2 * b] = make_double2(rpx - rmx, rpy - rmy);
     }
-    Ctab[(size_t)ija * Nhp + m] = make_double2(cxr, cyi);
+}
+
+// W = compile-time bound on w1 (table rows are zero padded to it); U rows and G planes in flight per wave
+template <int W, int U, int G>
+__global__ void __launch_bounds__(64) construct_fd(const cplx* __restrict__ FI, cplx* __restrict__ FD, const cplx* __restrict__ Rtab,
+                                                   const cplx* __restrict__ root1, int N0, int N1, int Nh, int Nhp, int Fij,
+                                                   int rows_per_wave, double scale)
+{
+    constexpr int RS = 1 + 2 * W;
+    const int lane = threadIdx.x;
+    const int m = blockIdx.x * 64 + lane;
+    const bool active = m < Nh;
+    const int mc = active ? m : 0;
+    double wx[W], wy[W];
+#pragma unroll
+    for (int b = 1; b <= W; ++b) {
+        const cplx t = root1[(int)(((long long)mc * b) % N1)];
+        wx[b - 1] = t.x; wy[b - 1] = t.y;
+    }
+    const size_t plane_sz = (size_t)N0 * Nhp;
+    const int lb = blockIdx.y * rows_per_wave;
+    const int le = min(N0, lb + rows_per_wave);
+    for (int l = lb; l < le; l += U) {
+        cplx acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = make_double2(0.0, 0.0);
+        for (int ij0 = 0; ij0 < Fij; ij0 += G) {
+            cplx fi[G][U];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int ij = min(ij0 + g, Fij - 1);
+#pragma unroll
+                for (int u = 0; u < U; ++u) fi[g][u] = FI[(size_t)ij * plane_sz + (size_t)min(l + u, N0 - 1) * Nhp + mc];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (ij0 + g < Fij) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const cplx* __restrict__ row = Rtab + ((size_t)(ij0 + g) * N0 + min(l + u, N0 - 1)) * RS;   // wave-uniform
+                        double kx = row[0].x, ky = row[0].y;
+#pragma unroll
+                        for (int b = 0; b < W; ++b) {
+                            const cplx P = row[2 * b + 1], M = row[2 * b + 2];
+                            kx = fma(wx[b], P.x, fma(-wy[b], M.y, kx));
+                            ky = fma(wx[b], P.y, fma(wy[b], M.x, ky));
+                        }
+                        acc[u].x = fma(fi[g][u].x, kx, fma(-fi[g][u].y, ky, acc[u].x));
+                        acc[u].y = fma(fi[g][u].x, ky, fma(fi[g][u].y, kx, acc[u].y));
+                    }
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (l + u < le) FD[(size_t)(l + u) * Nhp + m] = make_double2(scale * acc[u].x, scale * acc[u].y);
+        }
+    }
 }
 
 // separately varying scaling: DIFF -= SCALE * I * sum_s a_s00 * sbx[sp[s]][row] * sby[sq[s]][col]  (the centre term of
@@ -60,57 +127,6 @@ __global__ void __launch_bounds__(256) scaling_term(const double* __restrict__ I
     DIFF[o] -= scale * I[o] * acc;
 }
 
-#define CRL 8
-__global__ void __launch_bounds__(256) construct_fd(const cplx* __restrict__ FI, cplx* __restrict__ FD, const cplx* __restrict__ Ctab,
-                                                    const double* __restrict__ Soff, const cplx* __restrict__ root0,
-                                                    int N0, int Nh, int Nhp, int Fij, int L0, int w0, double scale)
-{
-    __shared__ cplx wl[CRL][72];
-    const int tid = threadIdx.x;
-    const int m = blockIdx.x * 256 + tid;
-    const int lbase = blockIdx.y * CRL;
-    for (int e = tid; e < CRL * L0; e += 256) {
-        const int r = e / L0, aa = e - r * L0;
-        const int l = lbase + r;
-        long long q = ((long long)l * (aa - w0)) % N0; if (q < 0) q += N0;
-        wl[r][aa] = root0[q];
-    }
-    __syncthreads();
-    if (m >= Nh) return;
-    cplx acc[CRL];
-#pragma unroll
-    for (int r = 0; r < CRL; ++r) acc[r] = make_double2(0.0, 0.0);
-    const size_t plane_sz = (size_t)N0 * Nhp;
-    for (int ij = 0; ij < Fij; ++ij) {
-        cplx kk[CRL];
-#pragma unroll
-        for (int r = 0; r < CRL; ++r) kk[r] = make_double2(0.0, 0.0);
-        for (int aa = 0; aa < L0; ++aa) {
-            const cplx c = Ctab[((size_t)ij * L0 + aa) * Nhp + m];
-#pragma unroll
-            for (int r = 0; r < CRL; ++r) {
-                const cplx w = wl[r][aa];
-                kk[r].x = fma(w.x, c.x, fma(-w.y, c.y, kk[r].x));
-                kk[r].y = fma(w.x, c.y, fma(w.y, c.x, kk[r].y));
-            }
-        }
-        const double so = Soff[ij];
-#pragma unroll
-        for (int r = 0; r < CRL; ++r) {
-            const int l = lbase + r;
-            if (l < N0) {
-                const cplx fi = FI[(size_t)ij * plane_sz + (size_t)l * Nhp + m];
-                const cplx kf = make_double2(scale * (kk[r].x - so), scale * kk[r].y);
-                acc[r] = cadd(acc[r], cmul(fi, kf));
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < CRL; ++r) {
-        const int l = lbase + r;
-        if (l < N0) FD[(size_t)l * Nhp + m] = acc[r];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Small spectrum-arithmetic kernels behind the FFT utilities (noise decorrelation, FFT convolution:

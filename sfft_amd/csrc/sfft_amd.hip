@@ -7,7 +7,7 @@
 //   FillLS_* + stripes        SFFTConfigure.py:198-711                  fill_system
 //   LSSolver                  SFFTSubtract.py:15-23, 398-403            blocked Cholesky (LU with partial pivoting as fallback)
 //   Extend_Solution           SFFTConfigure.py:716-732                  scatter_solution / lu_backsolve
-//   twiddles + Construct_FDIFF SFFTSubtract.py:433-447, SFFTConfigure.py:737-809   kernel_ctab + construct_fd
+//   twiddles + Construct_FDIFF SFFTSubtract.py:433-447, SFFTConfigure.py:737-809   kernel_rtab + construct_fd
 //   inverse DFT               SFFTSubtract.py:460-461                   cols_c2c(inverse) + rows_c2r_diff
 //
 // Layout in HBM: images [N0][N1] f64 row-major; spectra [plane][N0][Nhp] complex128 with Nh = N1/2+1
@@ -123,7 +123,7 @@ struct sfft_plan {
     double* d_partial = nullptr;        // [BACK_SLICES][CB] strip-product partials of the back substitution
     unsigned int* d_counter = nullptr;
     double* d_sol = nullptr;            // [NEQ] internal solution copy
-    cplx* d_ctab = nullptr; double* d_soff = nullptr;
+    cplx* d_rtab = nullptr; int wpad = 4;   // [Fij][N0][1 + 2 wpad] per-row kernel transfer table of the apply pass
     double* d_rowmom = nullptr; double* d_delta = nullptr;
     int* d_status = nullptr;
     size_t ws_bytes = 0;
@@ -550,8 +550,9 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_TRY(dev_alloc(p, &p->d_counter, (size_t)1));
     PLAN_HIP(hipMemset(p->d_counter, 0, sizeof(unsigned int)));
     PLAN_TRY(dev_alloc(p, &p->d_sol, (size_t)p->NEQ));
-    PLAN_TRY(dev_alloc(p, &p->d_ctab, (size_t)p->Fij * p->L * p->Nhp));
-    PLAN_TRY(dev_alloc(p, &p->d_soff, (size_t)p->Fij));
+    p->wpad = KerHW <= 4 ? 4 : KerHW <= 8 ? 8 : KerHW <= 12 ? 12 : KerHW <= 16 ? 16 : KerHW <= 24 ? 24 : 32;
+    PLAN_TRY(dev_alloc(p, &p->d_rtab, (size_t)p->Fij * N0 * (1 + 2 * p->wpad)));
+    PLAN_HIP(hipMemset(p->d_rtab, 0, (size_t)p->Fij * N0 * (1 + 2 * p->wpad) * sizeof(cplx)));     // entries beyond w stay zero
     PLAN_TRY(dev_alloc(p, &p->d_rowmom, (size_t)N0 * SFFT_MAX_BQ));
     PLAN_TRY(dev_alloc(p, &p->d_delta, (size_t)p->Fpq));
     PLAN_TRY(dev_alloc(p, &p->d_status, (size_t)1));
@@ -694,7 +695,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     hipSetDevice(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_ctab, p->d_soff, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
+                    p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
                     p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
@@ -1055,10 +1056,21 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
 {
     {
         StageTimer t(p, SFFT_ST_CONSTRUCT, s);
-        hipLaunchKernelGGL(kernel_ctab, dim3((p->Nh + 255) / 256, p->Fij * p->L), dim3(256), 0, s, d_solution, p->d_ctab, p->d_soff,
-                           p->Fij, p->L, p->L, p->w, p->Nh, p->Nhp, p->N1, p->ax1.root, p->mode == 3 ? 1 : 0);
-        hipLaunchKernelGGL(construct_fd, dim3((p->Nh + 255) / 256, (p->N0 + CRL - 1) / CRL), dim3(256), 0, s, FI, FD, p->d_ctab,
-                           p->d_soff, p->ax0.root, p->N0, p->Nh, p->Nhp, p->Fij, p->L, p->w, p->scale);
+        hipLaunchKernelGGL(kernel_rtab, dim3((p->N0 + 255) / 256, p->w + 1, p->Fij), dim3(256), 0, s, d_solution, p->d_rtab, p->Fij,
+                           p->L, p->L, p->w, p->w, p->N0, 1 + 2 * p->wpad, p->ax0.root, p->mode == 3 ? 1 : 0);
+        const int rpw = 32;             // rows per wave: 33 x 128 waves at 4096^2; fewer, longer waves measured slower
+        dim3 g((p->Nh + 63) / 64, (p->N0 + rpw - 1) / rpw);
+#define CONSTRUCT_LAUNCH(W, U, G) hipLaunchKernelGGL((construct_fd<W, U, G>), g, dim3(64), 0, s, FI, FD, p->d_rtab, p->ax1.root, \
+                                                     p->N0, p->N1, p->Nh, p->Nhp, p->Fij, rpw, p->scale)
+        switch (p->wpad) {
+            case 4: CONSTRUCT_LAUNCH(4, 2, 3); break;
+            case 8: CONSTRUCT_LAUNCH(8, 2, 3); break;
+            case 12: CONSTRUCT_LAUNCH(12, 2, 3); break;
+            case 16: CONSTRUCT_LAUNCH(16, 2, 3); break;
+            case 24: CONSTRUCT_LAUNCH(24, 2, 2); break;
+            default: CONSTRUCT_LAUNCH(32, 2, 2); break;
+        }
+#undef CONSTRUCT_LAUNCH
         LAUNCH_CHECK();
     }
     {
