@@ -15,8 +15,10 @@ per step (weak scaling, no data-path collective); the only collective is the gat
 end (sfft_amd/sharding.py).
 
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
-  roofline     -- the dominant stage (by HIP-event time measured inside the timed region, on the stream the
-                  kernels run on): algorithmic bytes / average duration against the 8 TB/s HBM3E peak
+  roofline     -- the dominant KERNEL by total time per pair, the column pass of the 2-D FFTs (cols_c2c_4096: three
+                  launches per pair): algorithmic bytes of the timed launch / its duration (HIP events on the launch
+                  stream) against the 8 TB/s HBM3E peak; `roofline_greek` is the same for the second kernel, the Omega
+                  pass of the Greek stage, which is bound by fp64 FMA issue, not by HBM
   cpu_baseline -- the numpy/scipy oracle (port of the reference's Numpy backend) timed on this host on a
                   bounded sample (smaller image, same kernel geometry), converted to 4096^2-pairs/s by pixel count
 """
@@ -33,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6    # same guide: fp64 vector = fp64 matrix (MFMA) peak on MI355X
 
 
 def alg_bytes(N0, N1, w, DK, DB):
@@ -49,8 +52,14 @@ def alg_bytes(N0, N1, w, DK, DB):
     n_gamp = Fij * DB                                   # dense Gamma column-factor passes (p >= 1); they read A only
     out = {
         "prelim_solve": (Fij + 1) * fwd_plane + r * P,  # + row moments of J
-        "greek_g1": n_omg * 2 * spec,                   # Omega passes: operands A and B, every pass streams both
-        "greek_g1b": n_the * 2 * spec + n_gamp * spec,  # Theta passes (A, FJ) + Gamma passes (A; B is a column factor)
+        "fwd_rows": 2 * r * P + (Fij + 1) * spec,       # rows_r2c: each image read once (all its planes from one read), spectra written
+        "fwd_cols": (Fij + 1) * 2 * spec,               # cols_c2c on the solve pass: every plane read + written in place
+        # Greek stage 1 as built: all passes of a (64-column x row-chunk) tile run on one XCD back to back, so each of the
+        # Fij (+ J) planes is streamed from HBM once and re-read from that XCD's L2; partial lag sums are written
+        "greek_g1": Fij * spec,
+        "greek_g1b": (Fij + 1) * spec,
+        # fp64 flops of the Omega passes: per pass and spectrum element one complex product (6) + 4 real FMAs per lag
+        "greek_g1_flops": n_omg * N0 * Nh * (6 + 2 * 4 * (2 * w)),
         "prelim_apply": Fij * fwd_plane,
         "construct": Fij * spec + spec,
         "inverse": 2 * spec + spec + r * P + r * P,      # columns r+w, rows read, J read, DIFF write
@@ -192,13 +201,24 @@ def main():
         except Exception:
             pass
 
-        def roof(stages):
-            timed = {k: v for k, v in stages.items() if k in ab}
-            dom = max(timed, key=timed.get)
-            ach = ab[dom] / (timed[dom] * 1e-3) / 1e9
+        KERNEL_OF = {"fwd_cols": "cols_c2c_4096" if N == 4096 else "cols_c2c / strided_dft",
+                     "fwd_rows": "rows_r2c_4096" if N == 4096 else "rows_r2c", "greek_g1": "greek_g1<16, 2> (Omega passes)",
+                     "greek_g1b": "greek_g1<8, 2> (Theta, Gamma passes)", "construct": "construct_fd"}
+
+        def roof(stages, dom="fwd_cols"):
+            ach = ab[dom] / (stages[dom] * 1e-3) / 1e9
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if (N, args.kerhw, args.dk, args.db) == (4096, 8, 2, 2) else None
-            return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": timed[dom]}
+            return {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": stages[dom]}
+
+        def roof_flops(stages):
+            tf = ab["greek_g1_flops"] / (stages["greek_g1"] * 1e-3) / 1e12
+            traffic = pmc.get("greek_g1", {}).get("hbm_bytes_per_launch") if (N, args.kerhw, args.dk, args.db) == (4096, 8, 2, 2) else None
+            return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_flops"],
+                    "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
+                    "note": "fp64 vector FMAs (the fp64 VALU and MFMA peaks are equal on MI355X); HBM side: "
+                            "%.0f GB/s of algorithmic bytes" % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
         out = {
             "metric": "image-pairs/sec, %dx%d, KerHW=%d polyOrd=%d" % (N, N, args.kerhw, args.dk),
             "value": value, "unit": "image-pairs/s", "mpix_per_s": value * N * N / 1e6,
@@ -211,8 +231,11 @@ def main():
                        "pairs_per_step": world * S, "pairs_in_flight_per_gpu": S, "plan_create_s": plan_s,
                        "solver": {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")},
             "stage_ms": stage_ms,
-            "roofline": dict(roof(iso_stage), measured="HIP events on the launch stream around the kernel, %d launches with one "
-                             "pair in flight right after the timed region (same process, same buffers)" % n_iso),
+            "roofline": dict(roof(iso_stage), measured="HIP events on the launch stream around the kernel (the %d-plane forward "
+                             "launch of the solve pass), %d launches with one pair in flight right after the timed region "
+                             "(same process, same buffers)" % (ab["fwd_cols"] // (2 * 16 * N * (N // 2 + 1)), n_iso),
+                             kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "construct")}),
+            "roofline_greek": dict(roof_flops(iso_stage), measured="same events, same launches"),
             "roofline_timed_region": dict(roof(stage_ms), measured="same events on stream 0 inside the timed region; durations "
                                           "include time sliced to the other %d streams' kernels" % (S - 1)),
             "single_pair": {"ms": iso_ms, "pairs_per_s": 1e3 / iso_ms, "stage_ms": iso_stage,

@@ -61,6 +61,8 @@ enum {
     SFFT_ST_CONSTRUCT,         /* j+k: kernel transfer function + Construct_FDIFF */
     SFFT_ST_INVERSE,           /* k: inverse DFT + DIFF epilogue */
     SFFT_ST_GREEK_G1B,         /* e..h: Theta and Gamma passes (kernel greek_g1, w lags) */
+    SFFT_ST_FWD_ROWS,          /* inside b+c of the solve: the row pass of the forward DFTs (kernel rows_r2c*) */
+    SFFT_ST_FWD_COLS,          /* inside b+c of the solve: the column pass of the forward DFTs (kernel cols_c2c*) */
     SFFT_ST_COUNT
 };
 

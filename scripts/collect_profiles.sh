@@ -10,6 +10,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
   python $GRAFT_REPO_ROOT/scripts/pmc_summary.py /tmp/pmc_$c/p_counter_collection.csv > $OUT/pmc_$c.txt
 done
+python $GRAFT_REPO_ROOT/scripts/make_pmc_traffic.py $OUT/pmc_FETCH_SIZE.txt $OUT/pmc_WRITE_SIZE.txt > $OUT/pmc_traffic.json
+cp $OUT/pmc_traffic.json $GRAFT_REPO_ROOT/profiles/pmc_traffic.json   # so that the default bench line below carries the fresh traffic figure
 # (3) the default bench line (pipelined), unprofiled
 python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_default.json 2> /dev/null
 tail -c 600 $OUT/bench_default.json

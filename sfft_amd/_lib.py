@@ -20,7 +20,8 @@ SFFT_ERR_NOMEM = -5
 QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1", "Fab", "Fij", "Fpq", "NEQ", "Fijab",
                 "NEQ_FSfree", "FOMG", "FGAM", "FTHE", "FPSI", "FPHI", "FDEL", "WORKSPACE_BYTES", "LAST_SOLVER",
                 "NUM_GREEK_PAIRS", "ScaFij"]
-STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b"]
+STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b",
+          "fwd_rows", "fwd_cols"]
 
 EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_create_varscale", "sfft_plan_set_regularization", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
            "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",

@@ -811,9 +811,11 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
     }
 }
 
-static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* dst, hipStream_t s)
+// st_rows / st_cols: stage ids that time the row pass / the column pass of this call (-1: not timed)
+static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* dst, hipStream_t s, int st_rows = -1, int st_cols = -1)
 {
     dim3 g1((p->N0 + 1) / 2, nplanes);
+    if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
     if (p->ax1.big) {
         const int npr = (p->N0 + 1) / 2;
         for (int k = 0; k < nplanes; ++k) {
@@ -835,14 +837,18 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
         hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
                            axis_dev(p->ax1), p->scale);
     LAUNCH_CHECK();
+    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
+    if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
     launch_cols(p, dst, nplanes, 0, s);
+    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
     LAUNCH_CHECK();
     return SFFT_OK;
 }
 
 // forward spectra of the Fij kernel-basis planes of image d_I (and, when d_J is given, of d_J itself as plane Fij)
 // and, with_sca, of the scaling planes (planes Fij + 1 ...)
-static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca = false)
+static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca = false,
+                                int st_rows = -1, int st_cols = -1)
 {
     const int total = p->Fij + (d_J ? 1 : 0) + ((with_sca && d_J) ? p->nsca : 0);
     const size_t plane_sz = (size_t)p->N0 * p->Nhp;
@@ -864,7 +870,7 @@ static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d
                 ra.wy[u] = p->d_sby + (size_t)p->spair[2 * sI + 1] * p->N1;
             }
         }
-        int rc = forward_planes(p, ra, n, dst + (size_t)k0 * plane_sz, s);
+        int rc = forward_planes(p, ra, n, dst + (size_t)k0 * plane_sz, s, st_rows, st_cols);     // (more than one chunk: the last one is timed)
         if (rc) return rc;
     }
     return SFFT_OK;
@@ -982,7 +988,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     int rc;
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
-        if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true))) return rc;
+        if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS))) return rc;
         if (p->nby <= 4) hipLaunchKernelGGL(row_moments<4>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
