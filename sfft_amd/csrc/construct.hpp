@@ -50,8 +50,8 @@ __global__ void __launch_bounds__(256) kernel_rtab(const double* __restrict__ so
 // W = compile-time bound on w1 (table rows are zero padded to it); U rows and G planes in flight per wave
 template <int W, int U, int G>
 __global__ void __launch_bounds__(64) construct_fd(const cplx* __restrict__ FI, cplx* __restrict__ FD, const cplx* __restrict__ Rtab,
-                                                   const cplx* __restrict__ root1, int N0, int N1, int Nh, int Nhp, int Fij,
-                                                   int rows_per_wave, double scale)
+                                                   const cplx* __restrict__ root1, int N0, int N1, int Nh, int Nhp, SpecLayout lay,
+                                                   int Fij, int rows_per_wave, double scale)
 {
     constexpr int RS = 1 + 2 * W;
     const int lane = threadIdx.x;
@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(64) construct_fd(const cplx* __restrict__ FI, 
         wx[b - 1] = t.x; wy[b - 1] = t.y;
     }
     const size_t plane_sz = (size_t)N0 * Nhp;
+    const size_t mo = lay.col(mc), rs = (size_t)lay.rstride;
     const int lb = blockIdx.y * rows_per_wave;
     const int le = min(N0, lb + rows_per_wave);
     for (int l = lb; l < le; l += U) {
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(64) construct_fd(const cplx* __restrict__ FI, 
             for (int g = 0; g < G; ++g) {
                 const int ij = min(ij0 + g, Fij - 1);
 #pragma unroll
-                for (int u = 0; u < U; ++u) fi[g][u] = FI[(size_t)ij * plane_sz + (size_t)min(l + u, N0 - 1) * Nhp + mc];
+                for (int u = 0; u < U; ++u) fi[g][u] = FI[(size_t)ij * plane_sz + (size_t)min(l + u, N0 - 1) * rs + mo];
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(64) construct_fd(const cplx* __restrict__ FI, 
         if (active) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (l + u < le) FD[(size_t)(l + u) * Nhp + m] = make_double2(scale * acc[u].x, scale * acc[u].y);
+                if (l + u < le) FD[(size_t)(l + u) * rs + mo] = make_double2(scale * acc[u].x, scale * acc[u].y);
         }
     }
 }
@@ -132,10 +133,11 @@ __global__ void __launch_bounds__(256) scaling_term(const double* __restrict__ I
 // Small spectrum-arithmetic kernels behind the FFT utilities (noise decorrelation, FFT convolution:
 // sfft/utils/PureCupyFFTKits.py, PureCupyDeCorrelationCalculator.py)
 // ------------------------------------------------------------------------------------------------
-__global__ void copy_spectrum_scaled(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, int src_ld, int dst_ld, double f)
+// dst(l, m) = f * src(l, m), each side in its own layout (a dense caller array is a row-major layout of leading dimension Nh)
+__global__ void copy_spectrum_scaled(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, SpecLayout sl, SpecLayout dl, double f)
 {
     const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-    if (m < Nh) { const cplx v = src[(size_t)l * src_ld + m]; dst[(size_t)l * dst_ld + m] = make_double2(v.x * f, v.y * f); }
+    if (m < Nh) { const cplx v = src[sl.at(l, m)]; dst[dl.at(l, m)] = make_double2(v.x * f, v.y * f); }
 }
 __global__ void scale_real(double* __restrict__ a, double f, size_t n)
 {
@@ -175,10 +177,10 @@ __global__ void half_to_full_real(const double* __restrict__ half, double* __res
 }
 
 // debug: copy a padded half-spectrum plane to a dense [N0][Nh] array
-__global__ void copy_spectrum(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, int Nhp)
+__global__ void copy_spectrum(const cplx* __restrict__ src, cplx* __restrict__ dst, int N0, int Nh, SpecLayout sl)
 {
     const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-    if (m < Nh) dst[(size_t)l * Nh + m] = src[(size_t)l * Nhp + m];
+    if (m < Nh) dst[(size_t)l * Nh + m] = src[sl.at(l, m)];
 }
 
 #endif

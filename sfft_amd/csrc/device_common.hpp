@@ -4,6 +4,22 @@
 #define SFFT_AMD_DEVICE_COMMON_HPP
 
 // ------------------------------------------------------------------------------------------------
+// Layout of one half-spectrum plane ([N0] rows x [Nhp] padded columns of complex128, N0 * Nhp elements either way):
+//   row-major   element (l, m) at l * Nhp + m                                   (shift = 31: every column is "panel 0")
+//   panels      [Nhp / PW][N0][PW]: (m / PW) * N0 * PW + l * PW + (m % PW), PW a power of two.
+// The column pass of the 4096-point fast path walks one column pair down all rows: in row-major order every 32-byte
+// piece it touches lies in a different 128-byte line (measured: that, not arithmetic or DRAM locality, bounds the pass);
+// with PW = 2 its tile is one contiguous 128 KiB block.  Row-wise consumers see PW * 16 contiguous bytes per row.
+// ------------------------------------------------------------------------------------------------
+struct SpecLayout {
+    int shift, mask;          // panel of column m = m >> shift, position inside it = m & mask
+    int rstride;              // elements between consecutive rows of one column
+    long long pstride;        // elements between consecutive panels
+    __host__ __device__ __forceinline__ size_t col(int m) const { return (size_t)(m >> shift) * (size_t)pstride + (size_t)(m & mask); }
+    __host__ __device__ __forceinline__ size_t at(int l, int m) const { return col(m) + (size_t)l * (size_t)rstride; }
+};
+
+// ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }

@@ -82,15 +82,19 @@ __device__ __forceinline__ void fft4096_core(cplx (&u)[16], int j, cplx* lds, co
 // count) of a launch group share their source image: the workgroup reads its two rows once and produces every plane.
 struct RowGroups { int ngroups; int first[SFFT_MAX_PLANES]; int count[SFFT_MAX_PLANES]; };
 
-__global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp,
-                                                     const cplx* __restrict__ tw, double scale)
+// Workgroup b takes row pair (b % 8) * pairs_per_xcd + b / 8: consecutive row pairs run on one XCD, so that with a panel
+// layout the pieces of a 128-byte line written by neighbouring row pairs merge in that XCD's L2.
+__global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp, SpecLayout lay,
+                                                     const cplx* __restrict__ tw, double scale, int pairs_per_xcd)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* lds = reinterpret_cast<cplx*>(smem_raw);
     const int N1 = 4096;
     const int j = threadIdx.x;
     const int pfirst = grp.first[blockIdx.y], pcount = grp.count[blockIdx.y];
-    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const int rp = (int)(blockIdx.x & 7) * pairs_per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= pairs_per_xcd || 2 * rp >= N0) return;
+    const int l0 = 2 * rp, l1 = l0 + 1;
     const bool has1 = l1 < N0;
     const double* __restrict__ src = a.src[pfirst];
     const double* r0p = src + (size_t)l0 * N1;
@@ -121,8 +125,8 @@ __global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, 
 #pragma unroll
         for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)];
         __syncthreads();
-        cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
-        cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
+        cplx* o0 = out + (size_t)plane * N0 * Nhp + (size_t)l0 * lay.rstride;
+        cplx* o1 = out + (size_t)plane * N0 * Nhp + (size_t)l1 * lay.rstride;
 #pragma unroll
         for (int sx = 0; sx <= 8; ++sx) {
             const int m = j + 256 * sx;
@@ -130,8 +134,9 @@ __global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, 
                 const cplx z = u[R16_OUT(sx)];
                 const cplx zp = lds[(N1 - m) & (N1 - 1)];
                 const cplx zc = make_double2(zp.x, -zp.y);
-                o0[m] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
-                if (has1) o1[m] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+                const size_t mo = lay.col(m);
+                o0[mo] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
+                if (has1) o1[mo] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
             }
         }
     }
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, 
 
 // columns, complex -> complex in place (N0 = 4096), two adjacent columns per workgroup (512 threads).
 // Blocks that share 128-byte lines are mapped to the same XCD (block b runs on XCD b % 8) so its L2 merges them.
-__global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, int ncols, int Nhp, const cplx* __restrict__ tw,
+__global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, int ncols, int Nhp, SpecLayout lay, const cplx* __restrict__ tw,
                                                      int inverse, double scale, int pairs_per_xcd)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -149,11 +154,12 @@ __global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, in
     const int cp = (blockIdx.x & 7) * pairs_per_xcd + (blockIdx.x >> 3);
     const int col = 2 * cp + c;
     const bool ok = (blockIdx.x >> 3) < pairs_per_xcd && col < ncols;
-    cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp + (ok ? col : 0);
+    cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp + lay.col(ok ? col : 0);
+    const size_t rs = (size_t)lay.rstride;
     cplx u[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        cplx z = ok ? base[(size_t)(j + 256 * r) * Nhp] : make_double2(0.0, 0.0);
+        cplx z = ok ? base[(size_t)(j + 256 * r) * rs] : make_double2(0.0, 0.0);
         if (inverse) z.y = -z.y;
         u[r] = z;
     }
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, in
     for (int sx = 0; sx < 16; ++sx) {
         cplx z = u[R16_OUT(sx)];
         if (inverse) z.y = -z.y;
-        base[(size_t)(j + 256 * sx) * Nhp] = make_double2(z.x * scale, z.y * scale);
+        base[(size_t)(j + 256 * sx) * rs] = make_double2(z.x * scale, z.y * scale);
     }
 }
 
@@ -171,7 +177,7 @@ __global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, in
 template <int NQ>
 __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict__ FD, const double* __restrict__ J,
                                                           const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
-                                                          int N0, int Nhp, const cplx* __restrict__ tw)
+                                                          int N0, SpecLayout lay, const cplx* __restrict__ tw)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* lds = reinterpret_cast<cplx*>(smem_raw);
@@ -179,16 +185,17 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
     const int j = threadIdx.x;
     const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
     const bool has1 = l1 < N0;
-    const cplx* f0 = FD + (size_t)l0 * Nhp;
-    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * Nhp;
+    const cplx* f0 = FD + (size_t)l0 * lay.rstride;
+    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * lay.rstride;
     cplx u[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = j + 256 * r;
         const bool mir = m > N1 / 2;
         const int mm = mir ? N1 - m : m;
-        cplx x0 = f0[mm];
-        cplx x1 = has1 ? f1[mm] : make_double2(0.0, 0.0);
+        const size_t mo = lay.col(mm);
+        cplx x0 = f0[mo];
+        cplx x1 = has1 ? f1[mo] : make_double2(0.0, 0.0);
         if (mm == 0 || mm == N1 / 2) { x0.y = 0.0; x1.y = 0.0; }
         if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
         u[r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)

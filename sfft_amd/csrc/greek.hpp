@@ -50,7 +50,7 @@ __device__ __forceinline__ void g1_row(const cplx av, const cplx bv, const cplx*
 
 template <int HBW, int U>
 __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
-                                               cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int rows_per_chunk,
+                                               cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay, int rows_per_chunk,
                                                int r_base, const cplx* __restrict__ W0tab, int HM, const cplx* __restrict__ Xp,
                                                int ncb, int S, int npass)
 {
@@ -73,7 +73,9 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
     const bool active = m < Nh;
     const int mc = active ? m : 0;
     const size_t plane_sz = (size_t)N0 * Nhp;
-    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz + mc;
+    const size_t mo = lay.col(mc);
+    const size_t rs = (size_t)lay.rstride;
+    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz + mo;
     const bool colfac = pr.b_plane < 0;
     const int rfirst = r_base + 1;                  // lags rfirst .. rfirst + HBW - 1 (those beyond h are not stored)
     double S1[HBW], S2[HBW], S3[HBW], S4[HBW];
@@ -84,27 +86,27 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
     const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + rfirst;
     int l = lb;
     if (!colfac) {
-        const cplx* __restrict__ B = spec + (size_t)pr.b_plane * plane_sz + mc;
+        const cplx* __restrict__ B = spec + (size_t)pr.b_plane * plane_sz + mo;
         for (; l + U <= le; l += U, trow += (size_t)U * HM) {
             cplx av[U], bv[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) av[u] = A[(size_t)(l + u) * Nhp];
+            for (int u = 0; u < U; ++u) av[u] = A[(size_t)(l + u) * rs];
 #pragma unroll
-            for (int u = 0; u < U; ++u) bv[u] = B[(size_t)(l + u) * Nhp];
+            for (int u = 0; u < U; ++u) bv[u] = B[(size_t)(l + u) * rs];
 #pragma unroll
             for (int u = 0; u < U; ++u) g1_row<HBW>(av[u], bv[u], trow + (size_t)u * HM, S1, S2, S3, S4, g0x, g0y);
         }
-        for (; l < le; ++l, trow += HM) g1_row<HBW>(A[(size_t)l * Nhp], B[(size_t)l * Nhp], trow, S1, S2, S3, S4, g0x, g0y);
+        for (; l < le; ++l, trow += HM) g1_row<HBW>(A[(size_t)l * rs], B[(size_t)l * rs], trow, S1, S2, S3, S4, g0x, g0y);
     } else {
         const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;     // wave-uniform column factor
         for (; l + U <= le; l += U, trow += (size_t)U * HM) {
             cplx av[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) av[u] = A[(size_t)(l + u) * Nhp];
+            for (int u = 0; u < U; ++u) av[u] = A[(size_t)(l + u) * rs];
 #pragma unroll
             for (int u = 0; u < U; ++u) g1_row<HBW>(av[u], xp[l + u], trow + (size_t)u * HM, S1, S2, S3, S4, g0x, g0y);
         }
-        for (; l < le; ++l, trow += HM) g1_row<HBW>(A[(size_t)l * Nhp], xp[l], trow, S1, S2, S3, S4, g0x, g0y);
+        for (; l < le; ++l, trow += HM) g1_row<HBW>(A[(size_t)l * rs], xp[l], trow, S1, S2, S3, S4, g0x, g0y);
     }
     if (!active) return;
     cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp + m;
@@ -130,13 +132,13 @@ __global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root
 
 // Gamma passes with p = 0: Xp = N0 * delta[l], so G[r][m] = N0 * A[0][m] for every lag (chunk 0; other chunks zero)
 __global__ void __launch_bounds__(256) greek_g1_row0(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
-                                                     cplx* __restrict__ Gp, int N0, int Nh, int Nhp, int S)
+                                                     cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay, int S)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= Nh) return;
     const G1Pass pr = passes[pass0 + blockIdx.y];
     const int PH = 2 * pr.h + 1;
-    const cplx a0 = spec[(size_t)pr.a_plane * N0 * Nhp + m];
+    const cplx a0 = spec[(size_t)pr.a_plane * N0 * Nhp + lay.col(m)];
     const cplx v = make_double2(a0.x * (double)N0, a0.y * (double)N0);
     cplx* g = Gp + pr.gp_off + m;
     for (int c = 0; c < S; ++c)

@@ -74,6 +74,7 @@ struct sfft_plan {
     int Nh = 0, Nhp = 0;
     double scale = 0.0;
     AxisHost ax0, ax1;
+    SpecLayout lay;                     // layout of every half-spectrum plane of this plan (row-major, or panels on the 4096^2 fast path)
     int TC = 1, MS = 0;                 // column pass tiling
     int nt_rows = 64, nt_cols = 64;
     size_t lds_rows = 0, lds_cols = 0;
@@ -136,6 +137,7 @@ struct sfft_plan {
 };
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static SpecLayout rowmajor_layout(int ld) { SpecLayout L; L.shift = 31; L.mask = 0x7fffffff; L.rstride = ld; L.pstride = 0; return L; }
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 template <typename T>
@@ -377,6 +379,16 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     }
     PLAN_TRY(build_axis(p, p->ax0, N0));
     PLAN_TRY(build_axis(p, p->ax1, N1));
+    p->lay = rowmajor_layout(p->Nhp);
+    {   // panel layout: only when both passes are the 4096-point fast kernels (the generic and four-step kernels are row-major)
+        int pw = 4;     // measured at 4096^2: 2 is best for the column pass alone (0.60 -> 0.40 ms) but slows every row-wise
+                        // consumer (32 lines per wave load); 4 keeps them at speed and still gives 0.60 -> 0.47 ms; 8 gains nothing
+        if (const char* ev = getenv("SFFT_PANEL")) pw = atoi(ev);
+        const bool both_fast = !p->no_fast_fft && !p->ax0.big && !p->ax0.blue && p->ax0.M == 4096 && !p->ax1.big && !p->ax1.blue && p->ax1.M == 4096;
+        if (both_fast && pw > 1 && is_pow2(pw) && p->Nhp % pw == 0) {
+            p->lay.shift = ilog2(pw); p->lay.mask = pw - 1; p->lay.rstride = pw; p->lay.pstride = (long long)N0 * pw;
+        }
+    }
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
     if (!p->ax1.big) {
         p->nt_rows = std::min(1024, std::max(64, p->ax1.M / 16));
@@ -803,7 +815,7 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
         const int npairs = (p->Nh + 1) / 2;
         const int per = (npairs + 7) / 8;
         hipLaunchKernelGGL(cols_c2c_4096, dim3(8 * per, nplanes), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, data, p->Nh, p->Nhp,
-                           p->ax0.tw, inverse, 1.0, per);
+                           p->lay, p->ax0.tw, inverse, 1.0, per);
     } else {
         dim3 g2((p->Nh + p->TC - 1) / p->TC, nplanes);
         hipLaunchKernelGGL(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, data, p->N0, p->Nh, p->Nhp, p->TC, p->MS,
@@ -830,8 +842,9 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
             if (k > 0 && ra.src[k] == ra.src[k - 1]) ++grp.count[grp.ngroups - 1];
             else { grp.first[grp.ngroups] = k; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
         }
-        hipLaunchKernelGGL(rows_r2c_4096, dim3((p->N0 + 1) / 2, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp, dst,
-                           p->N0, p->Nhp, p->ax1.tw, p->scale);
+        const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
+        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp, dst,
+                           p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     else
         hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
@@ -884,7 +897,7 @@ static void launch_g1(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
     dim3 g(8 * ((total + 7) / 8));
     for (int rb = 0; rb < h || rb == 0; rb += HBW)
         hipLaunchKernelGGL((greek_g1<HBW, U>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
-                           p->Nhp, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+                           p->Nhp, p->lay, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
 }
 
 // lags per launch: the whole band in one launch up to 16 lags (64 accumulators per lane), else the split with the
@@ -1003,7 +1016,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
         if ((rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
         if (p->n_row0 > 0) {
             hipLaunchKernelGGL(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_row0), dim3(256), 0, s, p->d_spec, p->d_passes,
-                               p->n_omg + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->S);
+                               p->n_omg + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->lay, p->S);
             LAUNCH_CHECK();
         }
     }
@@ -1067,7 +1080,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         const int rpw = 32;             // rows per wave: 33 x 128 waves at 4096^2; fewer, longer waves measured slower
         dim3 g((p->Nh + 63) / 64, (p->N0 + rpw - 1) / rpw);
 #define CONSTRUCT_LAUNCH(W, U, G) hipLaunchKernelGGL((construct_fd<W, U, G>), g, dim3(64), 0, s, FI, FD, p->d_rtab, p->ax1.root, \
-                                                     p->N0, p->N1, p->Nh, p->Nhp, p->Fij, rpw, p->scale)
+                                                     p->N0, p->N1, p->Nh, p->Nhp, p->lay, p->Fij, rpw, p->scale)
         switch (p->wpad) {
             case 4: CONSTRUCT_LAUNCH(4, 2, 3); break;
             case 8: CONSTRUCT_LAUNCH(8, 2, 3); break;
@@ -1092,10 +1105,10 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         {
             if (p->nby <= 4)
                 hipLaunchKernelGGL(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
-                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->Nhp, p->ax1.tw);
+                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
             else
                 hipLaunchKernelGGL(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
-                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->Nhp, p->ax1.tw);
+                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
         }
         else
             hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
@@ -1187,7 +1200,7 @@ extern "C" int sfft_fft2_r2c(sfft_plan* p, const double* d_real, double* d_spec,
     int rc = forward_planes(p, ra, 1, p->d_spec, s);
     if (rc) return rc;
     hipLaunchKernelGGL(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec, p->N0, p->Nh,
-                       p->Nhp, p->Nh, scale / p->scale);
+                       p->lay, rowmajor_layout(p->Nh), scale / p->scale);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -1208,7 +1221,7 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
     }
     cplx* FD = p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp;
     hipLaunchKernelGGL(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, (const cplx*)d_spec, FD, p->N0, p->Nh,
-                       p->Nh, p->Nhp, 1.0);
+                       rowmajor_layout(p->Nh), p->lay, 1.0);
     LAUNCH_CHECK();
     // reuse the inverse path of the subtraction: with J = 0 and b = 0 it returns -IDFT2(FD)
     launch_cols(p, FD, 1, 1, s);
@@ -1220,7 +1233,7 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
                            d_real, p->N0, p->N1);
     } else if (fast_axis(p->ax1) && !p->no_fast_fft)
         hipLaunchKernelGGL(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, p->d_zero,
-                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->Nhp, p->ax1.tw);
+                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->lay, p->ax1.tw);
     else
         hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, p->d_zero,
                            p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->N1, p->Nh, p->Nhp, axis_dev(p->ax1));
@@ -1279,7 +1292,7 @@ extern "C" int sfft_dbg_forward_spectrum(sfft_plan* p, const double* d_I, int i,
     ra.src[0] = d_I; ra.wx[0] = p->d_kbx + (size_t)i * p->N0; ra.wy[0] = p->d_kby + (size_t)j * p->N1;
     int rc = forward_planes(p, ra, 1, p->d_spec, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(copy_spectrum, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec_out, p->N0, p->Nh, p->Nhp);
+    hipLaunchKernelGGL(copy_spectrum, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec_out, p->N0, p->Nh, p->lay);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;
