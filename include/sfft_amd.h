@@ -163,6 +163,14 @@ int sfft_spec_multiply(const double* d_a, const double* d_b, int b_is_real, doub
 /* d_full [N0][N1] float64 of a real conjugate-symmetric spectrum quantity from its half d_half [N0][N1/2+1] */
 int sfft_half_to_full_real(const double* d_half, double* d_full, int N0, int N1, void* stream);
 
+/* BSpline_GridConvolve.GSVC_GPU (sfft/BSplineSFFT.py:4951-5006): grid-wise space-varying convolution.
+ * d_labels [N0][N1] int32 assigns every pixel to one of Nseg box segments (the reference's AllocatedL), d_kerstack
+ * [Nseg][L0][L1] float64 holds one kernel per segment (normalise on the host if wanted).
+ *   d_out[x][y] = sum_ab kerstack[label][a][b] * d_in[x + (L0-1)/2 - a][y + (L1-1)/2 - b],  zeros beyond the image,
+ * i.e. convolve2d(mode='same', boundary='fill', fillvalue=0) of each segment with its own kernel.  Stream-ordered. */
+int sfft_grid_convolve(const double* d_in, const int* d_labels, const double* d_kerstack, int N0, int N1, int Nseg,
+                       int L0, int L1, double* d_out, int device, void* stream);
+
 /* enable (1) / disable (0) hipEvent timing of the stages of subsequent calls */
 int sfft_set_timing(sfft_plan* plan, int enable);
 

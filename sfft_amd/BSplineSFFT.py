@@ -25,7 +25,8 @@ from .sfftcore.SFFTSubtract import (ElementalSFFTSubtract, ElementalSFFTSubtract
 from .utils import minifits
 
 __all__ = ["SingleSFFTConfigure", "ElementalSFFTSubtract", "GeneralSFFTSubtract", "GeneralSFFTSubtract_PureCupy",
-           "BSpline_Packet", "Create_BSplineBasis", "Create_BSplineBasis_Req"]
+           "BSpline_Packet", "Create_BSplineBasis", "Create_BSplineBasis_Req", "Read_SFFTSolution", "BSpline_MatchingKernel",
+           "ConvKernel_Convertion", "BSpline_DeCorrelation", "BSpline_GridConvolve"]
 
 try:  # pragma: no cover - astropy is absent from the target image
     from astropy.io import fits as _afits
@@ -345,3 +346,203 @@ class BSpline_Packet:
                     minifits.set_card(cards, k, v, 'SFFT')
                 minifits.writeto(FITS_Solution, np.ascontiguousarray(Solution.reshape((-1, 1)).T), cards)
         return Solution, PixA_DIFF
+
+
+# ------------------------------------------------------------------------------------------------
+# Post-subtraction classes of sfft/BSplineSFFT.py.  The solution decoding and the kernel realisation are
+# host numpy in the reference too; the decorrelation kernel and the grid convolution run on the GPU.
+# ------------------------------------------------------------------------------------------------
+def _scaling_mode(SEPARATE_SCALING, DS):
+    if not SEPARATE_SCALING:
+        return 'ENTANGLED'
+    return 'SEPARATE-CONSTANT' if DS == 0 else 'SEPARATE-VARYING'
+
+
+def _term_list(SpType, Degree, Fi, Fj):
+    """REF_ij of a basis: (i, j) with i + j <= Degree, or the full Fi x Fj tensor grid."""
+    if SpType == 'Polynomial':
+        return [(i, j) for i in range(Degree + 1) for j in range(Degree + 1 - i)]
+    return [(i, j) for i in range(Fi) for j in range(Fj)]
+
+
+class Read_SFFTSolution:
+    """Solution vector -> dictionaries of the SFFT-format coefficients ac_ijab = a_ijab / (N0 N1) (BSplineSFFT.py:4358-4553):
+    SfftKerDict[(i, j)] is the [L0][L1] stamp of spatial term (i, j); with separately varying scaling its centre entry is NaN
+    and SfftScaDict[(i, j)] holds the coefficient of scaling term (i, j) (otherwise SfftScaDict is None)."""
+
+    def FromArray(self, Solution, KerSpType, N0, N1, DK, L0, L1, Fi, Fj, Fpq, SEPARATE_SCALING, ScaSpType, DS, ScaFi, ScaFj):
+        mode = _scaling_mode(SEPARATE_SCALING, DS)
+        w0, w1 = (L0 - 1) // 2, (L1 - 1) // 2
+        kterms = _term_list(KerSpType, DK, Fi, Fj)
+        ac = (np.asarray(Solution, dtype=np.float64)[:-Fpq] / (N0 * N1)).reshape(len(kterms), L0, L1)
+        SfftKerDict = {t: ac[k].copy() for k, t in enumerate(kterms)}
+        if mode != 'SEPARATE-VARYING':
+            return SfftKerDict, None
+        sterms = _term_list(ScaSpType, DS, ScaFi, ScaFj)       # the first ScaFij kernel slots carry the scaling terms
+        SfftScaDict = {t: float(ac[k, w0, w1]) for k, t in enumerate(sterms)}
+        for t in kterms:
+            SfftKerDict[t][w0, w1] = np.nan
+        return SfftKerDict, SfftScaDict
+
+    def FromFITS(self, FITS_Solution):
+        Solution, phdr = _read_solution_fits(FITS_Solution)
+        a = _solution_header_args(phdr)
+        return self.FromArray(Solution=Solution, KerSpType=a['KerSpType'], N0=a['N0'], N1=a['N1'], DK=a['DK'], L0=a['L0'], L1=a['L1'],
+                              Fi=a['Fi'], Fj=a['Fj'], Fpq=a['Fpq'], SEPARATE_SCALING=a['SEPARATE_SCALING'], ScaSpType=a['ScaSpType'],
+                              DS=a['DS'], ScaFi=a['ScaFi'], ScaFj=a['ScaFj'])
+
+
+def _read_solution_fits(FITS_Solution):
+    if _afits is not None:
+        return _afits.getdata(FITS_Solution, ext=0)[0], _afits.getheader(FITS_Solution, ext=0)
+    data, cards = minifits.getdata(FITS_Solution)
+    return np.asarray(data, dtype=np.float64)[0], minifits.header_dict(cards)
+
+
+def _solution_header_args(phdr):
+    """The keywords BSP writes next to the solution (BSplineSFFT.py:4282-4351) back into FromArray's arguments."""
+    a = dict(KerHW=phdr['KERHW'], KerSpType=phdr['KSPTYPE'], N0=int(phdr['N0']), N1=int(phdr['N1']), DK=int(phdr['DK']),
+             L0=int(phdr['L0']), L1=int(phdr['L1']), Fi=int(phdr['FI']), Fj=int(phdr['FJ']), Fpq=int(phdr['FPQ']),
+             KerIntKnotX=[phdr['KIKX%d' % i] for i in range(int(phdr['NKIKX']))],
+             KerIntKnotY=[phdr['KIKY%d' % i] for i in range(int(phdr['NKIKY']))],
+             SEPARATE_SCALING=str(phdr['SEPSCA']) == 'True', ScaSpType=None, DS=None, ScaIntKnotX=None, ScaIntKnotY=None,
+             ScaFi=None, ScaFj=None)
+    if a['SEPARATE_SCALING']:
+        a['ScaSpType'], a['DS'] = phdr['SSPTYPE'], int(phdr['SSPDEG'])
+        a['ScaIntKnotX'] = [phdr['SIKX%d' % i] for i in range(int(phdr['NSIKX']))]
+        a['ScaIntKnotY'] = [phdr['SIKY%d' % i] for i in range(int(phdr['NSIKY']))]
+        if a['DS'] > 0:
+            a['ScaFi'], a['ScaFj'] = int(phdr['SCAFI']), int(phdr['SCAFJ'])
+    return a
+
+
+class BSpline_MatchingKernel:
+    """Matching-kernel stamps [NPOINT][L0][L1] (standard delta basis) realised at the coordinates XY_q (FortranCoor)
+    (BSplineSFFT.py:4555-4723)."""
+
+    def __init__(self, XY_q, VERBOSE_LEVEL=2):
+        self.XY_q = XY_q
+        self.VERBOSE_LEVEL = VERBOSE_LEVEL
+
+    def FromArray(self, Solution, KerSpType, KerIntKnotX, KerIntKnotY, N0, N1, DK, L0, L1, Fi, Fj, Fpq,
+                  SEPARATE_SCALING, ScaSpType, ScaIntKnotX, ScaIntKnotY, DS, ScaFi, ScaFj):
+        sXY = np.array(self.XY_q, dtype=np.float64)
+        CX, CY = sXY[:, 0] / N0, sXY[:, 1] / N1                                 # ScaledFortranCoor
+        SfftKerDict, SfftScaDict = Read_SFFTSolution().FromArray(
+            Solution=Solution, KerSpType=KerSpType, N0=N0, N1=N1, DK=DK, L0=L0, L1=L1, Fi=Fi, Fj=Fj, Fpq=Fpq,
+            SEPARATE_SCALING=SEPARATE_SCALING, ScaSpType=ScaSpType, DS=DS, ScaFi=ScaFi, ScaFj=ScaFj)
+        w0, w1 = (L0 - 1) // 2, (L1 - 1) // 2
+        KerBASE = _spatial_at(N0, N1, KerSpType, DK, KerIntKnotX, KerIntKnotY, CX, CY)            # [Fij][NPOINT]
+        KerCOEFF = np.array([SfftKerDict[t] for t in _term_list(KerSpType, DK, Fi, Fj)])          # [Fij][L0][L1]
+        KerStack = np.tensordot(KerBASE, KerCOEFF, (0, 0))                                        # [NPOINT][L0][L1]
+        # modified delta basis -> pixels: the centre pixel is (scaling) - (sum of the off-centre pixels)
+        if SfftScaDict is None:
+            centre = KerStack[:, w0, w1].copy()
+            KerStack[:, w0, w1] = centre - (np.sum(KerStack, axis=(1, 2)) - centre)
+        else:
+            ScaBASE = _spatial_at(N0, N1, ScaSpType, DS, ScaIntKnotX, ScaIntKnotY, CX, CY)        # [ScaFij][NPOINT]
+            ScaCOEFF = np.array([SfftScaDict[t] for t in _term_list(ScaSpType, DS, ScaFi, ScaFj)])
+            KerStack[:, w0, w1] = ScaCOEFF @ ScaBASE - np.nansum(KerStack, axis=(1, 2))            # centre entries are NaN here
+        return KerStack
+
+    def FromFITS(self, FITS_Solution):
+        Solution, phdr = _read_solution_fits(FITS_Solution)
+        a = _solution_header_args(phdr)
+        if self.VERBOSE_LEVEL in [1, 2]:
+            print('\n --//--//--//--//-- SFFT CONFIGURATION --//--//--//--//-- ')
+            print('\n ---//--- %s Kernel | KerSpDegree %d | KerHW %d ---//---' % (a['KerSpType'], a['DK'], a['KerHW']))
+        return self.FromArray(Solution=Solution, KerSpType=a['KerSpType'], KerIntKnotX=a['KerIntKnotX'], KerIntKnotY=a['KerIntKnotY'],
+                              N0=a['N0'], N1=a['N1'], DK=a['DK'], L0=a['L0'], L1=a['L1'], Fi=a['Fi'], Fj=a['Fj'], Fpq=a['Fpq'],
+                              SEPARATE_SCALING=a['SEPARATE_SCALING'], ScaSpType=a['ScaSpType'], ScaIntKnotX=a['ScaIntKnotX'],
+                              ScaIntKnotY=a['ScaIntKnotY'], DS=a['DS'], ScaFi=a['ScaFi'], ScaFj=a['ScaFj'])
+
+
+class ConvKernel_Convertion:
+    """CSZ / iCSZ as in BSplineSFFT.py:4725-4753 (iCSZ returns the lost weight as well, unlike sfft/utils/ConvKernelConvertion.py)."""
+
+    def CSZ(ConvKernel, N0, N1):
+        L0, L1 = ConvKernel.shape
+        out = np.zeros((N0, N1), dtype=np.result_type(ConvKernel, np.float64))
+        out[:L0, :L1] = ConvKernel
+        return np.roll(out, (-((L0 - 1) // 2), -((L1 - 1) // 2)), axis=(0, 1))
+
+    def iCSZ(KIMG, L0, L1):
+        back = np.roll(KIMG, ((L0 - 1) // 2, (L1 - 1) // 2), axis=(0, 1))
+        ConvKernel = back[:L0, :L1]
+        return ConvKernel, 1.0 - np.sum(np.abs(ConvKernel)) / np.sum(np.abs(back))
+
+
+class BSpline_DeCorrelation:
+    @staticmethod
+    def BDC(MK_JLst, SkySig_JLst, MK_ILst=[], SkySig_ILst=[], MK_Fin=None, KERatio=2.0, DENO_CLIP_RATIO=100000.0, VERBOSE_LEVEL=2,
+            CUDA_DEVICE=None):
+        """Noise-decorrelation kernel from realised matching kernels (BSplineSFFT.py:4755-4868): as DeCorrelation_Calculator.DCC
+        plus a floor of max / DENO_CLIP_RATIO on the Fourier-space denominator.  Host arrays in, host array out; the
+        transforms run on the GPU (sfft_fft2_r2c / sfft_ifft2_c2r)."""
+        import math
+        from .utils.PureCupyDeCorrelationCalculator import PureCupy_DeCorrelation_Calculator
+        NumI, NumJ = len(MK_ILst), len(MK_JLst)
+        if NumI == 0:
+            if NumJ < 2:
+                raise Exception('MeLOn ERROR: %s' % 'Image-Stacking Mode requires at least 2 J-images!')
+            if np.sum([MKj is not None for MKj in MK_JLst]) == 0:
+                raise Exception('MeLOn ERROR: %s' % 'Image-Stacking Mode requires at least 1 not-None J-kernel!')
+            MK_Queue = list(MK_JLst)
+        else:
+            if NumJ == 0:
+                raise Exception('MeLOn ERROR: %s' % 'Image-Subtraction Mode requires at least 1 I-image & 1 J-image!')
+            if np.sum([MK is not None for MK in list(MK_JLst) + list(MK_ILst) + [MK_Fin]]) == 0:
+                raise Exception('MeLOn ERROR: %s' % 'Image-Subtraction Mode requires at least 1 not-None J/I/Fin-kernel!')
+            MK_Queue = list(MK_JLst) + [MK_Fin] + list(MK_ILst)
+        shapes = np.array([MK.shape for MK in MK_Queue if MK is not None])
+        L_KDeCo = [int(round(KERatio * shapes[:, ax].max())) for ax in (0, 1)]
+        L_KDeCo = [L + 1 if L % 2 == 0 else L for L in L_KDeCo]
+        if VERBOSE_LEVEL in [1, 2]:
+            print('MeLOn CheckPoint: %s' % ('DeCorrelation Kernel with size [%d, %d]' % tuple(L_KDeCo)))
+        N0, N1 = [2 ** (math.ceil(np.log2(shapes[:, ax].max())) + 1) for ax in (0, 1)]   # "trivial image size" (:4805-4806)
+        dev = torch.device("cuda", torch.cuda.current_device() if CUDA_DEVICE is None else int(CUDA_DEVICE))
+        tg = lambda K: None if K is None else torch.from_numpy(np.ascontiguousarray(K, dtype=np.float64)).to(dev)
+        KDeCo = PureCupy_DeCorrelation_Calculator.PCDC(
+            NX_IMG=N0, NY_IMG=N1, KERNEL_GPU_JQueue=[tg(K) for K in MK_JLst], BKGSIG_JQueue=list(SkySig_JLst),
+            KERNEL_GPU_IQueue=[tg(K) for K in MK_ILst], BKGSIG_IQueue=list(SkySig_ILst), MATCH_KERNEL_GPU=tg(MK_Fin),
+            REAL_OUTPUT=True, REAL_OUTPUT_SIZE=tuple(L_KDeCo), NORMALIZE_OUTPUT=True, VERBOSE_LEVEL=VERBOSE_LEVEL,
+            CUDA_DEVICE=dev.index, DENO_CLIP_RATIO=DENO_CLIP_RATIO)
+        return KDeCo.cpu().numpy()
+
+
+class BSpline_GridConvolve:
+    """Grid-wise space-varying convolution (BSplineSFFT.py:4870-5008): AllocatedL labels compact boxes of PixA_obj, KerStack[label]
+    is the kernel of each box.  Only the GPU variant exists here (`sfft_grid_convolve`: direct sums in fp64, which is what both
+    branches of the reference's GSVC_GPU compute -- `use_fft` only chooses how)."""
+
+    def __init__(self, PixA_obj, AllocatedL, KerStack, nan_fill_value=0.0, use_fft=False, normalize_kernel=True):
+        PixA_in = np.array(PixA_obj, dtype=np.float64)
+        PixA_in[np.isnan(PixA_in)] = nan_fill_value
+        self.PixA_in = PixA_in
+        self.AllocatedL = AllocatedL
+        self.KerStack = KerStack
+        self.use_fft = use_fft
+        self.normalize_kernel = normalize_kernel
+
+    def GSVC_CPU(self, nproc=32):
+        raise Exception("MeLOn ERROR: sfft_amd only provides the GPU variant (GSVC_GPU); there is no CPU path")
+
+    def GSVC_GPU(self, CUDA_DEVICE='0', CLEAN_GPU_MEMORY=False, nproc=32):
+        import ctypes
+        from . import _lib
+        dev = torch.device("cuda", int(CUDA_DEVICE))
+        N0, N1 = self.PixA_in.shape
+        KerStack = np.asarray(self.KerStack, dtype=np.float64)
+        Nseg, L0, L1 = KerStack.shape
+        if self.normalize_kernel:
+            KerStack = KerStack / np.sum(KerStack, axis=(1, 2))[:, np.newaxis, np.newaxis]
+        lab = np.ascontiguousarray(self.AllocatedL, dtype=np.int32)
+        assert lab.shape == (N0, N1) and lab.min() >= 0 and lab.max() < Nseg
+        d_in = torch.from_numpy(np.ascontiguousarray(self.PixA_in)).to(dev)
+        d_lab = torch.from_numpy(lab).to(dev)
+        d_ker = torch.from_numpy(np.ascontiguousarray(KerStack)).to(dev)
+        d_out = torch.empty((N0, N1), dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().sfft_grid_convolve(d_in.data_ptr(), d_lab.data_ptr(), d_ker.data_ptr(), N0, N1, Nseg, L0, L1,
+                                                 d_out.data_ptr(), dev.index,
+                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return d_out.cpu().numpy()

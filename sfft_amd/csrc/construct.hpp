@@ -183,4 +183,54 @@ __global__ void copy_spectrum(const cplx* __restrict__ src, cplx* __restrict__ d
     if (m < Nh) dst[(size_t)l * Nh + m] = src[sl.at(l, m)];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grid-wise space-varying convolution (BSpline_GridConvolve.GSVC_GPU, sfft/BSplineSFFT.py:4951-5006):
+//   out(x, y) = sum_ab K[label(x, y)][a][b] * in(x + w0 - a, y + w1 - b),   w = (L - 1) / 2,   zeros beyond the image
+// (= scipy / cupyx convolve2d(mode='same', boundary='fill') of every box segment with its own kernel; the reference
+// extends each box by w + 1 pixels before convolving, so inside a box only the image border ever supplies zeros).
+// 16 x 16 output pixels per workgroup; the input tile with its halo sits in LDS; a wave whose pixels share one label reads
+// the kernel through scalar loads.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) grid_convolve(const double* __restrict__ in, const int* __restrict__ labels,
+                                                     const double* __restrict__ kers, int N0, int N1, int Nseg, int L0, int L1,
+                                                     double* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);
+    const int w0 = (L0 - 1) / 2, w1 = (L1 - 1) / 2;
+    const int TH = 16 + L0 - 1, TW = 16 + L1 - 1;
+    const int x0 = blockIdx.y * 16, y0 = blockIdx.x * 16;
+    const int ox = x0 - (L0 - 1 - w0), oy = y0 - (L1 - 1 - w1);       // image coordinates of tile[0][0]
+    for (int e = threadIdx.x; e < TH * TW; e += 256) {
+        const int tx = e / TW, ty = e - tx * TW;
+        const int gx = ox + tx, gy = oy + ty;
+        tile[e] = (gx >= 0 && gx < N0 && gy >= 0 && gy < N1) ? in[(size_t)gx * N1 + gy] : 0.0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x >> 4, ly = threadIdx.x & 15;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = x < N0 && y < N1;
+    int lab = inside ? labels[(size_t)x * N1 + y] : -1;
+    if (lab >= Nseg) lab = -1;
+    const int lab_u = __builtin_amdgcn_readfirstlane(lab);
+    double acc = 0.0;
+    // tile row of in(x + w0 - a, .) is lx + (L0 - 1) - a; column of in(., y + w1 - b) is ly + (L1 - 1) - b
+    if (__all(lab == lab_u)) {
+        if (lab_u >= 0) {
+            const double* __restrict__ K = kers + (size_t)lab_u * L0 * L1;          // wave-uniform
+            for (int a = 0; a < L0; ++a) {
+                const double* trow = tile + (lx + (L0 - 1) - a) * TW + ly + (L1 - 1);
+                for (int b = 0; b < L1; ++b) acc = fma(K[a * L1 + b], trow[-b], acc);
+            }
+        }
+    } else if (lab >= 0) {
+        const double* __restrict__ K = kers + (size_t)lab * L0 * L1;
+        for (int a = 0; a < L0; ++a) {
+            const double* trow = tile + (lx + (L0 - 1) - a) * TW + ly + (L1 - 1);
+            for (int b = 0; b < L1; ++b) acc = fma(K[a * L1 + b], trow[-b], acc);
+        }
+    }
+    if (inside) out[(size_t)x * N1 + y] = acc;
+}
+
 #endif

@@ -1281,6 +1281,22 @@ extern "C" int sfft_half_to_full_real(const double* d_half, double* d_full, int 
     return SFFT_OK;
 }
 
+// BSpline_GridConvolve.GSVC_GPU (sfft/BSplineSFFT.py:4951-5006): every pixel is convolved with the kernel of its segment
+extern "C" int sfft_grid_convolve(const double* d_in, const int* d_labels, const double* d_kerstack, int N0, int N1, int Nseg,
+                                  int L0, int L1, double* d_out, int device, void* stream)
+{
+    if (!d_in || !d_labels || !d_kerstack || !d_out) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    if (N0 < 1 || N1 < 1 || Nseg < 1 || L0 < 1 || L1 < 1) return set_err(SFFT_ERR_INVALID_ARG, "bad size");
+    const size_t lds = (size_t)(16 + L0 - 1) * (16 + L1 - 1) * sizeof(double);
+    if (lds > 150 * 1024) return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "kernel stamp too large for the on-chip tile of this build");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFuncSetAttribute((const void*)grid_convolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(grid_convolve, dim3((N1 + 15) / 16, (N0 + 15) / 16), dim3(256), lds, (hipStream_t)stream, d_in, d_labels, d_kerstack,
+                       N0, N1, Nseg, L0, L1, d_out);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
 extern "C" int sfft_dbg_forward_spectrum(sfft_plan* p, const double* d_I, int i, int j, double* d_spec_out, void* stream)
 {
     if (!p || !d_I || !d_spec_out) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");

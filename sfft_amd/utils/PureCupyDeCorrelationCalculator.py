@@ -13,8 +13,10 @@ class PureCupy_DeCorrelation_Calculator:
     @staticmethod
     def PCDC(NX_IMG, NY_IMG, KERNEL_GPU_JQueue, BKGSIG_JQueue, KERNEL_GPU_IQueue=[], BKGSIG_IQueue=[],
              MATCH_KERNEL_GPU=None, REAL_OUTPUT=False, REAL_OUTPUT_SIZE=None, NORMALIZE_OUTPUT=True, VERBOSE_LEVEL=2,
-             CUDA_DEVICE=None):
-        """Decorrelation kernel: Fourier-space (REAL_OUTPUT=False, full [NX_IMG][NY_IMG] float64) or real-space."""
+             CUDA_DEVICE=None, DENO_CLIP_RATIO=None):
+        """Decorrelation kernel: Fourier-space (REAL_OUTPUT=False, full [NX_IMG][NY_IMG] float64) or real-space.
+        DENO_CLIP_RATIO (not in the reference's PCDC; used by BSpline_DeCorrelation.BDC, sfft/BSplineSFFT.py:4845-4847): floor the
+        denominator at max / ratio."""
         NUM_I, NUM_J = len(KERNEL_GPU_IQueue), len(KERNEL_GPU_JQueue)
         assert NUM_J > 0
         if NUM_I == 0:
@@ -44,6 +46,8 @@ class PureCupy_DeCorrelation_Calculator:
         FMK = spectrum(MATCH_KERNEL_GPU)
         for K, BKGSIG in zip(KERNEL_GPU_IQueue, BKGSIG_IQueue):
             abs2_accumulate(FDENO, spectrum(K), float(BKGSIG) ** 2 / NUM_I ** 2, FMK)
+        if DENO_CLIP_RATIO is not None:
+            FDENO = torch.clamp_min(FDENO, float(FDENO.max()) / float(DENO_CLIP_RATIO))   # the half spectrum holds every distinct value
         FK_half = rsqrt(FDENO)                                  # 1 / sqrt(denominator): real & conjugate-symmetric
         if not REAL_OUTPUT:
             FKDECO = half_to_full_real(FK_half, NY_IMG)

@@ -9,6 +9,8 @@ Tolerances (fp64; SURVEY.md 8c, restated in DESIGN.md):
   apply-only DIFF            pixel RMS error <= 1e-10 * RMS(J)
   end-to-end DIFF            pixel RMS error <= 1e-6  * RMS(DIFF_ref)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -661,3 +663,74 @@ def test_pcdc_and_fft_convolve_match_oracle(dev):
     out = FK.FFT_CONVOLVE(t(img), t(K11), PAD_FILL_VALUE=1.0, NAN_FILL_VALUE=0.0, NORMALIZE_KERNEL=True).cpu().numpy()
     ref = DO.fft_convolve(img.copy(), K11, 1.0, 0.0, True)
     assert out.shape == img.shape and np.max(np.abs(out - ref)) <= 1e-11 * np.max(np.abs(ref))
+
+
+# ------------------------------------------------------------------------------------------------
+# (g) B-spline post-processing on the GPU: decorrelation kernel from realised kernels, grid convolution
+# ------------------------------------------------------------------------------------------------
+def test_bspline_decorrelation_matches_reference(dev):
+    """BSpline_DeCorrelation.BDC against the reference's own output (tests/golden/make_golden_bspline_post.py)."""
+    from sfft_amd.BSplineSFFT import BSpline_DeCorrelation
+    from _golden import GOLDEN_DIR
+    G = np.load(os.path.join(GOLDEN_DIR, "bspline_post_cases.npz"), allow_pickle=False)
+    mkj, mki, mkf = G["bdc_mkj"], G["bdc_mki"], G["bdc_mkf"]
+    out = BSpline_DeCorrelation.BDC(MK_JLst=[mkj], SkySig_JLst=[3.0], MK_ILst=[mki], SkySig_ILst=[2.0], MK_Fin=mkf, KERatio=2.0,
+                                    DENO_CLIP_RATIO=100000.0, VERBOSE_LEVEL=0, CUDA_DEVICE=dev.index)
+    assert out.shape == G["bdc_sub"].shape and np.abs(out - G["bdc_sub"]).max() <= 1e-11 * np.abs(G["bdc_sub"]).max()
+    out = BSpline_DeCorrelation.BDC(MK_JLst=[None], SkySig_JLst=[3.0], MK_ILst=[mki], SkySig_ILst=[2.0], MK_Fin=None, KERatio=1.5,
+                                    DENO_CLIP_RATIO=1000.0, VERBOSE_LEVEL=0, CUDA_DEVICE=dev.index)
+    assert out.shape == G["bdc_sub_nofin"].shape and np.abs(out - G["bdc_sub_nofin"]).max() <= 1e-11 * np.abs(G["bdc_sub_nofin"]).max()
+    out = BSpline_DeCorrelation.BDC(MK_JLst=[mkj, None, mkf], SkySig_JLst=[3.0, 2.5, 4.0], KERatio=2.0, VERBOSE_LEVEL=0, CUDA_DEVICE=dev.index)
+    assert out.shape == G["bdc_stack"].shape and np.abs(out - G["bdc_stack"]).max() <= 1e-11 * np.abs(G["bdc_stack"]).max()
+    with pytest.raises(Exception, match="at least 2 J-images"):
+        BSpline_DeCorrelation.BDC(MK_JLst=[mkj], SkySig_JLst=[3.0], VERBOSE_LEVEL=0, CUDA_DEVICE=dev.index)
+
+
+@pytest.mark.parametrize("shape,TiHW,L,norm", [((200, 170), 10, (7, 7), True), ((96, 131), 7, (5, 9), False), ((64, 64), 31, (21, 21), True)])
+def test_grid_convolve_matches_oracle(dev, shape, TiHW, L, norm):
+    """BSpline_GridConvolve.GSVC_GPU against the scipy restatement of the reference's loop (parity unpinned: the reference
+    needs CuPy / astropy); both of its branches (direct and FFT) are reproduced by the same direct sums."""
+    from oracle import gridconv_oracle as GO
+    from sfft_amd.BSplineSFFT import BSpline_GridConvolve
+    rng = np.random.default_rng(shape[0])
+    N0, N1 = shape
+    img = rng.normal(size=shape) + 10.0
+    img[3, 5] = np.nan
+    lab, XY = GO.tile_labels(N0, N1, TiHW)
+    Nseg = int(lab.max()) + 1
+    kers = rng.uniform(0.1, 1.0, size=(Nseg, L[0], L[1]))           # asymmetric kernels: convolution, not correlation
+    gc = BSpline_GridConvolve(img, lab, kers, nan_fill_value=0.0, use_fft=False, normalize_kernel=norm)
+    out = gc.GSVC_GPU(CUDA_DEVICE=str(dev.index))
+    ref = GO.gsvc(gc.PixA_in, lab, kers, normalize_kernel=norm, use_fft=False)
+    assert np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
+    ref_fft = GO.gsvc(gc.PixA_in, lab, kers, normalize_kernel=norm, use_fft=True)
+    assert np.abs(out - ref_fft).max() <= 1e-10 * np.abs(ref).max()
+    with pytest.raises(Exception, match="GPU variant"):
+        gc.GSVC_CPU()
+
+
+def test_matching_kernel_grid_convolve_reproduces_sfft_model(dev):
+    """Ties the post-processing to the core: realise the solved kernel on a tile grid, grid-convolve the reference image with
+    it, and compare with what the subtraction itself removed, J - DIFF - background (spatially constant kernel -> the tile
+    kernels are all equal and the two agree to rounding away from the image border, where SFFT wraps and GSVC zero-fills)."""
+    from oracle import gridconv_oracle as GO
+    from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC, GeneralSFFTSubtract as BGSS, BSpline_MatchingKernel, BSpline_GridConvolve
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1, w = 160, 128, 3
+    pair = make_pair(N0, N1, seed=19, mask=False, density=300.0)
+    kw = dict(KerSpType="Polynomial", KerSpDegree=0, SEPARATE_SCALING=False, BkgSpType="Polynomial", BkgSpDegree=1)
+    cfg = BSSC.SSC(NX=N0, NY=N1, KerHW=w, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index, **kw)
+    sol, D, _ = BGSS.GSS(pair["REF"], pair["SCI"], pair["REF"], pair["SCI"], cfg, VERBOSE_LEVEL=0)
+    P = cfg[0]
+    lab, XY = GO.tile_labels(N0, N1, 12)
+    ks = BSpline_MatchingKernel(XY, VERBOSE_LEVEL=0).FromArray(
+        Solution=sol, KerSpType="Polynomial", KerIntKnotX=[], KerIntKnotY=[], N0=N0, N1=N1, DK=0, L0=P["L0"], L1=P["L1"], Fi=-1, Fj=-1,
+        Fpq=P["Fpq"], SEPARATE_SCALING=False, ScaSpType=None, ScaIntKnotX=None, ScaIntKnotY=None, DS=None, ScaFi=None, ScaFj=None)
+    conv = BSpline_GridConvolve(pair["REF"], lab, ks, normalize_kernel=False).GSVC_GPU(CUDA_DEVICE=str(dev.index))
+    cx = (np.arange(N0)[:, None] + 1.0) / N0
+    cy = (np.arange(N1)[None, :] + 1.0) / N1
+    b = sol[P["Fijab"]:]
+    bkg = b[0] + b[1] * cy + b[2] * cx                  # REF_pq of degree 1: (0,0), (0,1), (1,0)
+    model = pair["SCI"] - D - bkg
+    inner = (slice(w, N0 - w), slice(w, N1 - w))
+    assert np.abs(conv[inner] - model[inner]).max() <= 1e-9 * np.abs(model).max()
