@@ -99,24 +99,27 @@ __global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, 
     const double* __restrict__ src = a.src[pfirst];
     const double* r0p = src + (size_t)l0 * N1;
     const double* r1p = src + (size_t)(has1 ? l1 : l0) * N1;
+    // (selects on wave-uniform conditions inside these unrolled loops become one scalar branch per element: the second row
+    //  is read unconditionally -- r1p falls back to row l0 -- and scaled by 0, and missing weights point at a table of ones)
+    const double h1 = has1 ? 1.0 : 0.0;
     double x0[16], x1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = j + 256 * r;
         x0[r] = r0p[n];
-        x1[r] = has1 ? r1p[n] : 0.0;
+        x1[r] = r1p[n] * h1;
     }
     const double hs = 0.5 * scale;
     for (int pp = 0; pp < pcount; ++pp) {
         const int plane = pfirst + pp;
         const double* __restrict__ wx = a.wx[plane];
         const double* __restrict__ wy = a.wy[plane];
-        const double cx0 = wx ? wx[l0] : 1.0;
-        const double cx1 = (wx && has1) ? wx[l1] : 1.0;
+        const double cx0 = wx[l0];
+        const double cx1 = wx[has1 ? l1 : l0];
         cplx u[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const double cyp = wy ? wy[j + 256 * r] : 1.0;
+            const double cyp = wy[j + 256 * r];
             u[r] = make_double2(x0[r] * (cx0 * cyp), x1[r] * (cx1 * cyp));
         }
         if (pp > 0) __syncthreads();            // the previous plane's partner reads are done

@@ -111,6 +111,7 @@ struct sfft_plan {
     // workspaces
     cplx* d_spec = nullptr;             // [Fij+1][N0][Nhp]   (plane Fij: J in solve, FD in apply)
     cplx *d_big1 = nullptr, *d_big2 = nullptr, *d_colscr = nullptr;   // work arrays of the four-step path
+    double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
     hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr; int no_overlap = 0;
@@ -354,6 +355,11 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         }
         PLAN_HIP(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
         PLAN_HIP(hipEventCreateWithFlags(&p->ev_pre, hipEventDisableTiming));
+    }
+    {
+        std::vector<double> ones((size_t)std::max(N0, N1), 1.0);
+        PLAN_TRY(dev_alloc(p, &p->d_ones, ones.size()));
+        PLAN_HIP(hipMemcpy(p->d_ones, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     {   // basis tables on the device
         PLAN_TRY(dev_alloc(p, &p->d_kbx, (size_t)BS.nkx * N0));
@@ -708,7 +714,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -837,13 +843,15 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
                                p->N0, p->N1, p->Nh, p->Nhp, p->scale);
         }
     } else if (fast_axis(p->ax1) && !p->no_fast_fft) {
+        RowsArgs rw = ra;                       // unweighted planes (J, plain FFTs) get the table of ones: branch-free kernel
+        for (int k = 0; k < nplanes; ++k) { if (!rw.wx[k]) rw.wx[k] = p->d_ones; if (!rw.wy[k]) rw.wy[k] = p->d_ones; }
         RowGroups grp; grp.ngroups = 0;
         for (int k = 0; k < nplanes; ++k) {
             if (k > 0 && ra.src[k] == ra.src[k - 1]) ++grp.count[grp.ngroups - 1];
             else { grp.first[grp.ngroups] = k; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
         }
         const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
-        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp, dst,
+        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, rw, grp, dst,
                            p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     else
