@@ -176,6 +176,51 @@ __global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, in
     }
 }
 
+// Forward column pass of the weighted planes.  Every spatial term is  I * fx(row) * fy(col):  the row pass only applies fy
+// (one "stage" plane per distinct column factor), and here each output plane (fx, fy) is the column transform of its stage
+// plane times fx(row).  For the polynomial basis of order 2 that is 3 row transforms for 6 output planes (4 for 7 with J).
+// One workgroup per (tile, output).  The 1-D grid is de-interleaved per XCD with the output index fastest, so the
+// workgroups that read the same stage tile -- and the neighbouring tiles that share its 128-byte lines -- run back to back
+// on one XCD: the tile comes from HBM once and from that XCD's L2 afterwards.
+#define COLG_MAX_OUT 32
+struct ColOuts {
+    int nout;
+    int stage_plane[COLG_MAX_OUT];                // source plane in the stage buffer
+    int out_plane[COLG_MAX_OUT];                  // destination plane
+    const double* wx[COLG_MAX_OUT];               // [N0] row factor
+};
+
+__global__ void __launch_bounds__(512) cols_fwd_weighted_4096(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int ncols,
+                                                              int Nhp, SpecLayout lay, const cplx* __restrict__ tw, int npairs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
+    const int N0 = 4096;
+    const int c = threadIdx.x & 1, j = threadIdx.x >> 1;
+    const int total = npairs * g.nout;
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || logical >= total) return;
+    const int cp = logical / g.nout, o = logical - cp * g.nout;
+    const int col = 2 * cp + c;
+    const bool ok = col < ncols;
+    const size_t plane_sz = (size_t)N0 * Nhp, cofs = lay.col(ok ? col : 0), rs = (size_t)lay.rstride;
+    const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * plane_sz + cofs;
+    const double* __restrict__ w = g.wx[o];
+    cplx u[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const cplx z = src[(size_t)(j + 256 * r) * rs];         // (!ok: column 0 again; nothing is stored)
+        const double f = w[j + 256 * r];
+        u[r] = make_double2(z.x * f, z.y * f);
+    }
+    fft4096_core(u, j, lds + c * (F4K_LDS + 4), tw);
+    if (!ok) return;
+    cplx* __restrict__ dst = out + (size_t)g.out_plane[o] * plane_sz + cofs;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) dst[(size_t)(j + 256 * sx) * rs] = u[R16_OUT(sx)];
+}
+
 // rows, half complex -> real (N1 = 4096), two rows per transform, DIFF epilogue (see rows_c2r_diff)
 template <int NQ>
 __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict__ FD, const double* __restrict__ J,

@@ -113,6 +113,8 @@ struct sfft_plan {
     cplx *d_big1 = nullptr, *d_big2 = nullptr, *d_colscr = nullptr;   // work arrays of the four-step path
     double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
+    cplx* d_stage = nullptr;            // fast path: row-pass output, one plane per distinct (image, column factor) (lazy)
+    int n_stage_alloc = 0;
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
     hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr; int no_overlap = 0;
     const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
@@ -130,6 +132,7 @@ struct sfft_plan {
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
+    int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     int timing = 0;
     hipEvent_t ev[SFFT_ST_COUNT][2];
@@ -312,6 +315,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     sfft_plan* p = new sfft_plan();
     p->dev = device;
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
+    if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
     if (BS.mode == 3) {
@@ -416,6 +420,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -714,7 +719,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -868,9 +873,75 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
 
 // forward spectra of the Fij kernel-basis planes of image d_I (and, when d_J is given, of d_J itself as plane Fij)
 // and, with_sca, of the scaling planes (planes Fij + 1 ...)
+// Fast path (both axes 4096): the row pass runs once per distinct (image, column factor) into the stage buffer, the weighted
+// column pass transforms stage plane x row factor for every output plane (see cols_fwd_weighted_4096).
+static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca,
+                                       int st_rows, int st_cols)
+{
+    struct Out { int plane; const double* wx; };
+    struct Stage { const double* src; const double* wy; std::vector<Out> outs; };
+    std::vector<Stage> stages;
+    auto add = [&](const double* src, const double* wy, int plane, const double* wx) {
+        for (auto& st : stages) if (st.src == src && st.wy == wy) { st.outs.push_back({plane, wx}); return; }
+        stages.push_back({src, wy, {{plane, wx}}});
+    };
+    for (int k = 0; k < p->Fij; ++k)
+        add(d_I, p->d_kby + (size_t)p->kpair[2 * k + 1] * p->N1, k, p->d_kbx + (size_t)p->kpair[2 * k] * p->N0);
+    if (d_J) add(d_J, p->d_ones, p->Fij, p->d_ones);
+    if (with_sca && d_J)
+        for (int sI = 0; sI < p->nsca; ++sI)
+            add(d_I, p->d_sby + (size_t)p->spair[2 * sI + 1] * p->N1, p->Fij + 1 + sI, p->d_sbx + (size_t)p->spair[2 * sI] * p->N0);
+    // stages that read the same image must be consecutive for the row kernel's one-read-per-image grouping
+    std::stable_sort(stages.begin(), stages.end(), [&](const Stage& a, const Stage& b) { return (a.src == d_I) > (b.src == d_I); });
+    const int nst = (int)stages.size();
+    if (nst > p->n_stage_alloc) {
+        if (p->d_stage) { HIPCHK(hipStreamSynchronize(s)); hipFree(p->d_stage); p->d_stage = nullptr; }
+        int rc = dev_alloc(p, &p->d_stage, (size_t)nst * p->N0 * p->Nhp);
+        if (rc) return rc;
+        p->n_stage_alloc = nst;
+    }
+    const size_t plane_sz = (size_t)p->N0 * p->Nhp;
+    if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
+    const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
+    for (int k0 = 0; k0 < nst; k0 += SFFT_MAX_PLANES) {
+        const int n = std::min(SFFT_MAX_PLANES, nst - k0);
+        RowsArgs ra;
+        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = p->d_ones; ra.wy[u] = p->d_ones; }
+        RowGroups grp; grp.ngroups = 0;
+        for (int u = 0; u < n; ++u) {
+            ra.src[u] = stages[k0 + u].src; ra.wy[u] = stages[k0 + u].wy;
+            if (u > 0 && ra.src[u] == ra.src[u - 1]) ++grp.count[grp.ngroups - 1];
+            else { grp.first[grp.ngroups] = u; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
+        }
+        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp,
+                           p->d_stage + (size_t)k0 * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
+    }
+    LAUNCH_CHECK();
+    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
+    if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
+    const int npairs = (p->Nh + 1) / 2;
+    int k = 0;
+    while (k < nst) {          // whole stages per launch, so that a stage tile's readers sit next to each other in the grid
+        ColOuts g; memset(&g, 0, sizeof(g));
+        while (k < nst && g.nout + (int)stages[k].outs.size() <= COLG_MAX_OUT) {
+            for (const Out& o : stages[k].outs) { g.stage_plane[g.nout] = k; g.out_plane[g.nout] = o.plane; g.wx[g.nout] = o.wx; ++g.nout; }
+            ++k;
+        }
+        if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
+        const int total = npairs * g.nout;
+        hipLaunchKernelGGL(cols_fwd_weighted_4096, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
+                           p->Nh, p->Nhp, p->lay, p->ax0.tw, npairs);
+    }
+    LAUNCH_CHECK();
+    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
+    return SFFT_OK;
+}
+
 static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca = false,
                                 int st_rows = -1, int st_cols = -1)
 {
+    if (!p->no_fast_fft && !p->no_staged && fast_axis(p->ax0) && fast_axis(p->ax1))
+        return forward_basis_planes_staged(p, d_I, d_J, dst, s, with_sca, st_rows, st_cols);
     const int total = p->Fij + (d_J ? 1 : 0) + ((with_sca && d_J) ? p->nsca : 0);
     const size_t plane_sz = (size_t)p->N0 * p->Nhp;
     for (int k0 = 0; k0 < total; k0 += SFFT_MAX_PLANES) {
