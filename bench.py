@@ -15,8 +15,8 @@ per step (weak scaling, no data-path collective); the only collective is the gat
 end (sfft_amd/sharding.py).
 
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
-  roofline     -- the dominant KERNEL by total time per pair, the column pass of the 2-D FFTs (cols_c2c_4096: three
-                  launches per pair): algorithmic bytes of the timed launch / its duration (HIP events on the launch
+  roofline     -- the dominant KERNEL by total time per pair, the column pass of the forward 2-D FFTs
+                  (cols_fwd_weighted_4096: two launches per pair): algorithmic bytes of the timed launch / its duration (HIP events on the launch
                   stream) against the 8 TB/s HBM3E peak; `roofline_greek` is the same for the second kernel, the Omega
                   pass of the Greek stage, which is bound by fp64 FMA issue, not by HBM
   cpu_baseline -- the numpy/scipy oracle (port of the reference's Numpy backend) timed on this host on a
@@ -52,8 +52,10 @@ def alg_bytes(N0, N1, w, DK, DB):
     n_gamp = Fij * DB                                   # dense Gamma column-factor passes (p >= 1); they read A only
     out = {
         "prelim_solve": (Fij + 1) * fwd_plane + r * P,  # + row moments of J
-        "fwd_rows": 2 * r * P + (Fij + 1) * spec,       # rows_r2c: each image read once (all its planes from one read), spectra written
-        "fwd_cols": (Fij + 1) * 2 * spec,               # cols_c2c on the solve pass: every plane read + written in place
+        # forward transforms of the solve pass as built: one row transform per distinct column factor (DK + 1 of them, + J) into
+        # stage planes; the column pass reads every stage plane (from HBM once, its other readers hit L2) and writes Fij + 1 planes
+        "fwd_rows": 2 * r * P + (DK + 2) * spec,
+        "fwd_cols": (DK + 2) * spec + (Fij + 1) * spec,
         # Greek stage 1 as built: all passes of a (64-column x row-chunk) tile run on one XCD back to back, so each of the
         # Fij (+ J) planes is streamed from HBM once and re-read from that XCD's L2; partial lag sums are written
         "greek_g1": Fij * spec,
@@ -201,7 +203,7 @@ def main():
         except Exception:
             pass
 
-        KERNEL_OF = {"fwd_cols": "cols_c2c_4096" if N == 4096 else "cols_c2c / strided_dft",
+        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096" if N == 4096 else "cols_c2c / strided_dft",
                      "fwd_rows": "rows_r2c_4096" if N == 4096 else "rows_r2c", "greek_g1": "greek_g1<16, 2> (Omega passes)",
                      "greek_g1b": "greek_g1<8, 2> (Theta, Gamma passes)", "construct": "construct_fd"}
 
@@ -231,9 +233,9 @@ def main():
                        "pairs_per_step": world * S, "pairs_in_flight_per_gpu": S, "plan_create_s": plan_s,
                        "solver": {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")},
             "stage_ms": stage_ms,
-            "roofline": dict(roof(iso_stage), measured="HIP events on the launch stream around the kernel (the %d-plane forward "
-                             "launch of the solve pass), %d launches with one pair in flight right after the timed region "
-                             "(same process, same buffers)" % (ab["fwd_cols"] // (2 * 16 * N * (N // 2 + 1)), n_iso),
+            "roofline": dict(roof(iso_stage), measured="HIP events on the launch stream around the kernel (the forward launch of the solve pass: "
+                             "%d stage planes in, %d planes out), %d launches with one pair in flight right after the timed region "
+                             "(same process, same buffers)" % (args.dk + 2, (args.dk + 1) * (args.dk + 2) // 2 + 1, n_iso),
                              kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "construct")}),
             "roofline_greek": dict(roof_flops(iso_stage), measured="same events, same launches"),
             "roofline_timed_region": dict(roof(stage_ms), measured="same events on stream 0 inside the timed region; durations "

@@ -42,10 +42,10 @@ doc = {
               "streaming reads on gfx950, MI355X_MICROARCH.md), WRITE_SIZE unchanged (calibration: rows_c2r_diff_4096 writes "
               "131072.0 KB = exactly the 134217728-byte DIFF image).",
     "source_files": [sys.argv[1].split("/")[-1], sys.argv[2].split("/")[-1]],
-    # cols_c2c_4096: launches of 7, 6 and 1 planes per pair -> the 7-plane launch is 7 / (14/3) of the mean
-    "fwd_cols": entry(["cols_c2c_4096"], 7.0 / (14.0 / 3.0), "mean over the 7-, 6- and 1-plane launches scaled to the 7-plane launch"),
-    # rows_r2c_4096: solve launch (2 images in, 7 spectra out) vs apply launch (1 in, 6 out)
-    "fwd_rows": entry(["rows_r2c_4096"], (2 * img + 7 * spec) / (0.5 * (2 * img + 7 * spec + img + 6 * spec)),
+    # cols_fwd_weighted_4096: solve launch (4 stage planes in, 7 planes out) vs apply launch (3 in, 6 out)
+    "fwd_cols": entry(["cols_fwd_weighted_4096"], 11.0 / (0.5 * (11.0 + 9.0)), "mean over the solve and apply launches scaled to the solve launch"),
+    # rows_r2c_4096: solve launch (2 images in, 4 stage planes out) vs apply launch (1 in, 3 out)
+    "fwd_rows": entry(["rows_r2c_4096"], (2 * img + 4 * spec) / (0.5 * (2 * img + 4 * spec + img + 3 * spec)),
                       "mean over the solve and apply launches scaled to the solve launch"),
     "greek_g1": entry(["greek_g1<16, 2>"]),
     "greek_g1b": entry(["greek_g1<8, 2>", "greek_g1_row0"]),
