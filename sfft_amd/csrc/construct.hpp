@@ -107,6 +107,124 @@ __global__ void __launch_bounds__(64) construct_fd(const cplx* __restrict__ FI, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mixed-domain apply for polynomial kernels on the staged fast path.  With S_j = row-DFT(I * cy^j) (the stage planes of the row
+// pass) and FI_ij = column-DFT(cx^i * S_j), the inverse column DFT of Construct_FDIFF's sum can be taken analytically:
+//   sum_l FI_ij[l][m] W0^(l a) e^(+2 pi i l x / N0) = N0 * cx^i[x - a] * S_j[x - a][m]
+//   => D[x][m] = N0 * SCALE * sum_ij ( sum_a C_ij[a][m] cx^i[x-a] S_j[x-a][m]  -  Soff_ij cx^i[x] S_j[x][m] ),
+//      C_ij[a][m] = sum_b a_ijab W1^(m b),
+// a (2w+1)-tap convolution ALONG THE COLUMNS of the stage planes with per-(tap, spectrum column) complex weights.  D is what
+// the inverse column pass would have produced, so the apply pass needs no column transform at all: row pass (DK + 1
+// planes), this kernel, inverse row pass.  (Replaces cols_fwd_weighted + construct_fd + the inverse cols_c2c there.)
+//
+// kernel_ctab_mixed: C'[t][a + W][m] = N0 * SCALE * (C_t[a][m] - [a == 0] Soff_t), zero for |a| > w (W = padded half width).
+// vconv_mixed: a wave is 16 spectrum columns x 4 independent row streams; the workgroup's 16 streams share the C' slice of
+// their 16 columns in LDS.  A stream walks down KS * L source rows (L = 2W + 1) and scatters each into the L output rows it
+// touches; the L accumulators are a window that slides down one row per source row.  Output row x is complete right
+// after source row x + W.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kernel_ctab_mixed(const double* __restrict__ sol, cplx* __restrict__ Ctab, int L0, int L1, int w0, int w1,
+                                                         int W, int Nh, int Nhp, int N1, const cplx* __restrict__ root1, double f)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int LT = 2 * W + 1;
+    const int t = blockIdx.y / LT, a = blockIdx.y % LT - W;
+    if (m >= Nhp) return;
+    cplx* dst = Ctab + ((size_t)blockIdx.y) * Nhp + m;
+    if (m >= Nh || a < -w0 || a > w0) { *dst = make_double2(0.0, 0.0); return; }
+    const int Fab = L0 * L1;
+    const double* arow = sol + (size_t)t * Fab + (size_t)(a + w0) * L1;
+    double cx = 0.0, cy = 0.0;
+    for (int bb = 0; bb < L1; ++bb) {
+        long long q = ((long long)m * (bb - w1)) % N1; if (q < 0) q += N1;
+        const cplx w = root1[q];
+        cx = fma(arow[bb], w.x, cx);
+        cy = fma(arow[bb], w.y, cy);
+    }
+    if (a == 0) {
+        double so = 0.0;
+        const int cen = w0 * L1 + w1;
+        const double* at = sol + (size_t)t * Fab;
+        for (int ab = 0; ab < Fab; ++ab) if (ab != cen) so += at[ab];
+        cx -= so;
+    }
+    *dst = make_double2(f * cx, f * cy);
+}
+
+template <int DK, int W, int KS>
+__global__ void __launch_bounds__(256, 4) vconv_mixed(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+                                                      const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
+                                                      cplx* __restrict__ trash)
+{
+    constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2, R = KS * L - 2 * W;
+    __shared__ cplx ctab[FIJ * L * 16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cl = lane & 15, sl = lane >> 4;
+    const int m = blockIdx.x * 16 + cl;
+    const bool active = m < Nh;
+    const int mc = active ? m : Nh - 1;
+    for (int e = threadIdx.x; e < FIJ * L * 16; e += 256) {
+        const int ta = e >> 4, c = e & 15;
+        ctab[e] = Ctab[(size_t)ta * Nhp + (size_t)min((int)blockIdx.x * 16 + c, Nh - 1)];
+    }
+    __syncthreads();
+    const int x0 = ((blockIdx.y * 4 + wv) * 4 + sl) * R;          // first output row of this stream
+    if (x0 >= N0) return;                                         // (no barrier below)
+    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(mc), rs = (size_t)lay.rstride;
+    // acc[q] collects output row (current source row) + q - W; after a source row, acc[0] is complete, is stored, and the
+    // window slides down by one (a register rotation: L moves against 24 L FMAs)
+    cplx acc[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q) acc[q] = make_double2(0.0, 0.0);
+    int y = x0 - W;
+    if (y < 0) y += N0;
+#pragma unroll 1
+    for (int sI = 0; sI < KS * L; ++sI) {
+        // the table does not change along the walk, so the compiler would hoist all FIJ * L reads out of the loop (4 registers
+        // each -> scratch spills); an opaque zero in the address makes them re-read from LDS for every source row
+        int opq;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+        const cplx* __restrict__ ct = ctab + cl + opq;
+        cplx S[NJ];
+        double fx[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            S[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            fx[jj] = kbx[(size_t)jj * N0 + y];
+        }
+#pragma unroll
+        for (int q = 0; q < L; ++q) {           // tap a = q - W
+            __builtin_amdgcn_sched_barrier(0);  // ... and a scheduling fence per tap keeps them from all being issued up front
+            double ax = acc[q].x, ay = acc[q].y;
+#pragma unroll
+            for (int jj = 0; jj <= DK; ++jj) {
+                double ex = 0.0, ey = 0.0;                         // E_j = sum_i cx^i[y] C'_(i,j)[a]
+#pragma unroll
+                for (int ii = 0; ii <= DK - jj; ++ii) {
+                    const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;           // REF_ij order: i major, j = 0 .. DK - i
+                    const cplx c = ct[(t * L + q) * 16];
+                    ex = fma(fx[ii], c.x, ex);
+                    ey = fma(fx[ii], c.y, ey);
+                }
+                ax = fma(S[jj].x, ex, fma(-S[jj].y, ey, ax));
+                ay = fma(S[jj].x, ey, fma(S[jj].y, ex, ay));
+            }
+            acc[q] = make_double2(ax, ay);
+        }
+        // the output row completed by this source row.  Stored without a branch (rows before the stream's first output, rows
+        // beyond the image and the padding columns go to a per-thread trash slot): a conditional store splits the loop body into
+        // blocks, and the table reads then end up a block away from the arithmetic that consumes them, i.e. in scratch
+        const int xo = x0 - 2 * W + sI;
+        const unsigned long long ok64 = 0ULL - (unsigned long long)(sI >= 2 * W && xo < N0 && active);     // all ones / zero: no select, no branch
+        const unsigned long long a_ok = (unsigned long long)(D + mo + (size_t)max(xo, 0) * rs), a_tr = (unsigned long long)(trash + threadIdx.x);
+        *reinterpret_cast<cplx*>((a_ok & ok64) | (a_tr & ~ok64)) = acc[0];
+#pragma unroll
+        for (int q = 0; q + 1 < L; ++q) acc[q] = acc[q + 1];
+        acc[L - 1] = make_double2(0.0, 0.0);
+        if (++y == N0) y = 0;
+    }
+}
+
 // separately varying scaling: DIFF -= SCALE * I * sum_s a_s00 * sbx[sp[s]][row] * sby[sq[s]][col]  (the centre term of
 // Construct_FDIFF, BSplineSFFT.py:2489-2497, taken in real space: it is a plain product there)
 struct ScaArgs {

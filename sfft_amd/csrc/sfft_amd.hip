@@ -113,6 +113,10 @@ struct sfft_plan {
     cplx *d_big1 = nullptr, *d_big2 = nullptr, *d_colscr = nullptr;   // work arrays of the four-step path
     double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
+    // mixed-domain apply (polynomial kernels on the staged fast path, KerHW <= 8): no column transforms in the apply pass
+    int use_vconv = 0, vw = 8;          // vw = compile-time half width the tables are padded to (4 or 8)
+    cplx* d_stage_a = nullptr;          // [DK+1] stage planes of the full image (apply pass)
+    cplx* d_ctabm = nullptr;            // [Fij][2 vw + 1][Nhp]
     cplx* d_stage = nullptr;            // fast path: row-pass output, one plane per distinct (image, column factor) (lazy)
     int n_stage_alloc = 0;
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
@@ -397,6 +401,13 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         const bool both_fast = !p->no_fast_fft && !p->ax0.big && !p->ax0.blue && p->ax0.M == 4096 && !p->ax1.big && !p->ax1.blue && p->ax1.M == 4096;
         if (both_fast && pw > 1 && is_pow2(pw) && p->Nhp % pw == 0) {
             p->lay.shift = ilog2(pw); p->lay.mask = pw - 1; p->lay.rstride = pw; p->lay.pstride = (long long)N0 * pw;
+        }
+        // polynomial plans (DK >= 0: made by sfft_plan_create, REF_ij term order) with a small stamp take the mixed-domain apply
+        if (both_fast && !p->no_staged && DK >= 0 && DK <= 3 && p->mode != 3 && KerHW >= 1 && KerHW <= 8 && !getenv("SFFT_NO_VCONV")) {
+            p->use_vconv = 1;
+            p->vw = KerHW <= 4 ? 4 : 8;
+            PLAN_TRY(dev_alloc(p, &p->d_stage_a, (size_t)(DK + 1) * N0 * p->Nhp));
+            PLAN_TRY(dev_alloc(p, &p->d_ctabm, (size_t)p->Fij * (2 * p->vw + 1) * p->Nhp + 256));   // + 256: trash slots of vconv_mixed
         }
     }
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
@@ -719,7 +730,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -1145,6 +1156,17 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
 static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t s)
 {
     StageTimer t(p, SFFT_ST_PRELIM_APPLY, s);
+    if (p->use_vconv) {      // only the row pass: DK + 1 stage planes I * cy^j, j = 0 .. DK
+        RowsArgs ra;
+        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = p->d_ones; ra.wy[u] = p->d_ones; }
+        RowGroups grp; grp.ngroups = 1; grp.first[0] = 0; grp.count[0] = p->DK + 1;
+        for (int jj = 0; jj <= p->DK; ++jj) { ra.src[jj] = d_I; ra.wy[jj] = p->d_kby + (size_t)jj * p->N1; }
+        const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
+        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, 1), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp, p->d_stage_a, p->N0, p->Nhp,
+                           p->lay, p->ax1.tw, p->scale, rp_per);
+        LAUNCH_CHECK();
+        return SFFT_OK;
+    }
     return forward_basis_planes(p, d_I, nullptr, dst, s);
 }
 
@@ -1152,7 +1174,22 @@ static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t 
 static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_I, const double* d_J, const double* d_solution,
                         double* d_diff, hipStream_t s)
 {
-    {
+    if (p->use_vconv) {
+        // `FI` is then the stage buffer holding S_j = row-DFT(I cy^j), j = 0 .. DK, in its first DK + 1 planes
+        StageTimer t(p, SFFT_ST_CONSTRUCT, s);
+        const int LT = 2 * p->vw + 1;
+        hipLaunchKernelGGL(kernel_ctab_mixed, dim3((p->Nhp + 255) / 256, p->Fij * LT), dim3(256), 0, s, d_solution, p->d_ctabm, p->L, p->L, p->w,
+                           p->w, p->vw, p->Nh, p->Nhp, p->N1, p->ax1.root, (double)p->N0 * p->scale);
+        constexpr int KS = 5;
+        const int R = KS * LT - 2 * p->vw, nstreams = (p->N0 + R - 1) / R;
+        dim3 g((p->Nh + 15) / 16, (nstreams + 15) / 16);
+#define VCONV_LAUNCH(DKT, WT) hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
+                                                 p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp)
+        if (p->vw == 4) { switch (p->DK) { case 0: VCONV_LAUNCH(0, 4); break; case 1: VCONV_LAUNCH(1, 4); break; case 2: VCONV_LAUNCH(2, 4); break; default: VCONV_LAUNCH(3, 4); } }
+        else { switch (p->DK) { case 0: VCONV_LAUNCH(0, 8); break; case 1: VCONV_LAUNCH(1, 8); break; case 2: VCONV_LAUNCH(2, 8); break; default: VCONV_LAUNCH(3, 8); } }
+#undef VCONV_LAUNCH
+        LAUNCH_CHECK();
+    } else {
         StageTimer t(p, SFFT_ST_CONSTRUCT, s);
         hipLaunchKernelGGL(kernel_rtab, dim3((p->N0 + 255) / 256, p->w + 1, p->Fij), dim3(256), 0, s, d_solution, p->d_rtab, p->Fij,
                            p->L, p->L, p->w, p->w, p->N0, 1 + 2 * p->wpad, p->ax0.root, p->mode == 3 ? 1 : 0);
@@ -1173,7 +1210,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
     }
     {
         StageTimer t(p, SFFT_ST_INVERSE, s);
-        launch_cols(p, FD, 1, 1, s);
+        if (!p->use_vconv) launch_cols(p, FD, 1, 1, s);         // (the mixed-domain kernel already left the column-inverse in FD)
         if (p->ax1.big) {
             const int npr = (p->N0 + 1) / 2;
             hipLaunchKernelGGL(retangle_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, FD, p->d_big1, p->N0, p->N1, p->Nh, p->Nhp);
@@ -1208,7 +1245,7 @@ extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, co
     HIPCHK(hipSetDevice(p->dev));
     int rc;
     if ((rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
-    return apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s);
+    return apply_finish(p, p->use_vconv ? p->d_stage_a : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s);
 }
 
 // GSS: the forward transforms of the full pair do not depend on the solution, and the dense solve leaves most
@@ -1234,7 +1271,8 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
         // the caller passed the full image as its own mask ("'same' means it is identical with I",
         // SFFTSubtract.py:849): the spectra of the solve pass are the spectra of the apply pass
         if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
-        if ((rc = apply_finish(p, p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+        // (mixed-domain apply: the solve pass left the stage planes of I first in d_stage)
+        if ((rc = apply_finish(p, p->use_vconv ? p->d_stage : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
         HIPCHK(hipStreamSynchronize(s));
         return SFFT_OK;
     }
@@ -1243,7 +1281,7 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
     p->overlap_I = nullptr;
     if (rc) { hipStreamSynchronize(p->s2); return rc; }
     HIPCHK(hipStreamWaitEvent(s, p->ev_pre, 0));
-    if ((rc = apply_finish(p, p->d_spec2, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+    if ((rc = apply_finish(p, p->use_vconv ? p->d_stage_a : p->d_spec2, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;
 }

@@ -734,3 +734,41 @@ def test_matching_kernel_grid_convolve_reproduces_sfft_model(dev):
     model = pair["SCI"] - D - bkg
     inner = (slice(w, N0 - w), slice(w, N1 - w))
     assert np.abs(conv[inner] - model[inner]).max() <= 1e-9 * np.abs(model).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# (h) alternative formulations on the 4096^2 fast path must agree with each other
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,DK,DB,cpr", [(8, 2, 2, True), (3, 3, 1, False), (5, 1, 2, True), (8, 0, 0, True)])
+def test_mixed_domain_apply_equals_fourier_apply_4096(dev, w, DK, DB, cpr):
+    """The apply pass of polynomial plans on the staged fast path convolves the stage planes along the columns in the mixed
+    (row index, column frequency) domain (vconv_mixed) instead of transforming 6 planes and multiplying in Fourier space.
+    Both are exact restatements of Construct_FDIFF + inverse DFT: same DIFF to rounding for a random solution, and the whole
+    GSS gives the same answer either way."""
+    from sfft_amd.plan import Plan
+    from sfft_amd.utils.synthetic import make_pair
+    N = 4096
+    pair = make_pair(N, N, seed=77 + w, mask=True)
+    I, J = _to(dev, pair["REF"]), _to(dev, pair["SCI"])
+    mI, mJ = _to(dev, pair["mREF"]), _to(dev, pair["mSCI"])
+    outs = []
+    for no_vconv in ("", "1"):
+        if no_vconv:
+            os.environ["SFFT_NO_VCONV"] = "1"
+        else:
+            os.environ.pop("SFFT_NO_VCONV", None)
+        try:
+            plan = Plan(N, N, w, DK, DB, cpr, device=dev.index)
+        finally:
+            os.environ.pop("SFFT_NO_VCONV", None)
+        rng = np.random.default_rng(5)
+        sol = rng.normal(size=plan.NEQ)
+        sol[:plan.Fijab] *= float(N) * float(N) * 0.01
+        d_rand = plan.apply(I, J, torch.from_numpy(sol).to(dev)).cpu().numpy()
+        s2, d2 = plan.subtract(I, J, mI, mJ)
+        outs.append((d_rand, s2.cpu().numpy(), d2.cpu().numpy()))
+        plan.close()
+    (da, sa, ga), (db, sb, gb) = outs
+    assert rms(da - db) <= 1e-12 * rms(db)
+    assert np.array_equal(sa, sb)                       # the solve pass is the same code either way
+    assert rms(ga - gb) <= 1e-11 * rms(pair["SCI"])
