@@ -62,9 +62,11 @@ def alg_bytes(N0, N1, w, DK, DB):
         "greek_g1b": (Fij + 1) * spec,
         # fp64 flops of the Omega passes: per pass and spectrum element one complex product (6) + 4 real FMAs per lag
         "greek_g1_flops": n_omg * N0 * Nh * (6 + 2 * 4 * (2 * w)),
-        "prelim_apply": Fij * fwd_plane,
-        "construct": Fij * spec + spec,
-        "inverse": 2 * spec + spec + r * P + r * P,      # columns r+w, rows read, J read, DIFF write
+        # apply pass as built (polynomial kernel, KerHW <= 8): row pass into DK + 1 stage planes, mixed-domain column convolution
+        # (reads them, writes one plane), inverse row pass with the DIFF epilogue -- no column transforms
+        "prelim_apply": r * P + (DK + 1) * spec,
+        "construct": (DK + 1) * spec + spec,
+        "inverse": spec + r * P + r * P,                # rows read, J read, DIFF write
     }
     n_pre = 1 + Fij + Fpq
     n_greek = Fij * Fij + 2 * Fij * Fpq + Fpq * Fpq + Fij + Fpq

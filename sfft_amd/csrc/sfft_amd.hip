@@ -1180,7 +1180,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         const int LT = 2 * p->vw + 1;
         hipLaunchKernelGGL(kernel_ctab_mixed, dim3((p->Nhp + 255) / 256, p->Fij * LT), dim3(256), 0, s, d_solution, p->d_ctabm, p->L, p->L, p->w,
                            p->w, p->vw, p->Nh, p->Nhp, p->N1, p->ax1.root, (double)p->N0 * p->scale);
-        constexpr int KS = 5;
+        constexpr int KS = 4;       // source rows per stream = KS * L (3..10 measured: 4 is best at KerHW 8)
         const int R = KS * LT - 2 * p->vw, nstreams = (p->N0 + R - 1) / R;
         dim3 g((p->Nh + 15) / 16, (nstreams + 15) / 16);
 #define VCONV_LAUNCH(DKT, WT) hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
