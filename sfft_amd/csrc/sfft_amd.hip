@@ -130,6 +130,10 @@ struct sfft_plan {
     double* d_rd = nullptr;             // [NEQfs] reciprocal diagonal of the Cholesky factor
     double* d_partial = nullptr;        // [BACK_SLICES][CB] strip-product partials of the back substitution
     unsigned int* d_counter = nullptr;
+    double* d_winv = nullptr;           // [nblk][CB][CB] inverses of the diagonal blocks of the Cholesky factor
+    unsigned int* d_bflags = nullptr;   // [nblk] "x_b published" flags of the back substitution, stamped with the solve's epoch
+    unsigned int back_epoch = 0;
+    int back_variant = 1;               // env SFFT_BACK=0: one launch per block (A/B testing)
     double* d_sol = nullptr;            // [NEQ] internal solution copy
     cplx* d_rtab = nullptr; int wpad = 4;   // [Fij][N0][1 + 2 wpad] per-row kernel transfer table of the apply pass
     double* d_rowmom = nullptr; double* d_delta = nullptr;
@@ -581,6 +585,16 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_TRY(dev_alloc(p, &p->d_xv, (size_t)p->NEQfs));
     PLAN_TRY(dev_alloc(p, &p->d_rd, (size_t)p->NEQfs));
     PLAN_TRY(dev_alloc(p, &p->d_partial, (size_t)BACK_SLICES * CB));
+    {
+        const int nblk_b = (p->NEQfs + CB - 1) / CB;
+        PLAN_TRY(dev_alloc(p, &p->d_winv, (size_t)nblk_b * CB * CB));
+        PLAN_TRY(dev_alloc(p, &p->d_bflags, (size_t)nblk_b));
+        PLAN_HIP(hipMemset(p->d_bflags, 0, (size_t)nblk_b * sizeof(unsigned int)));
+        if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
+        int ncu = 0;
+        PLAN_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        if (nblk_b > ncu) p->back_variant = 0;      // the one-launch version needs every block's workgroup resident at once
+    }
     PLAN_TRY(dev_alloc(p, &p->d_counter, (size_t)1));
     PLAN_HIP(hipMemset(p->d_counter, 0, sizeof(unsigned int)));
     PLAN_TRY(dev_alloc(p, &p->d_sol, (size_t)p->NEQ));
@@ -730,7 +744,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags};
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -1050,6 +1064,11 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
     LAUNCH_CHECK();
     HIPCHK(hipMemsetAsync(d_solution, 0, (size_t)p->NEQ * sizeof(double), s));
     const int nblk = (n + CB - 1) / CB;
+    if (p->back_variant == 1) {
+        hipLaunchKernelGGL(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
+        if (++p->back_epoch == 0u) p->back_epoch = 1u;
+        hipLaunchKernelGGL(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->back_epoch);
+    } else
     for (int b = nblk - 1; b >= 0; --b) {
         const int kb = b * CB, nb = std::min(CB, n - kb);
         const int rows_below = n - (kb + nb);

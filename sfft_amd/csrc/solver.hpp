@@ -277,6 +277,100 @@ __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__
 
 // Extend_Solution / Restore_Solution scatter (SFFTConfigure.py:1299-1311; BSplineSFFT.py:2274-2338):
 // solution[idx[i]] = x[i]; removed entries stay zero, tied entries all receive the value of their representative
+// ---- back substitution in two launches -----------------------------------------------------------------------
+// L^T x = y, y = border row of the factor.  A launch per 64-column block (the version above) costs ~20 us per block, almost
+// all of it launch and hand-off latency: 28 blocks -> 0.55 ms at n = 1735.  Instead:
+//  (1) chol_inv_diag: W_b = L_bb^-1 for every diagonal block, all blocks in parallel;
+//  (2) chol_back_all: one resident workgroup per block b, x_b = W_b^T (y_b - sum_{c > b} L_cb^T x_c).  Workgroup b folds
+//      in the blocks x_c as they are published (flag per block, epoch-stamped so that nothing needs zeroing), last to first;
+//      the only work on the critical path per block is two 64 x 64 matrix-vector products out of LDS and one flag hand-off.
+__global__ void __launch_bounds__(256) chol_inv_diag(const double* __restrict__ A, int ld, int n, const double* __restrict__ rd,
+                                                     double* __restrict__ Winv)
+{
+    __shared__ double Ls[CB][CB + 1];
+    __shared__ double Ws[CB][CB + 1];
+    const int tid = threadIdx.x, kb = blockIdx.x * CB, nb = min(CB, n - kb);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, r = e >> 6, q = e & 63;
+        Ls[r][q] = (r < nb && q <= r) ? A[(size_t)(kb + r) * ld + kb + q] : 0.0;
+        Ws[r][q] = 0.0;
+    }
+    __syncthreads();
+    // column j of W solves L w = e_j; four lanes per column split the dot product (same wave: tid = 4 j + g)
+    const int j = tid >> 2, g = tid & 3;
+    for (int i = 0; i < nb; ++i) {
+        double sacc = 0.0;
+        if (j <= i) for (int k = j + g; k < i; k += 4) sacc = fma(Ls[i][k], Ws[k][j], sacc);
+        sacc += __shfl_xor(sacc, 1);
+        sacc += __shfl_xor(sacc, 2);
+        if (g == 0 && j <= i && j < nb) Ws[i][j] = ((i == j ? 1.0 : 0.0) - sacc) * rd[kb + i];
+        __syncthreads();
+    }
+    double* W = Winv + (size_t)blockIdx.x * CB * CB;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, r = e >> 6, q = e & 63;
+        W[e] = Ws[r][q];
+    }
+}
+
+__global__ void __launch_bounds__(256) chol_back_all(const double* __restrict__ A, int ld, int n, const double* __restrict__ Winv,
+                                                     double* xv, unsigned int* flags, unsigned int epoch)
+{
+    __shared__ double Wb[CB][CB + 1];
+    __shared__ double Ln[CB][CB + 1];
+    __shared__ double xs[CB];
+    __shared__ double red[4][CB];
+    const int nblk = gridDim.x;
+    const int b = nblk - 1 - (int)blockIdx.x;          // the last block has no dependency: give it the first workgroup
+    const int tid = threadIdx.x, kb = b * CB, nb = min(CB, n - kb);
+    const int jj = tid & 63, gg = tid >> 6;
+    const double* W = Winv + (size_t)b * CB * CB;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, r = e >> 6, q = e & 63;
+        Wb[r][q] = W[e];
+        const int row = kb + CB + r;
+        Ln[r][q] = (b + 1 < nblk && row < n && q < nb) ? A[(size_t)row * ld + kb + q] : 0.0;
+    }
+    double acc = 0.0;                                   // threads tid < 64: sum_c (L_cb^T x_c)[tid]
+    for (int c = nblk - 1; c > b; --c) {
+        if (tid == 0) {
+            while (__hip_atomic_load(&flags[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        const int kc = c * CB, nc = min(CB, n - kc);
+        if (tid < CB) xs[tid] = tid < nc ? __hip_atomic_load(&xv[kc + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        double ps = 0.0;
+        if (c == b + 1) {
+#pragma unroll 4
+            for (int i = gg; i < CB; i += 4) ps = fma(Ln[i][jj], xs[i], ps);
+        } else if (jj < nb) {
+#pragma unroll 4
+            for (int i = gg; i < nc; i += 4) ps = fma(A[(size_t)(kc + i) * ld + kb + jj], xs[i], ps);
+        }
+        red[gg][jj] = ps;
+        __syncthreads();
+        if (tid < CB) acc += red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+    __syncthreads();
+    if (tid < CB) xs[tid] = tid < nb ? A[(size_t)n * ld + kb + tid] - acc : 0.0;       // y_b - strip products
+    __syncthreads();
+    double ps = 0.0;
+#pragma unroll 4
+    for (int i = gg; i < CB; i += 4) ps = fma(Wb[i][jj], xs[i], ps);                   // x_b = W_b^T rhs
+    red[gg][jj] = ps;
+    __syncthreads();
+    if (tid < nb) __hip_atomic_store(&xv[kb + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        __hip_atomic_store(&flags[b], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ void __launch_bounds__(256) scatter_solution(const double* __restrict__ xv, int n, const int* __restrict__ idx,
                                                         double* __restrict__ solution, int NEQ, int tie_first, int tie_cnt, int tie_stride)
 {
