@@ -50,6 +50,16 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
         const int c = cg + 4 * q;
         a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
     }
+    // this workgroup's panel rows are requested now, so that their latency hides behind the factorization of the diagonal
+    // block (the barriers below would otherwise keep the loads after it)
+    const int r0 = k + nb + ((int)blockIdx.x - 1) * CB;
+    const int nr = blockIdx.x == 0 ? 0 : min(CB, n + 1 - r0);
+    double p[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
+    }
     // Four columns per step (16 steps, two barriers each).  Step jq eliminates columns 4 jq .. 4 jq + 3:
     //   1. every thread publishes its raw element of that column block (the quad of a row holds the four of them);
     //   2. all threads factor the 4x4 pivot block T redundantly (four reciprocal square roots in sequence);
@@ -108,15 +118,7 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
         if (tid < nb) rd[k + tid] = rdiag[tid];
         return;
     }
-    const int r0 = k + nb + (blockIdx.x - 1) * CB;
-    const int nr = min(CB, n + 1 - r0);
     if (nr <= 0) return;
-    double p[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
-    }
     // X L^T = A_panel, row by row: x_j = (a_j - sum_{t<j} x_t L[j][t]) / L[j][j].  The four lanes of a row each hold
     // the x_t with t = cg (mod 4); they form partial sums over their own t and combine them with two quad
     // shuffles, so this phase needs no barrier at all (rows are independent).
@@ -166,8 +168,18 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
         Li[i][t] = (i < ni && t < nb) ? A[(size_t)(i0 + i) * ld + k + t] : 0.0;
         Lj[i][t] = (i < nj && t < nb) ? A[(size_t)(j0 + i) * ld + k + t] : 0.0;
     }
-    __syncthreads();
     const int tx = tid & 15, ty = tid >> 4;
+    // the entries to be updated are requested before the barrier and the product loop, which then hide their latency
+    double old[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * r, j = tx + 16 * q;
+            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
+            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
+        }
+    __syncthreads();
     double c[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -185,16 +197,6 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
 #pragma unroll
             for (int q = 0; q < 4; ++q) c[r][q] = fma(av[r], bv[q], c[r][q]);
     }
-    // epilogue: all 16 loads first (independent), then the stores
-    double old[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = ty + 16 * r, j = tx + 16 * q;
-            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
-            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
-        }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
