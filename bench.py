@@ -15,8 +15,10 @@ per step (weak scaling, no data-path collective); the only collective is the gat
 end (sfft_amd/sharding.py).
 
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
-  roofline     -- the dominant KERNEL by total time per pair, the column pass of the forward 2-D FFTs
-                  (cols_fwd_weighted_4096: two launches per pair): algorithmic bytes of the timed launch / its duration (HIP events on the launch
+  roofline     -- the dominant KERNEL by time per pair.  Since the forward transforms were halved that is the Omega pass of the
+                  Greek stage (greek_g1<16,2>), priced against the fp64 FMA peak (bound "mfma": the fp64 vector and matrix
+                  peaks are equal on MI355X); `roofline_hbm` is the dominant HBM-bound kernel, the forward column pass
+                  (cols_fwd_weighted_4096): algorithmic bytes of the timed launch / its duration (HIP events on the launch
                   stream) against the 8 TB/s HBM3E peak; `roofline_greek` is the same for the second kernel, the Omega
                   pass of the Greek stage, which is bound by fp64 FMA issue, not by HBM
   cpu_baseline -- the numpy/scipy oracle (port of the reference's Numpy backend) timed on this host on a
@@ -235,10 +237,14 @@ def main():
                        "pairs_per_step": world * S, "pairs_in_flight_per_gpu": S, "plan_create_s": plan_s,
                        "solver": {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")},
             "stage_ms": stage_ms,
-            "roofline": dict(roof(iso_stage), measured="HIP events on the launch stream around the kernel (the forward launch of the solve pass: "
-                             "%d stage planes in, %d planes out), %d launches with one pair in flight right after the timed region "
-                             "(same process, same buffers)" % (args.dk + 2, (args.dk + 1) * (args.dk + 2) // 2 + 1, n_iso),
+            # the dominant kernel by time per pair: the Omega pass of the Greek stage (one launch per pair) since the forward
+            # transforms were halved; it is bound by fp64 FMA issue.  The dominant HBM-bound kernel (forward column pass) follows.
+            "roofline": dict(roof_flops(iso_stage) if iso_stage["greek_g1"] >= iso_stage["fwd_cols"] else roof(iso_stage),
+                             measured="HIP events on the launch stream around the kernel, %d launches with one pair in flight right after "
+                             "the timed region (same process, same buffers)" % n_iso,
                              kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "construct")}),
+            "roofline_hbm": dict(roof(iso_stage), measured="same events, same launches (the forward column launch of the solve pass: "
+                                 "%d stage planes in, %d planes out)" % (args.dk + 2, (args.dk + 1) * (args.dk + 2) // 2 + 1)),
             "roofline_greek": dict(roof_flops(iso_stage), measured="same events, same launches"),
             "roofline_timed_region": dict(roof(stage_ms), measured="same events on stream 0 inside the timed region; durations "
                                           "include time sliced to the other %d streams' kernels" % (S - 1)),
