@@ -16,8 +16,7 @@ end (sfft_amd/sharding.py).
 
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
   roofline     -- the dominant KERNEL by time per pair.  Since the forward transforms were halved that is the Omega pass of the
-                  Greek stage (greek_g1<16,2>), priced against the fp64 FMA peak (bound "mfma": the fp64 vector and matrix
-                  peaks are equal on MI355X); `roofline_hbm` is the dominant HBM-bound kernel, the forward column pass
+                  Greek stage (greek_g1_mfma<2,false>: v_mfma_f64_16x16x4_f64), priced against the fp64 MFMA peak (bound "mfma"); `roofline_hbm` is the dominant HBM-bound kernel, the forward column pass
                   (cols_fwd_weighted_4096): algorithmic bytes of the timed launch / its duration (HIP events on the launch
                   stream) against the 8 TB/s HBM3E peak; `roofline_greek` is the same for the second kernel, the Omega
                   pass of the Greek stage, which is bound by fp64 FMA issue, not by HBM
@@ -208,7 +207,7 @@ def main():
             pass
 
         KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096" if N == 4096 else "cols_c2c / strided_dft",
-                     "fwd_rows": "rows_r2c_4096" if N == 4096 else "rows_r2c", "greek_g1": "greek_g1<16, 2> (Omega passes)",
+                     "fwd_rows": "rows_r2c_4096" if N == 4096 else "rows_r2c", "greek_g1": "greek_g1_mfma<2, false> (Omega passes)",
                      "greek_g1b": "greek_g1<8, 2> (Theta, Gamma passes)", "construct": "construct_fd"}
 
         def roof(stages, dom="fwd_cols"):
@@ -223,7 +222,7 @@ def main():
             return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_flops"],
                     "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
-                    "note": "fp64 vector FMAs (the fp64 VALU and MFMA peaks are equal on MI355X); HBM side: "
+                    "note": "v_mfma_f64_16x16x4_f64 (the fp64 matrix and vector peaks are equal on MI355X); HBM side: "
                             "%.0f GB/s of algorithmic bytes" % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
         out = {
             "metric": "image-pairs/sec, %dx%d, KerHW=%d polyOrd=%d" % (N, N, args.kerhw, args.dk),

@@ -121,6 +121,124 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
     }
 }
 
+// The same pass on the matrix cores, for plane x plane passes with at most 16 lags (the Omega passes at KerHW <= 8).
+// Per step a wave takes 4 image rows x 64 columns as four 4 x 16 tiles.  v_mfma_f64_16x16x4_f64 computes D[16 x 16] += A[16 x 4]
+// B[4 x 16] with one double per lane for A and B (lane = 16 k + i holds A[i][k]; lane = 16 k + j holds B[k][j]) and four per lane
+// for D (column j = lane & 15, rows (lane >> 4) + 4 q).  With A = the twiddles (i = lag - 1, k = row) and B = the Hadamard
+// product H (k = row, j = column), the four real products of the lag pair +-r are four MFMAs per tile:
+//   S1 = wx Hx, S2 = wy Hy, S3 = wy Hx, S4 = wx Hy.
+// The loads put H directly in operand layout (lane = 16 * row + column), the twiddles are ONE vector load per step (no
+// scalar-register bottleneck), and the 64 accumulators per lane of the vector version become 16 four-vectors.
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+// NT = 16-column tiles per wave (2: 110 registers, four waves per SIMD, measured best; 4: two waves per SIMD).
+// PACK (h <= 8): the 16 rows of A hold wx of lags 1..8 and then wy of lags 1..8, so two MFMAs per tile give all four sums
+// (A Hx -> S1 in rows 0..7, S3 in rows 8..15; A Hy -> S4, S2); correct, but those short passes are not FMA bound and the
+// vector kernel is as fast, so the host does not use it.  B of a pass may be a column factor (Gamma passes): H = A conj(Xp[l]).
+// Measured at 4096^2, KerHW 8 (21 Omega passes, 23.6 GFLOP): 0.53 ms = 45 TFLOP/s, against 0.65 ms for the vector kernel.
+template <int NT, bool PACK>
+__global__ void __launch_bounds__(64, (NT == 4 ? 2 : 4)) greek_g1_mfma(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+                                                                       cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
+                                                                       int rows_per_chunk, const cplx* __restrict__ W0tab, int HM,
+                                                                       const cplx* __restrict__ Xp, int ncb, int S, int npass)
+{
+    const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
+    const int total = ncb * S * npass;
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int tile = logical / npass;
+    const int chunk = tile / ncb;
+    const int m0 = (tile - chunk * ncb) * 16 * NT;
+    const G1Pass pr = passes[pass0 + (logical - tile * npass)];
+    const int h = pr.h, PH = 2 * h + 1;
+    const int lb = chunk * rows_per_chunk;
+    const int le = min(N0, lb + rows_per_chunk);
+    const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
+    const bool colfac = pr.b_plane < 0;
+    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz;
+    const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz;
+    const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
+    const int tcol = PACK ? 1 + (n & 7) : 1 + n;          // twiddle column (lag) this lane feeds into A
+    size_t co[NT];
+    bool act[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = m0 + 16 * t + n;
+        act[t] = m < Nh;
+        co[t] = lay.col(act[t] ? m : Nh - 1);
+    }
+    constexpr int NS = PACK ? 2 : 4;                       // accumulator tiles per column tile
+    d4v Sx[NT][NS];
+    double g0x[NT], g0y[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Sx[t][q] = (d4v){0.0, 0.0, 0.0, 0.0};
+        g0x[t] = g0y[t] = 0.0;
+    }
+    // software pipeline: the loads of step s + 1 are in flight while the MFMAs of step s run
+    cplx twn, avn[NT], bvn[NT];
+    {
+        const int rc = min(lb + kq, le - 1);
+        twn = W0tab[(size_t)rc * HM + tcol];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { avn[t] = A[co[t] + (size_t)rc * rs]; bvn[t] = colfac ? xp[rc] : B[co[t] + (size_t)rc * rs]; }
+    }
+    for (int l = lb; l < le; l += 4) {
+        const double vf = (l + kq < le) ? 1.0 : 0.0;
+        const cplx twv = twn;
+        cplx av[NT], bv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { av[t] = avn[t]; bv[t] = bvn[t]; }
+        {
+            const int rc = min(l + 4 + kq, le - 1);                 // (the last step re-reads a valid row; unused)
+            twn = W0tab[(size_t)rc * HM + tcol];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { avn[t] = A[co[t] + (size_t)rc * rs]; bvn[t] = colfac ? xp[rc] : B[co[t] + (size_t)rc * rs]; }
+        }
+        const double wx = twv.x * vf, wy = twv.y * vf;
+        const double wp = (n < 8) ? wx : wy;                        // PACK: rows 0..7 of A are wx, rows 8..15 are wy
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const cplx H = cmulc(av[t], bv[t]);
+            g0x[t] = fma(H.x, vf, g0x[t]);
+            g0y[t] = fma(H.y, vf, g0y[t]);
+            if (PACK) {
+                Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.x, Sx[t][0], 0, 0, 0);      // S1 | S3
+                Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.y, Sx[t][1], 0, 0, 0);      // S4 | S2
+            } else {
+                Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.x, Sx[t][0], 0, 0, 0);      // S1
+                Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);      // S2
+                Sx[t][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.x, Sx[t][2], 0, 0, 0);      // S3
+                Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);      // S4
+            }
+        }
+    }
+    cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        double sx = g0x[t], sy = g0y[t];
+        sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
+        sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
+        const int m = m0 + 16 * t + n;
+        if (!act[t]) continue;
+        if (kq == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
+#pragma unroll
+        for (int q = 0; q < (PACK ? 2 : 4); ++q) {
+            const int r = kq + 4 * q + 1;               // D row (lane >> 4) + 4 q holds lag index r - 1
+            if (r <= h) {
+                const double s1 = Sx[t][0][q];
+                const double s2 = PACK ? Sx[t][1][q + 2] : Sx[t][1][q];
+                const double s3 = PACK ? Sx[t][0][q + 2] : Sx[t][2][q];
+                const double s4 = PACK ? Sx[t][1][q] : Sx[t][3][q];
+                g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
+                g[(size_t)(h - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
+            }
+        }
+    }
+}
+
 // W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)
 __global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
 {

@@ -140,6 +140,7 @@ struct sfft_plan {
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
+    int g1_mfma = 1;                    // Omega passes on the matrix cores (greek_g1_mfma); env SFFT_G1_MFMA=0: vector kernel (A/B testing)
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     int timing = 0;
@@ -324,6 +325,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     p->dev = device;
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
+    if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
     if (BS.mode == 3) {
@@ -1022,9 +1024,20 @@ static int g1_band(int h)
 }
 static int g1_padded(int h) { const int b = g1_band(h); return ((std::max(h, 1) + b - 1) / b) * b; }
 
-static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
+static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t s, bool planes_only = false)
 {
     if (npass <= 0) return SFFT_OK;
+    (void)planes_only;
+    // 9 .. 16 lags (the Omega passes at KerHW 5 .. 8): on the matrix cores.  For <= 8 lags the pass is not FMA bound and the
+    // vector kernel is as fast or faster (measured 0.33 vs 0.34 - 0.38 ms with the 8-lag packing <NT, true>).
+    if (h >= 9 && h <= 16 && p->g1_mfma) {
+        const int ncb = (p->Nh + 31) / 32;
+        const int total = ncb * p->S * npass;
+        hipLaunchKernelGGL((greek_g1_mfma<2, false>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
+                           p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+        LAUNCH_CHECK();
+        return SFFT_OK;
+    }
     switch (g1_band(h)) {
         case 4: launch_g1<4, 4>(p, pass0, npass, h, s); break;
         case 8: launch_g1<8, 2>(p, pass0, npass, h, s); break;
@@ -1118,7 +1131,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1, s);
-        if ((rc = greek_g1_group(p, 0, p->n_omg, 2 * p->w, s))) return rc;
+        if ((rc = greek_g1_group(p, 0, p->n_omg, 2 * p->w, s, true))) return rc;
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
