@@ -133,6 +133,9 @@ struct sfft_plan {
     double* d_winv = nullptr;           // [nblk][CB][CB] inverses of the diagonal blocks of the Cholesky factor
     unsigned int* d_bflags = nullptr;   // [nblk] "x_b published" flags of the back substitution, stamped with the solve's epoch
     unsigned int back_epoch = 0;
+    int fused_step = 1;                 // env SFFT_FUSED_STEP=0: separate update / panel launches (A/B testing)
+    unsigned int step_epoch = 0;
+    int n_bflags = 0;
     int back_variant = 1;               // env SFFT_BACK=0: one launch per block (A/B testing)
     double* d_sol = nullptr;            // [NEQ] internal solution copy
     cplx* d_rtab = nullptr; int wpad = 4;   // [Fij][N0][1 + 2 wpad] per-row kernel transfer table of the apply pass
@@ -583,15 +586,17 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_TRY(dev_alloc(p, &p->d_spec, (size_t)(p->Fij + 1 + p->nsca) * N0 * p->Nhp));
     p->ld = (p->NEQfs + 1 + 3) & ~3;
     PLAN_TRY(dev_alloc(p, &p->d_A, (size_t)(p->NEQfs + 1) * p->ld));
-    PLAN_TRY(dev_alloc(p, &p->d_dbuf, (size_t)2 * CB * CB));
+    PLAN_TRY(dev_alloc(p, &p->d_dbuf, (size_t)3 * CB * CB));      // two hand-over blocks of the two-kernel path + the raw block of chol_step
     PLAN_TRY(dev_alloc(p, &p->d_xv, (size_t)p->NEQfs));
     PLAN_TRY(dev_alloc(p, &p->d_rd, (size_t)p->NEQfs));
     PLAN_TRY(dev_alloc(p, &p->d_partial, (size_t)BACK_SLICES * CB));
     {
         const int nblk_b = (p->NEQfs + CB - 1) / CB;
         PLAN_TRY(dev_alloc(p, &p->d_winv, (size_t)nblk_b * CB * CB));
-        PLAN_TRY(dev_alloc(p, &p->d_bflags, (size_t)nblk_b));
-        PLAN_HIP(hipMemset(p->d_bflags, 0, (size_t)nblk_b * sizeof(unsigned int)));
+        p->n_bflags = nblk_b + 1;                   // + 1: the hand-off flag of chol_step
+        PLAN_TRY(dev_alloc(p, &p->d_bflags, (size_t)p->n_bflags));
+        PLAN_HIP(hipMemset(p->d_bflags, 0, (size_t)p->n_bflags * sizeof(unsigned int)));
+        if (const char* ev = getenv("SFFT_FUSED_STEP")) p->fused_step = atoi(ev);
         if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
         int ncu = 0;
         PLAN_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -1063,7 +1068,30 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
     const int n = p->NEQfs;
     hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
     int step = 0;
-    for (int k = 0; k < n; k += CB, ++step) {
+    int k_start = 0;
+    if (p->fused_step && n >= 2 * CB) {
+        // step 0: panel only; steps with a full block: one fused launch each (update with the previous panel + this panel)
+        {
+            const int rows_below = n + 1 - CB;
+            hipLaunchKernelGGL(chol_panel, dim3(1 + (rows_below + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, 0, p->d_dbuf, p->d_status, p->d_rd);
+        }
+        int k = CB;
+        for (; n - k >= CB; k += CB) {
+            const int ntile = (n + 1 - k + CB - 1) / CB;
+            if (++p->step_epoch == 0u) p->step_epoch = 1u;
+            hipLaunchKernelGGL(chol_step, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
+                               p->d_bflags + p->n_bflags - 1, p->step_epoch, p->d_status, p->d_rd);
+        }
+        // what is left: the update with the last full panel (it also hands over the raw diagonal block) and the partial block
+        if (k < n) {
+            const int rows_below = n + 1 - k;
+            const int ntile = (rows_below + CB - 1) / CB;
+            hipLaunchKernelGGL(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf);
+        }
+        k_start = k;
+        step = 0;
+    }
+    for (int k = k_start; k < n; k += CB, ++step) {
         const int nb = std::min(CB, n - k);
         const int rows_below = n + 1 - (k + nb);
         const int nblk = 1 + (rows_below + CB - 1) / CB;

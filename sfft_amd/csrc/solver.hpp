@@ -34,32 +34,22 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 // (i, cg + 4q), q < 16, in registers; four columns per pair of barriers; fully unrolled so that all register
 // indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
 // b >= 1 then solve X L^T = A_panel for 64 rows below it (border row n included) without barriers (see below).
-__global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
-                                                  int* __restrict__ status, double* __restrict__ rd)
+// Scratch of the diagonal-block factorisation (one per workgroup)
+struct PanelLds {
+    double Dl[CB][CB + 1];     // factor of the diagonal block
+    double rdiag[CB];          // 1 / L[j][j]
+    double Rw[CB][4];          // raw column block published in step 1
+    double Fw[CB][4];          // final column block published in step 3
+};
+
+// Factor the CB x CB diagonal block held as a[q] = D[i][cg + 4 q] by thread (i = tid >> 2, cg = tid & 3) (identity padding
+// beyond nb); on return L.Dl holds the lower-triangular factor and L.rdiag the reciprocal diagonal.  All 256 threads call.
+__device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, int tid, int nb, bool report, int* __restrict__ status)
 {
-    __shared__ double Dl[CB][CB + 1];     // factor of the diagonal block
-    __shared__ double rdiag[CB];          // 1 / L[j][j]
-    __shared__ double Rw[CB][4];          // raw column block published in step 1
-    __shared__ double Fw[CB][4];          // final column block published in step 3
-    const int tid = threadIdx.x;
-    const int nb = min(CB, n - k);
     const int i = tid >> 2, cg = tid & 3;
-    double a[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
-    }
-    // this workgroup's panel rows are requested now, so that their latency hides behind the factorization of the diagonal
-    // block (the barriers below would otherwise keep the loads after it)
-    const int r0 = k + nb + ((int)blockIdx.x - 1) * CB;
-    const int nr = blockIdx.x == 0 ? 0 : min(CB, n + 1 - r0);
-    double p[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
-    }
+    double (&Rw)[CB][4] = L.Rw;
+    double (&Fw)[CB][4] = L.Fw;
+    double (&rdiag)[CB] = L.rdiag;
     // Four columns per step (16 steps, two barriers each).  Step jq eliminates columns 4 jq .. 4 jq + 3:
     //   1. every thread publishes its raw element of that column block (the quad of a row holds the four of them);
     //   2. all threads factor the 4x4 pivot block T redundantly (four reciprocal square roots in sequence);
@@ -85,7 +75,7 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
         const double t32 = fma(-t31, t21, fma(-t30, t20, r32)) * rs2;
         const double d3 = fma(-t32, t32, fma(-t31, t31, fma(-t30, t30, r33)));
         const double rs3 = rsqrt_nr(d3);
-        if (tid == 0 && blockIdx.x == 0 && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
+        if (tid == 0 && report && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
         const double l0 = x0 * rs0;
         const double l1 = fma(-l0, t10, x1) * rs1;
         const double l2 = fma(-l1, t21, fma(-l0, t20, x2)) * rs2;
@@ -107,18 +97,17 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = cg + 4 * q;
-        Dl[i][c] = (c <= i) ? a[q] : 0.0;
+        L.Dl[i][c] = (c <= i) ? a[q] : 0.0;
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int e = tid; e < nb * nb; e += 256) {
-            const int r = e / nb, c = e - r * nb;
-            if (c <= r) A[(size_t)(k + r) * ld + k + c] = Dl[r][c];
-        }
-        if (tid < nb) rd[k + tid] = rdiag[tid];
-        return;
-    }
-    if (nr <= 0) return;
+}
+
+// X L^T = P for the workgroup's CB rows, thread (i, cg) holding P[i][cg + 4 q] in p[q]; no barriers
+__device__ __forceinline__ void chol_trsm_rows(double (&p)[16], const PanelLds& L, int tid)
+{
+    const int cg = tid & 3;
+    const double (&Dl)[CB][CB + 1] = L.Dl;
+    const double (&rdiag)[CB] = L.rdiag;
     // X L^T = A_panel, row by row: x_j = (a_j - sum_{t<j} x_t L[j][t]) / L[j][j].  The four lanes of a row each hold
     // the x_t with t = cg (mod 4); they form partial sums over their own t and combine them with two quad
     // shuffles, so this phase needs no barrier at all (rows are independent).
@@ -141,6 +130,42 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
         const double xj = (p[jq] - tot) * rdiag[j];
         p[jq] = (cg == jr) ? xj : p[jq];
     }
+}
+
+__global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld, int n, int k, const double* __restrict__ Dsrc,
+                                                  int* __restrict__ status, double* __restrict__ rd)
+{
+    __shared__ PanelLds L;
+    const int tid = threadIdx.x;
+    const int nb = min(CB, n - k);
+    const int i = tid >> 2, cg = tid & 3;
+    double a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
+    }
+    // this workgroup's panel rows are requested now, so that their latency hides behind the factorization of the diagonal
+    // block (the barriers below would otherwise keep the loads after it)
+    const int r0 = k + nb + ((int)blockIdx.x - 1) * CB;
+    const int nr = blockIdx.x == 0 ? 0 : min(CB, n + 1 - r0);
+    double p[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cg + 4 * q;
+        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
+    }
+    chol_factor_diag(a, L, tid, nb, blockIdx.x == 0, status);
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e / nb, c = e - r * nb;
+            if (c <= r) A[(size_t)(k + r) * ld + k + c] = L.Dl[r][c];
+        }
+        if (tid < nb) rd[k + tid] = L.rdiag[tid];
+        return;
+    }
+    if (nr <= 0) return;
+    chol_trsm_rows(p, L, tid);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = cg + 4 * q;
@@ -148,7 +173,6 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
     }
 }
 
-// trailing update A[i][j] -= sum_t L[i][k+t] L[j][k+t] for i >= j >= k+nb (j < n), 64x64 tiles, 4x4 per thread
 __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int ld, int n, int k, double* __restrict__ Dnext)
 {
     const int ti = blockIdx.y, tj = blockIdx.x;
@@ -279,6 +303,130 @@ __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__
 
 // Extend_Solution / Restore_Solution scatter (SFFTConfigure.py:1299-1311; BSplineSFFT.py:2274-2338):
 // solution[idx[i]] = x[i]; removed entries stay zero, tied entries all receive the value of their representative
+// ---- one launch per block step -----------------------------------------------------------------------------------
+// chol_step(k): trailing update with the panel of step k - CB (as chol_update), and, in the tiles of the first trailing block
+// column, the panel work of step k on the freshly updated values (as chol_panel): tile (0, 0) publishes the updated, not yet
+// factored diagonal block (global scratch + an epoch-stamped flag; it is the first workgroup of the grid), every tile of that
+// block column then factors it redundantly and solves its own 64 rows.  Halves the number of dependent launches of the
+// factorisation (update and panel used to be 20 + 27 us each, most of it launch / first-load latency).  Only for full blocks
+// (n - k >= CB); the last, partial block keeps the two-kernel path.
+__global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld, int n, int kp, double* Draw, unsigned int* flag,
+                                                 unsigned int epoch, int* __restrict__ status, double* __restrict__ rd)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16];
+    double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // later: the updated tile T
+    double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // later: start of the PanelLds
+    PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
+    const int tid = threadIdx.x;
+    const int k = kp + CB;                  // this step's first column = start of the trailing matrix
+    const int i0 = k + ti * CB, j0 = k + tj * CB;
+    const int ni = min(CB, n + 1 - i0), nj = min(CB, n - j0);
+    if (ni <= 0 || nj <= 0) return;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it;
+        const int i = e >> 6, t = e & 63;
+        Li[i][t] = (i < ni) ? A[(size_t)(i0 + i) * ld + kp + t] : 0.0;
+        Lj[i][t] = (i < nj) ? A[(size_t)(j0 + i) * ld + kp + t] : 0.0;
+    }
+    const int tx = tid & 15, ty = tid >> 4;
+    double old[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 16 * r, j = tx + 16 * q;
+            const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
+            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
+        }
+    __syncthreads();
+    double c[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[r][q] = 0.0;
+#pragma unroll 8
+    for (int t = 0; t < CB; ++t) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = Li[ty + 16 * r][t];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = Lj[tx + 16 * q][t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[r][q] = fma(av[r], bv[q], c[r][q]);
+    }
+    if (tj != 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = ty + 16 * r, j = tx + 16 * q;
+                if ((i < ni) && (j < nj) && (j0 + j <= i0 + i)) A[(size_t)(i0 + i) * ld + j0 + j] = old[r][q] - c[r][q];
+            }
+        return;
+    }
+    // ---- first trailing block column: the panel of step k (nb = nj = CB columns) --------------------------------------
+    __syncthreads();                        // everyone is done reading Li / Lj
+    double (*T)[CB + 1] = Li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[ty + 16 * r][tx + 16 * q] = old[r][q] - c[r][q];      // (entries outside the tile: 0 - 0)
+    __syncthreads();
+    const int i = tid >> 2, cg = tid & 3;
+    double a[16], p[16];
+    if (ti == 0) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it;
+            Draw[e] = T[e >> 6][e & 63];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cc = cg + 4 * q;
+            a[q] = (cc <= i) ? T[i][cc] : ((i == cc) ? 1.0 : 0.0);
+            p[q] = 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) p[q] = T[i][cg + 4 * q];
+        if (tid == 0) {
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cc = cg + 4 * q;
+            a[q] = (cc <= i) ? __hip_atomic_load(&Draw[i * CB + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((i == cc) ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();                        // T has been read; the PanelLds region (old Lj) may be overwritten
+    chol_factor_diag(a, L, tid, CB, ti == 0, status);
+    if (ti == 0) {
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int r = e >> 6, cc = e & 63;
+            if (cc <= r) A[(size_t)(k + r) * ld + k + cc] = L.Dl[r][cc];
+        }
+        if (tid < CB) rd[k + tid] = L.rdiag[tid];
+        return;
+    }
+    chol_trsm_rows(p, L, tid);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int cc = cg + 4 * q;
+        if (i < ni) A[(size_t)(i0 + i) * ld + k + cc] = p[q];
+    }
+}
+
 // ---- back substitution in two launches -----------------------------------------------------------------------
 // L^T x = y, y = border row of the factor.  A launch per 64-column block (the version above) costs ~20 us per block, almost
 // all of it launch and hand-off latency: 28 blocks -> 0.55 ms at n = 1735.  Instead:
