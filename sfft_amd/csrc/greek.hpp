@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J,
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+#pragma unroll 8                        // eight rows of loads in flight: the kernel is one streaming read of J
     for (int n = tid; n < N1; n += 256) {
         const double v = J[(size_t)l * N1 + n];
 #pragma unroll

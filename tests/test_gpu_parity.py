@@ -168,6 +168,8 @@ ORACLE_CASES = [
     (64, 48, 9, 0, 0, True, "REF", False),      # 4w+1 > N1/2: lags wrap around the image
     (6144, 72, 2, 1, 1, True, "REF", False),    # axis 0 needs the four-step transform (6144 = 2048 x 3)
     (80, 9232, 2, 1, 0, True, "SCI", True),     # axis 1 needs it (9232 = 16 x 577, Bluestein inside)
+    (160, 144, 2, 3, 2, False, "REF", False),   # NEQ = 256 = 4 x 64: the fused Cholesky steps end exactly at the matrix edge
+    (160, 144, 2, 1, 0, True, "REF", False),    # NEQ_FSfree = 74: one fused step would not fit (n < 128), two-kernel path only
 ]
 
 
