@@ -1108,7 +1108,7 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
     if (p->back_variant == 1) {
         hipLaunchKernelGGL(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
         if (++p->back_epoch == 0u) p->back_epoch = 1u;
-        hipLaunchKernelGGL(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->back_epoch);
+        hipLaunchKernelGGL(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->back_epoch, p->d_status);
     } else
     for (int b = nblk - 1; b >= 0; --b) {
         const int kb = b * CB, nb = std::min(CB, n - kb);

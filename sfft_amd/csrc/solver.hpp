@@ -399,8 +399,12 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) p[q] = T[i][cg + 4 * q];
-        if (tid == 0) {
-            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        if (tid == 0) {      // bounded spin (~ seconds): a protocol error must not hang the device; it reports through `status` -> LU fallback
+            long long spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1LL << 26)) { atomicOr(status, 4); break; }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -466,7 +470,7 @@ __global__ void __launch_bounds__(256) chol_inv_diag(const double* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256) chol_back_all(const double* __restrict__ A, int ld, int n, const double* __restrict__ Winv,
-                                                     double* xv, unsigned int* flags, unsigned int epoch)
+                                                     double* xv, unsigned int* flags, unsigned int epoch, int* __restrict__ status)
 {
     __shared__ double Wb[CB][CB + 1];
     __shared__ double Ln[CB][CB + 1];
@@ -486,8 +490,12 @@ __global__ void __launch_bounds__(256) chol_back_all(const double* __restrict__ 
     }
     double acc = 0.0;                                   // threads tid < 64: sum_c (L_cb^T x_c)[tid]
     for (int c = nblk - 1; c > b; --c) {
-        if (tid == 0) {
-            while (__hip_atomic_load(&flags[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        if (tid == 0) {      // bounded spin, as in chol_step
+            long long spins = 0;
+            while (__hip_atomic_load(&flags[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1LL << 26)) { atomicOr(status, 4); break; }
+            }
         }
         __syncthreads();
         const int kc = c * CB, nc = min(CB, n - kc);
