@@ -310,6 +310,8 @@ __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__
 // block column then factors it redundantly and solves its own 64 rows.  Halves the number of dependent launches of the
 // factorisation (update and panel used to be 20 + 27 us each, most of it launch / first-load latency).  Only for full blocks
 // (n - k >= CB); the last, partial block keeps the two-kernel path.
+typedef double d4s __attribute__((ext_vector_type(4)));
+
 __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld, int n, int kp, double* Draw, unsigned int* flag,
                                                  unsigned int epoch, int* __restrict__ status, double* __restrict__ rd)
 {
@@ -331,41 +333,36 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
         Li[i][t] = (i < ni) ? A[(size_t)(i0 + i) * ld + kp + t] : 0.0;
         Lj[i][t] = (i < nj) ? A[(size_t)(j0 + i) * ld + kp + t] : 0.0;
     }
-    const int tx = tid & 15, ty = tid >> 4;
+    // rank-CB update on the matrix cores: wave wv owns rows 16 wv .. 16 wv + 15 of the tile, four 16 x 16 column tiles, 16
+    // k-steps of v_mfma_f64_16x16x4_f64 each (A[i][k] = Li[16 wv + i][4 ks + k], B[k][j] = Lj[16 jt + j][4 ks + k]).
+    // Thread holds C[16 wv + (lane >> 4) + 4 q][16 jt + (lane & 15)] in c[jt][q].
+    const int lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     double old[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = ty + 16 * r, j = tx + 16 * q;
+            const int i = 16 * wv + lk + 4 * q, j = 16 * jt + ln;
             const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
-            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
+            old[jt][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
         }
     __syncthreads();
-    double c[4][4];
+    d4s c[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int jt = 0; jt < 4; ++jt) c[jt] = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < CB / 4; ++ks) {
+        const double av = Li[16 * wv + ln][4 * ks + lk];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) c[r][q] = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < CB; ++t) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = Li[ty + 16 * r][t];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = Lj[tx + 16 * q][t];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[r][q] = fma(av[r], bv[q], c[r][q]);
+        for (int jt = 0; jt < 4; ++jt) c[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Lj[16 * jt + ln][4 * ks + lk], c[jt], 0, 0, 0);
     }
     if (tj != 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = ty + 16 * r, j = tx + 16 * q;
-                if ((i < ni) && (j < nj) && (j0 + j <= i0 + i)) A[(size_t)(i0 + i) * ld + j0 + j] = old[r][q] - c[r][q];
+                const int i = 16 * wv + lk + 4 * q, j = 16 * jt + ln;
+                if ((i < ni) && (j < nj) && (j0 + j <= i0 + i)) A[(size_t)(i0 + i) * ld + j0 + j] = old[jt][q] - c[jt][q];
             }
         return;
     }
@@ -373,9 +370,9 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
     __syncthreads();                        // everyone is done reading Li / Lj
     double (*T)[CB + 1] = Li;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) T[ty + 16 * r][tx + 16 * q] = old[r][q] - c[r][q];      // (entries outside the tile: 0 - 0)
+        for (int q = 0; q < 4; ++q) T[16 * wv + lk + 4 * q][16 * jt + ln] = old[jt][q] - c[jt][q];      // (entries outside the tile: 0 - 0)
     __syncthreads();
     const int i = tid >> 2, cg = tid & 3;
     double a[16], p[16];
