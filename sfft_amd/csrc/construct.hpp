@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256, 4) vconv_mixed(const cplx* __restrict__ s
                                                       cplx* __restrict__ trash)
 {
     constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2, R = KS * L - 2 * W;
-    __shared__ cplx ctab[FIJ * L * 16];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // FIJ * L * 16 complex (up to 64 KB: dynamic)
+    cplx* ctab = reinterpret_cast<cplx*>(smem_raw);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cl = lane & 15, sl = lane >> 4;
     const int m = blockIdx.x * 16 + cl;

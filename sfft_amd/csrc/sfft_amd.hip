@@ -114,7 +114,8 @@ struct sfft_plan {
     double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
     // mixed-domain apply (polynomial kernels on the staged fast path, KerHW <= 8): no column transforms in the apply pass
-    int use_vconv = 0, vw = 8;          // vw = compile-time half width the tables are padded to (4 or 8)
+    int use_vconv = 0, vw = 8;          // vw = compile-time half width the tables are padded to (4, 8 or 12)
+    bool staged_solve = false;          // the solve pass leaves the stage planes of I first in d_stage (4096^2 fast path)
     cplx* d_stage_a = nullptr;          // [DK+1] stage planes of the full image (apply pass)
     cplx* d_ctabm = nullptr;            // [Fij][2 vw + 1][Nhp]
     cplx* d_stage = nullptr;            // fast path: row-pass output, one plane per distinct (image, column factor) (lazy)
@@ -411,10 +412,12 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         if (both_fast && pw > 1 && is_pow2(pw) && p->Nhp % pw == 0) {
             p->lay.shift = ilog2(pw); p->lay.mask = pw - 1; p->lay.rstride = pw; p->lay.pstride = (long long)N0 * pw;
         }
-        // polynomial plans (DK >= 0: made by sfft_plan_create, REF_ij term order) with a small stamp take the mixed-domain apply
-        if (both_fast && !p->no_staged && DK >= 0 && DK <= 3 && p->mode != 3 && KerHW >= 1 && KerHW <= 8 && !getenv("SFFT_NO_VCONV")) {
+        // polynomial plans (DK >= 0: made by sfft_plan_create, REF_ij term order) with a stamp of at most 25 x 25 take the
+        // mixed-domain apply, whatever the image shape: it needs the row pass only, and no transform along axis 0 at all
+        p->staged_solve = both_fast && !p->no_staged;
+        if (DK >= 0 && DK <= 3 && p->mode != 3 && KerHW >= 1 && KerHW <= 12 && !getenv("SFFT_NO_VCONV")) {
             p->use_vconv = 1;
-            p->vw = KerHW <= 4 ? 4 : 8;
+            p->vw = KerHW <= 4 ? 4 : KerHW <= 8 ? 8 : 12;
             PLAN_TRY(dev_alloc(p, &p->d_stage_a, (size_t)(DK + 1) * N0 * p->Nhp));
             PLAN_TRY(dev_alloc(p, &p->d_ctabm, (size_t)p->Fij * (2 * p->vw + 1) * p->Nhp + 256));   // + 256: trash slots of vconv_mixed
         }
@@ -867,7 +870,9 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
 }
 
 // st_rows / st_cols: stage ids that time the row pass / the column pass of this call (-1: not timed)
-static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* dst, hipStream_t s, int st_rows = -1, int st_cols = -1)
+// rows_only: stop after the row pass (the planes are then "stage" planes: row-DFT only)
+static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* dst, hipStream_t s, int st_rows = -1, int st_cols = -1,
+                          bool rows_only = false)
 {
     dim3 g1((p->N0 + 1) / 2, nplanes);
     if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
@@ -896,6 +901,7 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
                            axis_dev(p->ax1), p->scale);
     LAUNCH_CHECK();
     if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
+    if (rows_only) return SFFT_OK;
     if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
     launch_cols(p, dst, nplanes, 0, s);
     if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
@@ -1218,14 +1224,9 @@ static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t 
     StageTimer t(p, SFFT_ST_PRELIM_APPLY, s);
     if (p->use_vconv) {      // only the row pass: DK + 1 stage planes I * cy^j, j = 0 .. DK
         RowsArgs ra;
-        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = p->d_ones; ra.wy[u] = p->d_ones; }
-        RowGroups grp; grp.ngroups = 1; grp.first[0] = 0; grp.count[0] = p->DK + 1;
+        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = nullptr; ra.wy[u] = nullptr; }
         for (int jj = 0; jj <= p->DK; ++jj) { ra.src[jj] = d_I; ra.wy[jj] = p->d_kby + (size_t)jj * p->N1; }
-        const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
-        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, 1), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp, p->d_stage_a, p->N0, p->Nhp,
-                           p->lay, p->ax1.tw, p->scale, rp_per);
-        LAUNCH_CHECK();
-        return SFFT_OK;
+        return forward_planes(p, ra, p->DK + 1, p->d_stage_a, s, -1, -1, true);
     }
     return forward_basis_planes(p, d_I, nullptr, dst, s);
 }
@@ -1243,10 +1244,14 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         constexpr int KS = 4;       // source rows per stream = KS * L (3..10 measured: 4 is best at KerHW 8)
         const int R = KS * LT - 2 * p->vw, nstreams = (p->N0 + R - 1) / R;
         dim3 g((p->Nh + 15) / 16, (nstreams + 15) / 16);
-#define VCONV_LAUNCH(DKT, WT) hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
-                                                 p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp)
-        if (p->vw == 4) { switch (p->DK) { case 0: VCONV_LAUNCH(0, 4); break; case 1: VCONV_LAUNCH(1, 4); break; case 2: VCONV_LAUNCH(2, 4); break; default: VCONV_LAUNCH(3, 4); } }
-        else { switch (p->DK) { case 0: VCONV_LAUNCH(0, 8); break; case 1: VCONV_LAUNCH(1, 8); break; case 2: VCONV_LAUNCH(2, 8); break; default: VCONV_LAUNCH(3, 8); } }
+        const size_t lds = (size_t)p->Fij * LT * 16 * sizeof(cplx);
+#define VCONV_LAUNCH(DKT, WT) do { \
+        HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
+                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } while (0)
+#define VCONV_DK(WT) switch (p->DK) { case 0: VCONV_LAUNCH(0, WT); break; case 1: VCONV_LAUNCH(1, WT); break; case 2: VCONV_LAUNCH(2, WT); break; default: VCONV_LAUNCH(3, WT); }
+        if (p->vw == 4) { VCONV_DK(4) } else if (p->vw == 8) { VCONV_DK(8) } else { VCONV_DK(12) }
+#undef VCONV_DK
 #undef VCONV_LAUNCH
         LAUNCH_CHECK();
     } else {
@@ -1324,15 +1329,16 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
         HIPCHK(hipStreamSynchronize(s));
         return SFFT_OK;
     }
-    if (!p->d_spec2) {
+    if (!p->use_vconv && !p->d_spec2) {      // (the mixed-domain apply keeps its DK + 1 stage planes in d_stage_a instead)
         if ((rc = dev_alloc(p, &p->d_spec2, (size_t)p->Fij * p->N0 * p->Nhp))) return rc;
     }
     if (d_I == d_mI) {
         // the caller passed the full image as its own mask ("'same' means it is identical with I",
         // SFFTSubtract.py:849): the spectra of the solve pass are the spectra of the apply pass
         if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
-        // (mixed-domain apply: the solve pass left the stage planes of I first in d_stage)
-        if ((rc = apply_finish(p, p->use_vconv ? p->d_stage : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+        // (mixed-domain apply: a staged solve pass left the stage planes of I first in d_stage; otherwise they are made now)
+        if (p->use_vconv && !p->staged_solve && (rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
+        if ((rc = apply_finish(p, p->use_vconv ? (p->staged_solve ? p->d_stage : p->d_stage_a) : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
         HIPCHK(hipStreamSynchronize(s));
         return SFFT_OK;
     }
