@@ -109,10 +109,79 @@ __device__ __forceinline__ void lds_fft(cplx* s, int M, int logM, int nb, int st
     }
 }
 
+// Mixed-radix variant for M = 2^log2p * 3^n3 (image axes such as 6144 or 9216): the same two-phase Stockham stages
+// with general index arithmetic, radix-2/4 stages first and the radix-3 stages last.  A thread owns at most
+// ceil(16/R) butterflies of a radix-R stage (same nb*M <= 16*blockDim.x contract as lds_fft).
+template <int R>
+__device__ __forceinline__ void lds_stage_mixed(cplx* s, int M, int p, int nb, int stride, const cplx* __restrict__ tw)
+{
+    constexpr int IT = (R == 2) ? 8 : (R == 4) ? 4 : 6;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int T = M / R, total = nb * T, step = T / p;       // twiddle step M/(R p)
+    cplx y[IT][R];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g / T, i = g - f * T;
+            const int k = i % p;
+            const cplx* b = s + f * stride;
+            cplx u[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = b[i + r * T];
+            if (p > 1) {
+                const int q = k * step;
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[q * r]);
+            }
+            if constexpr (R == 2) {
+                y[it][0] = cadd(u[0], u[1]);
+                y[it][1] = csub(u[0], u[1]);
+            } else if constexpr (R == 3) {
+                const double S3 = 0.86602540378443864676;      // sin(pi/3)
+                const cplx t1 = cadd(u[1], u[2]), d = csub(u[1], u[2]);
+                const cplx t2 = make_double2(u[0].x - 0.5 * t1.x, u[0].y - 0.5 * t1.y);
+                y[it][0] = cadd(u[0], t1);
+                // -i*S3*d = (S3*d.y, -S3*d.x)
+                y[it][1] = make_double2(t2.x + S3 * d.y, t2.y - S3 * d.x);
+                y[it][2] = make_double2(t2.x - S3 * d.y, t2.y + S3 * d.x);
+            } else {
+                const cplx a02 = cadd(u[0], u[2]), s02 = csub(u[0], u[2]);
+                const cplx a13 = cadd(u[1], u[3]), s13 = csub(u[1], u[3]);
+                y[it][0] = cadd(a02, a13);
+                y[it][2] = csub(a02, a13);
+                y[it][1] = make_double2(s02.x + s13.y, s02.y - s13.x);
+                y[it][3] = make_double2(s02.x - s13.y, s02.y + s13.x);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g / T, i = g - f * T;
+            const int k = i % p;
+            cplx* b = s + f * stride + ((i - k) * R + k);
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r * p] = y[it][r];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lds_fft_mixed(cplx* s, int M, int log2p, int n3, int nb, int stride, const cplx* __restrict__ tw)
+{
+    int p = 1;
+    if (log2p & 1) { lds_stage_mixed<2>(s, M, p, nb, stride, tw); p = 2; }
+    for (int l = log2p & 1; l < log2p; l += 2) { lds_stage_mixed<4>(s, M, p, nb, stride, tw); p *= 4; }
+    for (int l = 0; l < n3; ++l) { lds_stage_mixed<3>(s, M, p, nb, stride, tw); p *= 3; }
+}
+
 // One 1-D axis: length N transformed either directly (N = M power of two) or by Bluestein's chirp-z
-// (M = power of two >= 2N-1).  All tables live in device memory.
+// (M = power of two >= 2N-1), or directly with N = M = 2^logM * 3^n3.  All tables live in device memory.
 struct AxisDev {
-    int N, M, logM, blue;
+    int N, M, logM, blue, n3;
     const cplx* tw;     // [M]   exp(-2 pi i k / M)
     const cplx* chirp;  // [N]   exp(-i pi n^2 / N)            (Bluestein only)
     const cplx* bf;     // [M]   FFT_M(conj-chirp filter) / M  (Bluestein only)
@@ -124,6 +193,7 @@ struct AxisDev {
 __device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int stride)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (ax.n3) { lds_fft_mixed(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw); return; }
     if (!ax.blue) { lds_fft(s, ax.M, ax.logM, nb, stride, ax.tw); return; }
     const int M = ax.M;
     for (int e = tid; e < nb * M; e += nt) {           // a[n] = x[n] * chirp[n]

@@ -57,7 +57,7 @@ extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 // host side
 // ================================================================================================
 struct AxisHost {
-    int N = 0, M = 0, logM = 0, blue = 0;
+    int N = 0, M = 0, logM = 0, blue = 0, n3 = 0;   // n3 > 0: M = N = 2^logM * 3^n3 (mixed-radix on-chip transform)
     cplx *tw = nullptr, *chirp = nullptr, *bf = nullptr, *root = nullptr;
     bool root_is_tw = false;
     // four-step decomposition for lengths that do not fit one on-chip transform: N = A * B
@@ -193,11 +193,25 @@ static void host_fft_pow2(std::vector<long double>& re, std::vector<long double>
 }
 
 static const size_t LDS_MAX_ELEMS = 8192;   // longest on-chip transform: 128 KiB of complex128 (160 KiB LDS per CU on gfx950)
+static const size_t LDS_MIXED_ELEMS = 9216; // longest 2^a*3^b transform: 144 KiB (+16 B of column padding)
 static const size_t LDS_COL_ELEMS = 9216;   // column tile budget (144 KiB): two padded 4096-point columns fit
+
+// N = 2^a * 3^b with b >= 1: writes a, b
+static bool is_2a3b(int N, int* a, int* b)
+{
+    int e2 = 0, e3 = 0;
+    while (N % 2 == 0) { N /= 2; ++e2; }
+    while (N % 3 == 0) { N /= 3; ++e3; }
+    if (N != 1 || e3 == 0) return false;
+    *a = e2; *b = e3;
+    return true;
+}
 
 static bool fits_on_chip(int N)
 {
     if (is_pow2(N)) return (size_t)N <= LDS_MAX_ELEMS;
+    int a, b;
+    if (is_2a3b(N, &a, &b) && (size_t)N <= LDS_MIXED_ELEMS && !getenv("SFFT_NO_MIXED_RADIX")) return true;
     int M = 1; while (M < 2 * N - 1) M <<= 1;
     return (size_t)M <= LDS_MAX_ELEMS;
 }
@@ -235,9 +249,11 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
     const long double PI = acosl(-1.0L);
     if (!fits_on_chip(N)) return build_big_axis(p, ax, N);
     ax.N = N;
+    int e2 = 0, e3 = 0;
     if (is_pow2(N)) { ax.M = N; ax.blue = 0; }
+    else if (is_2a3b(N, &e2, &e3) && !getenv("SFFT_NO_MIXED_RADIX")) { ax.M = N; ax.blue = 0; ax.n3 = e3; }
     else { int M = 1; while (M < 2 * N - 1) M <<= 1; ax.M = M; ax.blue = 1; }
-    ax.logM = ilog2(ax.M);
+    ax.logM = ax.n3 ? e2 : ilog2(ax.M);
     int rc;
     std::vector<cplx> h(ax.M);
     for (int k = 0; k < ax.M; ++k) {
@@ -276,7 +292,7 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
 
 static AxisDev axis_dev(const AxisHost& a)
 {
-    AxisDev d; d.N = a.N; d.M = a.M; d.logM = a.logM; d.blue = a.blue; d.tw = a.tw; d.chirp = a.chirp; d.bf = a.bf; d.root = a.root;
+    AxisDev d; d.N = a.N; d.M = a.M; d.logM = a.logM; d.blue = a.blue; d.n3 = a.n3; d.tw = a.tw; d.chirp = a.chirp; d.bf = a.bf; d.root = a.root;
     return d;
 }
 
@@ -424,14 +440,14 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     }
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
     if (!p->ax1.big) {
-        p->nt_rows = std::min(1024, std::max(64, p->ax1.M / 16));
+        p->nt_rows = std::min(1024, std::max(64, (p->ax1.M + 15) / 16));
         p->lds_rows = (size_t)p->ax1.M * sizeof(cplx);
     }
     if (!p->ax0.big) {
         p->MS = p->ax0.M + 1;
         p->TC = 1;
         while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS) p->TC *= 2;
-        p->nt_cols = std::min(1024, std::max(64, p->TC * p->ax0.M / 16));
+        p->nt_cols = std::min(1024, std::max(64, (p->TC * p->ax0.M + 15) / 16));
         p->lds_cols = (size_t)p->TC * p->MS * sizeof(cplx);
     }
     PLAN_HIP(hipFuncSetAttribute((const void*)strided_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -825,7 +841,7 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
     const int MS = sub.M + 1;
     int TC = 1;
     while (TC < 16 && (size_t)(2 * TC) * MS <= LDS_COL_ELEMS) TC *= 2;
-    const int nt = std::min(1024, std::max(64, TC * sub.M / 16));
+    const int nt = std::min(1024, std::max(64, (TC * sub.M + 15) / 16));
     const int ngroups = (d.mode == 2) ? (d.nlines + TC - 1) / TC : (d.J + TC - 1) / TC;
     const int gy = (d.mode == 2) ? d.J : d.nlines;
     hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, MS);

@@ -46,7 +46,9 @@ NAMES = golden_names()
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(8, 8), (64, 64), (128, 32), (48, 40), (45, 35), (100, 96), (512, 256), (300, 500),
                                    (1024, 2048), (4096, 64), (64, 4096), (4096, 4096), (4095, 4096), (8192, 16),
-                                   (6144, 40), (40, 6144), (9232, 64), (64, 9216), (4100, 5000)])   # last rows: four-step axes
+                                   (6144, 40), (40, 6144), (9232, 64), (64, 9216), (4100, 5000),     # big axes
+                                   (12, 24), (9, 18), (27, 24), (81, 162), (96, 1536), (1536, 96), (8748, 16), (16, 8748),
+                                   (9216, 24), (2304, 3072)])   # last rows: 2^a*3^b axes (mixed-radix on-chip transform)
 @pytest.mark.parametrize("ij", [(0, 0), (2, 1)])
 def test_forward_spectrum_matches_numpy_fft2(dev, shape, ij):
     from sfft_amd.plan import get_plan
@@ -613,7 +615,7 @@ def test_varying_scaling_large_shape_properties(dev):
 # ------------------------------------------------------------------------------------------------
 # (f) FFT utilities / noise decorrelation
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(64, 64), (276, 300), (4096, 128), (100, 4100)])
+@pytest.mark.parametrize("shape", [(64, 64), (276, 300), (4096, 128), (100, 4100), (6144, 48), (72, 9216)])
 def test_rfft2_irfft2_roundtrip_and_numpy(dev, shape):
     from sfft_amd.fftkit import get_fft_plan
     rng = np.random.default_rng(shape[0])
