@@ -60,7 +60,12 @@ __global__ void __launch_bounds__(1024) cols_c2c(cplx* __restrict__ data, int N0
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* s = reinterpret_cast<cplx*>(smem_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int c0 = blockIdx.x * TC;
+    // workgroups are dealt round-robin to the 8 XCDs: give the 8/TC tiles that share 128-byte lines to one XCD, back to back,
+    // so that the partially used lines are served by that XCD's L2 (grid x is padded to a multiple of 8 * G by the launcher)
+    const int G = TC >= 8 ? 1 : 8 / TC;
+    const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int c0 = (((t / G) * 8 + xcd) * G + t % G) * TC;
+    if (c0 >= ncols) return;
     cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp;
     for (int e = tid; e < TC * ax.M; e += nt) {
         const int l = e / TC, c = e - l * TC;

@@ -84,7 +84,7 @@ struct RowGroups { int ngroups; int first[SFFT_MAX_PLANES]; int count[SFFT_MAX_P
 
 // Workgroup b takes row pair (b % 8) * pairs_per_xcd + b / 8: consecutive row pairs run on one XCD, so that with a panel
 // layout the pieces of a 128-byte line written by neighbouring row pairs merge in that XCD's L2.
-__global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp, SpecLayout lay,
+__global__ void __launch_bounds__(256, 2) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp, SpecLayout lay,
                                                      const cplx* __restrict__ tw, double scale, int pairs_per_xcd)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -123,7 +123,11 @@ __global__ void __launch_bounds__(256) rows_r2c_4096(RowsArgs a, RowGroups grp, 
             u[r] = make_double2(x0[r] * (cx0 * cyp), x1[r] * (cx1 * cyp));
         }
         if (pp > 0) __syncthreads();            // the previous plane's partner reads are done
-        fft4096_core(u, j, lds, tw);
+        // (an offset the compiler cannot see through: otherwise the 30 stage twiddles are hoisted out of the plane loop,
+        //  which costs 120 registers and halves the occupancy)
+        int zoff;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+        fft4096_core(u, j, lds, tw + zoff);
         __syncthreads();
 #pragma unroll
         for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)];

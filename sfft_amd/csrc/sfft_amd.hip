@@ -879,7 +879,8 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
         hipLaunchKernelGGL(cols_c2c_4096, dim3(8 * per, nplanes), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, data, p->Nh, p->Nhp,
                            p->lay, p->ax0.tw, inverse, 1.0, per);
     } else {
-        dim3 g2((p->Nh + p->TC - 1) / p->TC, nplanes);
+        const int G8 = 8 * (p->TC >= 8 ? 1 : 8 / p->TC);
+        dim3 g2(((p->Nh + p->TC - 1) / p->TC + G8 - 1) / G8 * G8, nplanes);
         hipLaunchKernelGGL(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, data, p->N0, p->Nh, p->Nhp, p->TC, p->MS,
                            axis_dev(p->ax0), inverse, 1.0);
     }
