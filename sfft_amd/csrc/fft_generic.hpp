@@ -89,6 +89,52 @@ __global__ void __launch_bounds__(1024) cols_c2c(cplx* __restrict__ data, int N0
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward column pass of weighted planes, out of place.  Every spatial term is  I * fx(row) * fy(col): the row pass applies fy
+// only (one "stage" plane per distinct (image, column factor)), and each output plane is the column transform of its stage
+// plane times fx[row].  1-D grid; on one XCD the order is: the G tiles that share 128-byte lines, then the next output of
+// the same tile group -- outputs that share a stage plane find its tile in that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+#define COLG_MAX_OUT 32
+struct ColOuts {
+    int nout;
+    int stage_plane[COLG_MAX_OUT];                // source plane in the stage buffer
+    int out_plane[COLG_MAX_OUT];                  // destination plane
+    const double* wx[COLG_MAX_OUT];               // [N0] row factor
+};
+
+__global__ void __launch_bounds__(1024) cols_fwd_weighted(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int N0, int ncols,
+                                                           int Nhp, int TC, int MS, AxisDev ax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int G = TC >= 8 ? 1 : 8 / TC;
+    const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int gq = t % G, o = (t / G) % g.nout, tg = t / (G * g.nout);
+    const int c0 = ((tg * 8 + xcd) * G + gq) * TC;
+    if (c0 >= ncols) return;
+    const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * N0 * Nhp;
+    cplx* __restrict__ dst = out + (size_t)g.out_plane[o] * N0 * Nhp;
+    const double* __restrict__ wx = g.wx[o];
+    for (int e = tid; e < TC * ax.M; e += nt) {
+        const int l = e / TC, c = e - l * TC;
+        cplx z = make_double2(0.0, 0.0);
+        if (l < N0 && c0 + c < ncols) {
+            z = src[(size_t)l * Nhp + c0 + c];
+            const double f = wx[l];
+            z.x *= f; z.y *= f;
+        }
+        s[c * MS + l] = z;
+    }
+    __syncthreads();
+    lds_dft(s, ax, TC, MS);
+    for (int e = tid; e < TC * N0; e += nt) {
+        const int l = e / TC, c = e - l * TC;
+        if (c0 + c < ncols) dst[(size_t)l * Nhp + c0 + c] = s[c * MS + l];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // inverse pass 2: rows, half complex -> real, two rows per transform, DIFF epilogue fused:
 //   DIFF = J - sum_pq b_pq cx^p cy^q - conv          (SFFTSubtract.py:452-461 with the J and T terms kept in real space)
 // ------------------------------------------------------------------------------------------------

@@ -186,13 +186,6 @@ __global__ void __launch_bounds__(512) cols_c2c_4096(cplx* __restrict__ data, in
 // One workgroup per (tile, output).  The 1-D grid is de-interleaved per XCD with the output index fastest, so the
 // workgroups that read the same stage tile -- and the neighbouring tiles that share its 128-byte lines -- run back to back
 // on one XCD: the tile comes from HBM once and from that XCD's L2 afterwards.
-#define COLG_MAX_OUT 32
-struct ColOuts {
-    int nout;
-    int stage_plane[COLG_MAX_OUT];                // source plane in the stage buffer
-    int out_plane[COLG_MAX_OUT];                  // destination plane
-    const double* wx[COLG_MAX_OUT];               // [N0] row factor
-};
 
 __global__ void __launch_bounds__(512) cols_fwd_weighted_4096(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int ncols,
                                                               int Nhp, SpecLayout lay, const cplx* __restrict__ tw, int npairs)

@@ -463,6 +463,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)lu_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if ((size_t)(p->NEQfs + 2) * 8 + (size_t)CB * (CB + 1) * 8 > 150 * 1024) {
@@ -956,6 +957,36 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
         p->n_stage_alloc = nst;
     }
     const size_t plane_sz = (size_t)p->N0 * p->Nhp;
+    const bool fast = !p->no_fast_fft && fast_axis(p->ax0) && fast_axis(p->ax1);
+    if (!fast) {
+        // generic shapes: the ordinary row pass (any axis-1 length) per stage plane, then the weighted on-chip column pass
+        for (int k0 = 0; k0 < nst; k0 += SFFT_MAX_PLANES) {
+            const int n = std::min(SFFT_MAX_PLANES, nst - k0);
+            RowsArgs ra;
+            for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = nullptr; ra.wy[u] = nullptr; }
+            for (int u = 0; u < n; ++u) { ra.src[u] = stages[k0 + u].src; ra.wy[u] = stages[k0 + u].wy; }
+            int rc = forward_planes(p, ra, n, p->d_stage + (size_t)k0 * plane_sz, s, st_rows, -1, true);
+            if (rc) return rc;
+        }
+        if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
+        const int G = p->TC >= 8 ? 1 : 8 / p->TC;
+        const int ntiles = (p->Nh + p->TC - 1) / p->TC;
+        const int ntg = (ntiles + 8 * G - 1) / (8 * G);           // tile groups per XCD
+        int k = 0;
+        while (k < nst) {
+            ColOuts g; memset(&g, 0, sizeof(g));
+            while (k < nst && g.nout + (int)stages[k].outs.size() <= COLG_MAX_OUT) {
+                for (const Out& o : stages[k].outs) { g.stage_plane[g.nout] = k; g.out_plane[g.nout] = o.plane; g.wx[g.nout] = o.wx; ++g.nout; }
+                ++k;
+            }
+            if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
+            hipLaunchKernelGGL(cols_fwd_weighted, dim3(8 * G * g.nout * ntg), dim3(p->nt_cols), p->lds_cols, s, p->d_stage, dst, g, p->N0, p->Nh,
+                               p->Nhp, p->TC, p->MS, axis_dev(p->ax0));
+        }
+        LAUNCH_CHECK();
+        if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
+        return SFFT_OK;
+    }
     if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
     const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
     for (int k0 = 0; k0 < nst; k0 += SFFT_MAX_PLANES) {
@@ -995,7 +1026,8 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
 static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca = false,
                                 int st_rows = -1, int st_cols = -1)
 {
-    if (!p->no_fast_fft && !p->no_staged && fast_axis(p->ax0) && fast_axis(p->ax1))
+    // staged: one row transform per distinct column factor.  Needs an on-chip column pass; pays when planes share factors
+    if (!p->no_staged && !p->ax0.big)
         return forward_basis_planes_staged(p, d_I, d_J, dst, s, with_sca, st_rows, st_cols);
     const int total = p->Fij + (d_J ? 1 : 0) + ((with_sca && d_J) ? p->nsca : 0);
     const size_t plane_sz = (size_t)p->N0 * p->Nhp;
