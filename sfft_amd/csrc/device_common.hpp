@@ -29,6 +29,168 @@ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x +
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double ipow(double x, int e) { double r = 1.0; for (int t = 0; t < e; ++t) r *= x; return r; }
 
+#define R16_OUT(s) (4 * ((s) & 3) + ((s) >> 2))      // register holding output s of dft16()
+
+__device__ __forceinline__ void dft4(cplx& a, cplx& b, cplx& c, cplx& d)
+{
+    const cplx s02 = cadd(a, c), d02 = csub(a, c), s13 = cadd(b, d), d13 = csub(b, d);
+    a = cadd(s02, s13);
+    c = csub(s02, s13);
+    b = make_double2(d02.x + d13.y, d02.y - d13.x);   // d02 - i d13
+    d = make_double2(d02.x - d13.y, d02.y + d13.x);   // d02 + i d13
+}
+
+// forward 16-point DFT in registers; output s ends in u[R16_OUT(s)]
+__device__ __forceinline__ void dft16(cplx (&u)[16])
+{
+    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(u[b], u[4 + b], u[8 + b], u[12 + b]);
+    // u[4c + b] *= W16^(b c)
+    u[5] = cmul(u[5], make_double2(c1, -s1));          // W^1
+    u[6] = cmul(u[6], make_double2(h, -h));            // W^2
+    u[7] = cmul(u[7], make_double2(s1, -c1));          // W^3
+    u[9] = cmul(u[9], make_double2(h, -h));            // W^2
+    u[10] = make_double2(u[10].y, -u[10].x);           // W^4 = -i
+    u[11] = cmul(u[11], make_double2(-h, -h));         // W^6
+    u[13] = cmul(u[13], make_double2(s1, -c1));        // W^3
+    u[14] = cmul(u[14], make_double2(-h, -h));         // W^6
+    u[15] = cmul(u[15], make_double2(-c1, s1));        // W^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(u[4 * c], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);
+}
+
+// u[r] *= tw[r q], r = 1..15, from four table entries (products of at most three factors)
+__device__ __forceinline__ void twiddle16(cplx (&u)[16], const cplx* __restrict__ tw, int q)
+{
+    const cplx w1 = tw[q], w2 = tw[2 * q], w4 = tw[4 * q], w8 = tw[8 * q];
+    const cplx w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
+    const cplx w7 = cmul(w4, w3);
+    u[1] = cmul(u[1], w1); u[2] = cmul(u[2], w2); u[3] = cmul(u[3], w3); u[4] = cmul(u[4], w4);
+    u[5] = cmul(u[5], w5); u[6] = cmul(u[6], w6); u[7] = cmul(u[7], w7); u[8] = cmul(u[8], w8);
+    u[9] = cmul(u[9], cmul(w8, w1)); u[10] = cmul(u[10], cmul(w8, w2)); u[11] = cmul(u[11], cmul(w8, w3));
+    u[12] = cmul(u[12], cmul(w8, w4)); u[13] = cmul(u[13], cmul(w8, w5)); u[14] = cmul(u[14], cmul(w8, w6));
+    u[15] = cmul(u[15], cmul(w8, w7));
+}
+
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+
+// forward 8-point DFT in registers, outputs in natural order
+__device__ __forceinline__ void dft8(cplx (&u)[8])
+{
+    const double h = 0.70710678118654752440;
+    dft4(u[0], u[2], u[4], u[6]);          // even samples -> E[0..3] in u[0], u[2], u[4], u[6]
+    dft4(u[1], u[3], u[5], u[7]);          // odd samples  -> O[0..3] in u[1], u[3], u[5], u[7]
+    const cplx o1 = cmul(u[3], make_double2(h, -h));
+    const cplx o2 = make_double2(u[5].y, -u[5].x);
+    const cplx o3 = cmul(u[7], make_double2(-h, -h));
+    const cplx e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1];
+    u[0] = cadd(e0, o0); u[4] = csub(e0, o0);
+    u[1] = cadd(e1, o1); u[5] = csub(e1, o1);
+    u[2] = cadd(e2, o2); u[6] = csub(e2, o2);
+    u[3] = cadd(e3, o3); u[7] = csub(e3, o3);
+}
+
+// Radix-16 Stockham FFT for M = 2^logM >= 16: one leading radix-2/4/8 stage when logM is not a multiple of 4 (no twiddles),
+// then radix-16 stages: half the passes over LDS and half the barriers of the radix-4 version below, and the 15 twiddles of
+// a butterfly come from four table entries.  Same contract (nb * M <= 16 * blockDim.x, every thread calls).  Between the
+// stages the sequence lives in a padded layout (element i at i + i / 16, so that the stride-16 writes of the first radix-16
+// stage spread over the banks): each sequence needs M + M / 16 elements of LDS; input and result are in natural order.
+// PRE: input element n is multiplied by pre[n] on the way in (n < npre; the rest of the sequence is zero) -- Bluestein's chirp
+template <int R, bool PRE>
+__device__ __forceinline__ void lds_stage_small(cplx* s, int M, int logM, int nb, int stride, const cplx* __restrict__ pre, int npre)
+{
+    constexpr int IT = 16 / R, LR = (R == 2) ? 1 : (R == 4) ? 2 : 3;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int T = M / R, logT = logM - LR, total = nb * T;
+    cplx y[IT][R];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g >> logT, i = g & (T - 1);
+            const cplx* b = s + f * stride;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                y[it][r] = b[i + r * T];
+                if (PRE) y[it][r] = cmul(y[it][r], pre[min(i + r * T, npre - 1)]);      // (entries >= npre are zero)
+            }
+            if constexpr (R == 2) { const cplx a = y[it][0], c = y[it][1]; y[it][0] = cadd(a, c); y[it][1] = csub(a, c); }
+            else if constexpr (R == 4) dft4(y[it][0], y[it][1], y[it][2], y[it][3]);
+            else dft8(y[it]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g >> logT, i = g & (T - 1);
+            cplx* b = s + f * stride;
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[pad16(i * R + r)] = y[it][r];
+        }
+    }
+    __syncthreads();
+}
+
+// POST (applied to output k of the last stage): 1: conj(X[k] * post[k]) -- the Bluestein filter; the next forward transform then
+// acts as the inverse one;  2: post[k] * conj(X[k]) for k < npost -- the closing chirp
+template <bool PRE, int POST>
+__device__ __forceinline__ void lds_fft_r16(cplx* s, int M, int logM, int nb, int stride, const cplx* __restrict__ tw,
+                                            const cplx* __restrict__ pre, int npre, const cplx* __restrict__ post, int npost)
+{
+    const int tid = threadIdx.x;
+    const int rem = logM & 3;
+    if (rem == 1) lds_stage_small<2, PRE>(s, M, logM, nb, stride, pre, npre);
+    else if (rem == 2) lds_stage_small<4, PRE>(s, M, logM, nb, stride, pre, npre);
+    else if (rem == 3) lds_stage_small<8, PRE>(s, M, logM, nb, stride, pre, npre);
+    bool padded = rem != 0;
+    const int T = M >> 4, logT = logM - 4, total = nb * T;
+    const bool mine = tid < total;
+    const int f = tid >> logT, i = tid & (T - 1);
+    cplx* b = s + f * stride;
+    for (int logp = rem; logp < logM; logp += 4) {
+        const int p = 1 << logp;
+        const int k = i & (p - 1);
+        const bool last = logp + 4 >= logM;
+        cplx u[16];
+        if (mine) {
+            if (padded) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = b[pad16(i + r * T)];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    u[r] = b[i + r * T];
+                    if (PRE) u[r] = cmul(u[r], pre[min(i + r * T, npre - 1)]);
+                }
+            }
+            if (logp > 0) twiddle16(u, tw, k << (logM - logp - 4));
+            dft16(u);
+        }
+        __syncthreads();
+        if (mine) {
+            const int o = ((i - k) << 4) + k;
+            if (last) {
+#pragma unroll
+                for (int sx = 0; sx < 16; ++sx) {
+                    cplx v = u[R16_OUT(sx)];
+                    const int kk = o + sx * p;
+                    if (POST == 1) v = cconj(cmul(v, post[kk]));
+                    if (POST == 2) v = cmul(post[min(kk, npost - 1)], cconj(v));
+                    b[kk] = v;
+                }
+            } else {
+#pragma unroll
+                for (int sx = 0; sx < 16; ++sx) b[pad16(o + sx * p)] = u[R16_OUT(sx)];
+            }
+        }
+        __syncthreads();
+        padded = true;
+    }
+}
+
 // In-place Stockham autosort FFT (forward, e^{-i}) of `nb` transforms of length M = 2^logM held in LDS at
 // s + f*stride.  Radix-4 stages (one leading radix-2 stage when logM is odd).  Every thread of the block
 // must call; requires nb*M <= 16*blockDim.x so that a thread owns at most 4 radix-4 butterflies per stage.
@@ -181,12 +343,18 @@ __device__ __forceinline__ void lds_fft_mixed(cplx* s, int M, int log2p, int n3,
 // One 1-D axis: length N transformed either directly (N = M power of two) or by Bluestein's chirp-z
 // (M = power of two >= 2N-1), or directly with N = M = 2^logM * 3^n3.  All tables live in device memory.
 struct AxisDev {
-    int N, M, logM, blue, n3;
+    int N, M, logM, blue, n3, r16;     // r16: power-of-two M >= 16 on the radix-16 stages (sequence needs M + M/16 LDS elements)
     const cplx* tw;     // [M]   exp(-2 pi i k / M)
     const cplx* chirp;  // [N]   exp(-i pi n^2 / N)            (Bluestein only)
     const cplx* bf;     // [M]   FFT_M(conj-chirp filter) / M  (Bluestein only)
     const cplx* root;   // [N]   exp(-2 pi i k / N)
 };
+
+__device__ __forceinline__ void lds_fft_pow2(cplx* s, const AxisDev& ax, int nb, int stride)
+{
+    if (ax.r16) lds_fft_r16<false, 0>(s, ax.M, ax.logM, nb, stride, ax.tw, nullptr, 0, nullptr, 0);
+    else lds_fft(s, ax.M, ax.logM, nb, stride, ax.tw);
+}
 
 // forward length-N DFT of nb sequences already resident in LDS (entries n >= N must be zero when blue).
 // On return entries [0, N) of each sequence hold the DFT.
@@ -194,7 +362,14 @@ __device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int 
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     if (ax.n3) { lds_fft_mixed(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw); return; }
-    if (!ax.blue) { lds_fft(s, ax.M, ax.logM, nb, stride, ax.tw); return; }
+    if (!ax.blue) { lds_fft_pow2(s, ax, nb, stride); return; }
+    if (ax.r16) {
+        // Bluestein with the three pointwise products folded into the transforms' first read / last write:
+        //   a = x * chirp;  A = FFT(a);  c = conj(A * Bf);  C = FFT(c);  X[k] = chirp[k] * conj(C[k])
+        lds_fft_r16<true, 1>(s, ax.M, ax.logM, nb, stride, ax.tw, ax.chirp, ax.N, ax.bf, ax.M);
+        lds_fft_r16<false, 2>(s, ax.M, ax.logM, nb, stride, ax.tw, nullptr, 0, ax.chirp, ax.N);
+        return;
+    }
     const int M = ax.M;
     for (int e = tid; e < nb * M; e += nt) {           // a[n] = x[n] * chirp[n]
         const int f = e / M, n = e - f * M;

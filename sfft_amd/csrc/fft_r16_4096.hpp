@@ -8,52 +8,8 @@
 // three radix-16 stages (4096 = 16^3); LDS is used only for the two inter-stage exchanges (padded by one
 // element per 16 so that the stride-16 writes of stage 1 are conflict free), not as the working array.
 // ================================================================================================
-#define R16_OUT(s) (4 * ((s) & 3) + ((s) >> 2))      // register holding output s of dft16()
 #define F4K_LDS 4352                                 // 4096 + 4096/16 complex per transform
 
-__device__ __forceinline__ void dft4(cplx& a, cplx& b, cplx& c, cplx& d)
-{
-    const cplx s02 = cadd(a, c), d02 = csub(a, c), s13 = cadd(b, d), d13 = csub(b, d);
-    a = cadd(s02, s13);
-    c = csub(s02, s13);
-    b = make_double2(d02.x + d13.y, d02.y - d13.x);   // d02 - i d13
-    d = make_double2(d02.x - d13.y, d02.y + d13.x);   // d02 + i d13
-}
-
-// forward 16-point DFT in registers; output s ends in u[R16_OUT(s)]
-__device__ __forceinline__ void dft16(cplx (&u)[16])
-{
-    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(u[b], u[4 + b], u[8 + b], u[12 + b]);
-    // u[4c + b] *= W16^(b c)
-    u[5] = cmul(u[5], make_double2(c1, -s1));          // W^1
-    u[6] = cmul(u[6], make_double2(h, -h));            // W^2
-    u[7] = cmul(u[7], make_double2(s1, -c1));          // W^3
-    u[9] = cmul(u[9], make_double2(h, -h));            // W^2
-    u[10] = make_double2(u[10].y, -u[10].x);           // W^4 = -i
-    u[11] = cmul(u[11], make_double2(-h, -h));         // W^6
-    u[13] = cmul(u[13], make_double2(s1, -c1));        // W^3
-    u[14] = cmul(u[14], make_double2(-h, -h));         // W^6
-    u[15] = cmul(u[15], make_double2(-c1, s1));        // W^9
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dft4(u[4 * c], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);
-}
-
-// u[r] *= tw[r q], r = 1..15, from four table entries (products of at most three factors)
-__device__ __forceinline__ void twiddle16(cplx (&u)[16], const cplx* __restrict__ tw, int q)
-{
-    const cplx w1 = tw[q], w2 = tw[2 * q], w4 = tw[4 * q], w8 = tw[8 * q];
-    const cplx w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
-    const cplx w7 = cmul(w4, w3);
-    u[1] = cmul(u[1], w1); u[2] = cmul(u[2], w2); u[3] = cmul(u[3], w3); u[4] = cmul(u[4], w4);
-    u[5] = cmul(u[5], w5); u[6] = cmul(u[6], w6); u[7] = cmul(u[7], w7); u[8] = cmul(u[8], w8);
-    u[9] = cmul(u[9], cmul(w8, w1)); u[10] = cmul(u[10], cmul(w8, w2)); u[11] = cmul(u[11], cmul(w8, w3));
-    u[12] = cmul(u[12], cmul(w8, w4)); u[13] = cmul(u[13], cmul(w8, w5)); u[14] = cmul(u[14], cmul(w8, w6));
-    u[15] = cmul(u[15], cmul(w8, w7));
-}
-
-__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
 // 4096-point forward FFT.  In: u[r] = x[j + 256 r].  Out: u[R16_OUT(s)] = X[j + 256 s].  j in [0, 256).
 // `lds` = this transform's F4K_LDS-element scratch.  Every thread of the block must call (barriers inside).

@@ -57,6 +57,7 @@ extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 // host side
 // ================================================================================================
 struct AxisHost {
+    int r16 = 0;                                    // power-of-two M >= 16: radix-16 stages (M + M/16 LDS elements per sequence)
     int N = 0, M = 0, logM = 0, blue = 0, n3 = 0;   // n3 > 0: M = N = 2^logM * 3^n3 (mixed-radix on-chip transform)
     cplx *tw = nullptr, *chirp = nullptr, *bf = nullptr, *root = nullptr;
     bool root_is_tw = false;
@@ -194,7 +195,8 @@ static void host_fft_pow2(std::vector<long double>& re, std::vector<long double>
 
 static const size_t LDS_MAX_ELEMS = 8192;   // longest on-chip transform: 128 KiB of complex128 (160 KiB LDS per CU on gfx950)
 static const size_t LDS_MIXED_ELEMS = 9216; // longest 2^a*3^b transform: 144 KiB (+16 B of column padding)
-static const size_t LDS_COL_ELEMS = 9216;   // column tile budget (144 KiB): two padded 4096-point columns fit
+static size_t lds_col_elems() { static size_t v = getenv("SFFT_COL_ELEMS") ? (size_t)atol(getenv("SFFT_COL_ELEMS")) : 9216; return v; }
+#define LDS_COL_ELEMS lds_col_elems()      // column tile budget (144 KiB): two padded 4096-point columns fit
 
 // N = 2^a * 3^b with b >= 1: writes a, b
 static bool is_2a3b(int N, int* a, int* b)
@@ -254,6 +256,7 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
     else if (is_2a3b(N, &e2, &e3) && !getenv("SFFT_NO_MIXED_RADIX")) { ax.M = N; ax.blue = 0; ax.n3 = e3; }
     else { int M = 1; while (M < 2 * N - 1) M <<= 1; ax.M = M; ax.blue = 1; }
     ax.logM = ax.n3 ? e2 : ilog2(ax.M);
+    ax.r16 = (!ax.n3 && ax.M >= 16 && !getenv("SFFT_NO_R16")) ? 1 : 0;
     int rc;
     std::vector<cplx> h(ax.M);
     for (int k = 0; k < ax.M; ++k) {
@@ -290,9 +293,12 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
     return SFFT_OK;
 }
 
+// LDS elements one sequence of this axis needs
+static int axis_lds_len(const AxisHost& a) { return a.r16 ? a.M + a.M / 16 : a.M; }
+
 static AxisDev axis_dev(const AxisHost& a)
 {
-    AxisDev d; d.N = a.N; d.M = a.M; d.logM = a.logM; d.blue = a.blue; d.n3 = a.n3; d.tw = a.tw; d.chirp = a.chirp; d.bf = a.bf; d.root = a.root;
+    AxisDev d; d.N = a.N; d.M = a.M; d.logM = a.logM; d.blue = a.blue; d.n3 = a.n3; d.r16 = a.r16; d.tw = a.tw; d.chirp = a.chirp; d.bf = a.bf; d.root = a.root;
     return d;
 }
 
@@ -441,10 +447,10 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
     if (!p->ax1.big) {
         p->nt_rows = std::min(1024, std::max(64, (p->ax1.M + 15) / 16));
-        p->lds_rows = (size_t)p->ax1.M * sizeof(cplx);
+        p->lds_rows = (size_t)axis_lds_len(p->ax1) * sizeof(cplx);
     }
     if (!p->ax0.big) {
-        p->MS = p->ax0.M + 1;
+        p->MS = axis_lds_len(p->ax0) + 1;
         p->TC = 1;
         while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS) p->TC *= 2;
         p->nt_cols = std::min(1024, std::max(64, (p->TC * p->ax0.M + 15) / 16));
@@ -839,7 +845,7 @@ static bool fast_axis(const AxisHost& a) { return !a.big && !a.blue && a.M == 40
 // one pass of batched strided sub-transforms
 static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, const AxisHost& sub, const cplx* rootN, hipStream_t s)
 {
-    const int MS = sub.M + 1;
+    const int MS = axis_lds_len(sub) + 1;
     int TC = 1;
     while (TC < 16 && (size_t)(2 * TC) * MS <= LDS_COL_ELEMS) TC *= 2;
     const int nt = std::min(1024, std::max(64, (TC * sub.M + 15) / 16));
