@@ -75,6 +75,10 @@ __device__ __forceinline__ void twiddle16(cplx (&u)[16], const cplx* __restrict_
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
+// The on-chip FFT kernels run nb * M / 16 threads (one radix-16 butterfly each); with at most 9216 elements per workgroup
+// that is <= 576 threads, and a 640-thread bound leaves the compiler 168 registers per lane.
+#define SFFT_FFT_MAX_THREADS 640
+
 // forward 8-point DFT in registers, outputs in natural order
 __device__ __forceinline__ void dft8(cplx (&u)[8])
 {
@@ -98,17 +102,17 @@ __device__ __forceinline__ void dft8(cplx (&u)[8])
 // stage spread over the banks): each sequence needs M + M / 16 elements of LDS; input and result are in natural order.
 // PRE: input element n is multiplied by pre[n] on the way in (n < npre; the rest of the sequence is zero) -- Bluestein's chirp
 template <int R, bool PRE>
-__device__ __forceinline__ void lds_stage_small(cplx* s, int M, int logM, int nb, int stride, const cplx* __restrict__ pre, int npre)
+__device__ __forceinline__ void lds_stage_small(cplx* s, int M, int nb, int stride, const cplx* __restrict__ pre, int npre)
 {
-    constexpr int IT = 16 / R, LR = (R == 2) ? 1 : (R == 4) ? 2 : 3;
+    constexpr int IT = 16 / R;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int T = M / R, logT = logM - LR, total = nb * T;
+    const int T = M / R, total = nb * T;
     cplx y[IT][R];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int g = tid + it * nt;
         if (g < total) {
-            const int f = g >> logT, i = g & (T - 1);
+            const int f = g / T, i = g - f * T;
             const cplx* b = s + f * stride;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -125,7 +129,7 @@ __device__ __forceinline__ void lds_stage_small(cplx* s, int M, int logM, int nb
     for (int it = 0; it < IT; ++it) {
         const int g = tid + it * nt;
         if (g < total) {
-            const int f = g >> logT, i = g & (T - 1);
+            const int f = g / T, i = g - f * T;
             cplx* b = s + f * stride;
 #pragma unroll
             for (int r = 0; r < R; ++r) b[pad16(i * R + r)] = y[it][r];
@@ -134,26 +138,74 @@ __device__ __forceinline__ void lds_stage_small(cplx* s, int M, int logM, int nb
     __syncthreads();
 }
 
-// POST (applied to output k of the last stage): 1: conj(X[k] * post[k]) -- the Bluestein filter; the next forward transform then
-// acts as the inverse one;  2: post[k] * conj(X[k]) for k < npost -- the closing chirp
+// one radix-3 stage on the padded layout (natural on the way out when `last`); p = product of the earlier radices
+__device__ __forceinline__ void lds_stage3_padded(cplx* s, int M, int p, int nb, int stride, const cplx* __restrict__ tw, bool padded_in, bool last)
+{
+    constexpr int IT = 6;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int T = M / 3, total = nb * T, step = T / p;
+    const double S3 = 0.86602540378443864676;      // sin(pi/3)
+    cplx y[IT][3];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g / T, i = g - f * T;
+            const int k = i % p;
+            const cplx* b = s + f * stride;
+            cplx u0, u1, u2;
+            if (padded_in) { u0 = b[pad16(i)]; u1 = b[pad16(i + T)]; u2 = b[pad16(i + 2 * T)]; }
+            else { u0 = b[i]; u1 = b[i + T]; u2 = b[i + 2 * T]; }
+            if (p > 1) {
+                const int q = k * step;
+                u1 = cmul(u1, tw[q]);
+                u2 = cmul(u2, tw[2 * q]);
+            }
+            const cplx t1 = cadd(u1, u2), dd = csub(u1, u2);
+            const cplx t2 = make_double2(u0.x - 0.5 * t1.x, u0.y - 0.5 * t1.y);
+            y[it][0] = cadd(u0, t1);
+            y[it][1] = make_double2(t2.x + S3 * dd.y, t2.y - S3 * dd.x);
+            y[it][2] = make_double2(t2.x - S3 * dd.y, t2.y + S3 * dd.x);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g / T, i = g - f * T;
+            const int k = i % p;
+            cplx* b = s + f * stride;
+            const int o = (i - k) * 3 + k;
+            if (last) { b[o] = y[it][0]; b[o + p] = y[it][1]; b[o + 2 * p] = y[it][2]; }
+            else { b[pad16(o)] = y[it][0]; b[pad16(o + p)] = y[it][1]; b[pad16(o + 2 * p)] = y[it][2]; }
+        }
+    }
+    __syncthreads();
+}
+
+// M = 2^log2p * 3^n3 (log2p >= 4 or n3 >= 1): leading radix-2/4/8 stage, radix-16 stages, then the radix-3 stages.
+// POST (applied to output k of the last stage, power-of-two M only): 1: conj(X[k] * post[k]) -- the Bluestein filter; the next
+// forward transform then acts as the inverse one;  2: post[k] * conj(X[k]) for k < npost -- the closing chirp
 template <bool PRE, int POST>
-__device__ __forceinline__ void lds_fft_r16(cplx* s, int M, int logM, int nb, int stride, const cplx* __restrict__ tw,
+__device__ __forceinline__ void lds_fft_r16(cplx* s, int M, int log2p, int n3, int nb, int stride, const cplx* __restrict__ tw,
                                             const cplx* __restrict__ pre, int npre, const cplx* __restrict__ post, int npost)
 {
     const int tid = threadIdx.x;
-    const int rem = logM & 3;
-    if (rem == 1) lds_stage_small<2, PRE>(s, M, logM, nb, stride, pre, npre);
-    else if (rem == 2) lds_stage_small<4, PRE>(s, M, logM, nb, stride, pre, npre);
-    else if (rem == 3) lds_stage_small<8, PRE>(s, M, logM, nb, stride, pre, npre);
+    const int rem = log2p & 3;
+    if (rem == 1) lds_stage_small<2, PRE>(s, M, nb, stride, pre, npre);
+    else if (rem == 2) lds_stage_small<4, PRE>(s, M, nb, stride, pre, npre);
+    else if (rem == 3) lds_stage_small<8, PRE>(s, M, nb, stride, pre, npre);
     bool padded = rem != 0;
-    const int T = M >> 4, logT = logM - 4, total = nb * T;
+    const int T = M >> 4, total = nb * T;
     const bool mine = tid < total;
-    const int f = tid >> logT, i = tid & (T - 1);
+    const int f = mine ? tid / T : 0, i = tid - f * T;
     cplx* b = s + f * stride;
-    for (int logp = rem; logp < logM; logp += 4) {
+    const int tstep0 = M >> 4;                       // twiddle step of a radix-16 stage is M / (16 p)
+    for (int logp = rem; logp + 4 <= log2p; logp += 4) {
         const int p = 1 << logp;
         const int k = i & (p - 1);
-        const bool last = logp + 4 >= logM;
+        const bool last = (logp + 8 > log2p) && n3 == 0;
         cplx u[16];
         if (mine) {
             if (padded) {
@@ -166,7 +218,7 @@ __device__ __forceinline__ void lds_fft_r16(cplx* s, int M, int logM, int nb, in
                     if (PRE) u[r] = cmul(u[r], pre[min(i + r * T, npre - 1)]);
                 }
             }
-            if (logp > 0) twiddle16(u, tw, k << (logM - logp - 4));
+            if (logp > 0) twiddle16(u, tw, k * (tstep0 >> logp));
             dft16(u);
         }
         __syncthreads();
@@ -187,6 +239,11 @@ __device__ __forceinline__ void lds_fft_r16(cplx* s, int M, int logM, int nb, in
             }
         }
         __syncthreads();
+        padded = true;
+    }
+    int p3 = 1 << log2p;
+    for (int l = 0; l < n3; ++l, p3 *= 3) {
+        lds_stage3_padded(s, M, p3, nb, stride, tw, padded, l == n3 - 1);
         padded = true;
     }
 }
@@ -352,7 +409,7 @@ struct AxisDev {
 
 __device__ __forceinline__ void lds_fft_pow2(cplx* s, const AxisDev& ax, int nb, int stride)
 {
-    if (ax.r16) lds_fft_r16<false, 0>(s, ax.M, ax.logM, nb, stride, ax.tw, nullptr, 0, nullptr, 0);
+    if (ax.r16) lds_fft_r16<false, 0>(s, ax.M, ax.logM, 0, nb, stride, ax.tw, nullptr, 0, nullptr, 0);
     else lds_fft(s, ax.M, ax.logM, nb, stride, ax.tw);
 }
 
@@ -361,13 +418,17 @@ __device__ __forceinline__ void lds_fft_pow2(cplx* s, const AxisDev& ax, int nb,
 __device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int stride)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
-    if (ax.n3) { lds_fft_mixed(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw); return; }
+    if (ax.n3) {
+        if (ax.r16) lds_fft_r16<false, 0>(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw, nullptr, 0, nullptr, 0);
+        else lds_fft_mixed(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw);
+        return;
+    }
     if (!ax.blue) { lds_fft_pow2(s, ax, nb, stride); return; }
     if (ax.r16) {
         // Bluestein with the three pointwise products folded into the transforms' first read / last write:
         //   a = x * chirp;  A = FFT(a);  c = conj(A * Bf);  C = FFT(c);  X[k] = chirp[k] * conj(C[k])
-        lds_fft_r16<true, 1>(s, ax.M, ax.logM, nb, stride, ax.tw, ax.chirp, ax.N, ax.bf, ax.M);
-        lds_fft_r16<false, 2>(s, ax.M, ax.logM, nb, stride, ax.tw, nullptr, 0, ax.chirp, ax.N);
+        lds_fft_r16<true, 1>(s, ax.M, ax.logM, 0, nb, stride, ax.tw, ax.chirp, ax.N, ax.bf, ax.M);
+        lds_fft_r16<false, 2>(s, ax.M, ax.logM, 0, nb, stride, ax.tw, nullptr, 0, ax.chirp, ax.N);
         return;
     }
     const int M = ax.M;

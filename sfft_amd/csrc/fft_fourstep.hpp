@@ -18,7 +18,7 @@ struct PassDesc {
     double scale;
 };
 
-__global__ void __launch_bounds__(1024) strided_dft(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax,
+__global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) strided_dft(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax,
                                                      const cplx* __restrict__ rootN, int TC, int MS)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];

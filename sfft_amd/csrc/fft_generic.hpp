@@ -13,7 +13,7 @@ struct RowsArgs {                           // plane k = src[k] * wx[k][row] * w
     const double* wy[SFFT_MAX_PLANES];      // [N1] factor along axis 1
 };
 
-__global__ void __launch_bounds__(1024) rows_r2c(RowsArgs a, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
+__global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_r2c(RowsArgs a, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
                                                   AxisDev ax, double scale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(1024) rows_r2c(RowsArgs a, cplx* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // pass 2: columns, complex -> complex in place, TC adjacent columns per workgroup
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) cols_c2c(cplx* __restrict__ data, int N0, int ncols, int Nhp, int TC, int MS,
+__global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_c2c(cplx* __restrict__ data, int N0, int ncols, int Nhp, int TC, int MS,
                                                   AxisDev ax, int inverse, double scale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -102,7 +102,7 @@ struct ColOuts {
     const double* wx[COLG_MAX_OUT];               // [N0] row factor
 };
 
-__global__ void __launch_bounds__(1024) cols_fwd_weighted(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int N0, int ncols,
+__global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_fwd_weighted(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int N0, int ncols,
                                                            int Nhp, int TC, int MS, AxisDev ax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -173,7 +173,7 @@ __device__ __forceinline__ double bkg_eval(const BkgArgs& bk, const double (&c)[
     return B;
 }
 
-__global__ void __launch_bounds__(1024) rows_c2r_diff(const cplx* __restrict__ FD, const double* __restrict__ J,
+__global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_c2r_diff(const cplx* __restrict__ FD, const double* __restrict__ J,
                                                        const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
                                                        int N0, int N1, int Nh, int Nhp, AxisDev ax)
 {

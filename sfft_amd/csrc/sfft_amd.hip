@@ -256,7 +256,7 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
     else if (is_2a3b(N, &e2, &e3) && !getenv("SFFT_NO_MIXED_RADIX")) { ax.M = N; ax.blue = 0; ax.n3 = e3; }
     else { int M = 1; while (M < 2 * N - 1) M <<= 1; ax.M = M; ax.blue = 1; }
     ax.logM = ax.n3 ? e2 : ilog2(ax.M);
-    ax.r16 = (!ax.n3 && ax.M >= 16 && !getenv("SFFT_NO_R16")) ? 1 : 0;
+    ax.r16 = ((ax.n3 || ax.M >= 16) && !getenv("SFFT_NO_R16")) ? 1 : 0;
     int rc;
     std::vector<cplx> h(ax.M);
     for (int k = 0; k < ax.M; ++k) {
@@ -446,14 +446,14 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     }
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
     if (!p->ax1.big) {
-        p->nt_rows = std::min(1024, std::max(64, (p->ax1.M + 15) / 16));
+        p->nt_rows = std::min(SFFT_FFT_MAX_THREADS, std::max(64, (p->ax1.M + 15) / 16));
         p->lds_rows = (size_t)axis_lds_len(p->ax1) * sizeof(cplx);
     }
     if (!p->ax0.big) {
         p->MS = axis_lds_len(p->ax0) + 1;
         p->TC = 1;
-        while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS) p->TC *= 2;
-        p->nt_cols = std::min(1024, std::max(64, (p->TC * p->ax0.M + 15) / 16));
+        while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS && (2 * p->TC * p->ax0.M + 15) / 16 <= SFFT_FFT_MAX_THREADS) p->TC *= 2;
+        p->nt_cols = std::min(SFFT_FFT_MAX_THREADS, std::max(64, (p->TC * p->ax0.M + 15) / 16));
         p->lds_cols = (size_t)p->TC * p->MS * sizeof(cplx);
     }
     PLAN_HIP(hipFuncSetAttribute((const void*)strided_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -847,8 +847,8 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
 {
     const int MS = axis_lds_len(sub) + 1;
     int TC = 1;
-    while (TC < 16 && (size_t)(2 * TC) * MS <= LDS_COL_ELEMS) TC *= 2;
-    const int nt = std::min(1024, std::max(64, (TC * sub.M + 15) / 16));
+    while (TC < 16 && (size_t)(2 * TC) * MS <= LDS_COL_ELEMS && (2 * TC * sub.M + 15) / 16 <= SFFT_FFT_MAX_THREADS) TC *= 2;
+    const int nt = std::min(SFFT_FFT_MAX_THREADS, std::max(64, (TC * sub.M + 15) / 16));
     const int ngroups = (d.mode == 2) ? (d.nlines + TC - 1) / TC : (d.J + TC - 1) / TC;
     const int gy = (d.mode == 2) ? d.J : d.nlines;
     hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, MS);
