@@ -14,7 +14,7 @@ struct RowsArgs {                           // plane k = src[k] * wx[k][row] * w
 };
 
 __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_r2c(RowsArgs a, cplx* __restrict__ out, int N0, int N1, int Nh, int Nhp,
-                                                  AxisDev ax, double scale)
+                                                  SpecLayout lay, AxisDev ax, double scale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* s = reinterpret_cast<cplx*>(smem_raw);
@@ -38,15 +38,16 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_r2c(RowsArgs a, cpl
     }
     __syncthreads();
     lds_dft(s, ax, 1, ax.M);
-    cplx* o0 = out + ((size_t)plane * N0 + l0) * Nhp;
-    cplx* o1 = out + ((size_t)plane * N0 + l1) * Nhp;
+    cplx* o0 = out + (size_t)plane * N0 * Nhp + (size_t)l0 * lay.rstride;
+    cplx* o1 = o0 + lay.rstride;
     for (int m = tid; m < Nh; m += nt) {
         const cplx z = s[m];
         const cplx zc = cconj(s[m == 0 ? 0 : N1 - m]);
-        o0[m] = make_double2(0.5 * scale * (z.x + zc.x), 0.5 * scale * (z.y + zc.y));
+        const size_t mo = lay.col(m);
+        o0[mo] = make_double2(0.5 * scale * (z.x + zc.x), 0.5 * scale * (z.y + zc.y));
         if (has1) {
             const double dx = z.x - zc.x, dy = z.y - zc.y;   // (Z - Zc) / (2i) = (dy, -dx)/2
-            o1[m] = make_double2(0.5 * scale * dy, -0.5 * scale * dx);
+            o1[mo] = make_double2(0.5 * scale * dy, -0.5 * scale * dx);
         }
     }
 }
@@ -54,8 +55,8 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_r2c(RowsArgs a, cpl
 // ------------------------------------------------------------------------------------------------
 // pass 2: columns, complex -> complex in place, TC adjacent columns per workgroup
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_c2c(cplx* __restrict__ data, int N0, int ncols, int Nhp, int TC, int MS,
-                                                  AxisDev ax, int inverse, double scale)
+__global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_c2c(cplx* __restrict__ data, int N0, int ncols, int Nhp, int TC, int LT, int MS,
+                                                  SpecLayout lay, AxisDev ax, int inverse, double scale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* s = reinterpret_cast<cplx*>(smem_raw);
@@ -67,24 +68,30 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_c2c(cplx* __restric
     const int c0 = (((t / G) * 8 + xcd) * G + t % G) * TC;
     if (c0 >= ncols) return;
     cplx* __restrict__ base = data + (size_t)blockIdx.y * N0 * Nhp;
-    for (int e = tid; e < TC * ax.M; e += nt) {
-        const int l = e / TC, c = e - l * TC;
+    // TC is a power of two and divides the block size: a thread keeps its column, its rows advance by nt / TC (no divisions and
+    // one address increment per element: the loads of a thread issue back to back)
+    const int c = tid & (TC - 1), lstep = nt >> LT;
+    const bool cok = c0 + c < ncols;
+    cplx* __restrict__ gp = base + lay.col(cok ? c0 + c : c0);
+    cplx* __restrict__ sp = s + c * MS;
+    const int rs = lay.rstride;
+#pragma unroll 4
+    for (int l = tid >> LT; l < ax.M; l += lstep) {
         cplx z = make_double2(0.0, 0.0);
-        if (l < N0 && c0 + c < ncols) {
-            z = base[(size_t)l * Nhp + c0 + c];
+        if (l < N0 && cok) {
+            z = gp[(size_t)(l * rs)];
             if (inverse) z.y = -z.y;
         }
-        s[c * MS + l] = z;
+        sp[l] = z;
     }
     __syncthreads();
     lds_dft(s, ax, TC, MS);
-    for (int e = tid; e < TC * N0; e += nt) {
-        const int l = e / TC, c = e - l * TC;
-        if (c0 + c < ncols) {
-            cplx z = s[c * MS + l];
-            if (inverse) z.y = -z.y;
-            base[(size_t)l * Nhp + c0 + c] = make_double2(z.x * scale, z.y * scale);
-        }
+    if (!cok) return;
+#pragma unroll 4
+    for (int l = tid >> LT; l < N0; l += lstep) {
+        cplx z = sp[l];
+        if (inverse) z.y = -z.y;
+        gp[(size_t)(l * rs)] = make_double2(z.x * scale, z.y * scale);
     }
 }
 
@@ -103,7 +110,7 @@ struct ColOuts {
 };
 
 __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_fwd_weighted(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int N0, int ncols,
-                                                           int Nhp, int TC, int MS, AxisDev ax)
+                                                           int Nhp, int TC, int LT, int MS, SpecLayout lay, AxisDev ax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* s = reinterpret_cast<cplx*>(smem_raw);
@@ -116,22 +123,28 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_fwd_weighted(const 
     const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * N0 * Nhp;
     cplx* __restrict__ dst = out + (size_t)g.out_plane[o] * N0 * Nhp;
     const double* __restrict__ wx = g.wx[o];
-    for (int e = tid; e < TC * ax.M; e += nt) {
-        const int l = e / TC, c = e - l * TC;
+    const int c = tid & (TC - 1), lstep = nt >> LT;            // (see cols_c2c)
+    const bool cok = c0 + c < ncols;
+    const size_t co = lay.col(cok ? c0 + c : c0);
+    const cplx* __restrict__ gp = src + co;
+    cplx* __restrict__ sp = s + c * MS;
+    const int rs = lay.rstride;
+#pragma unroll 4
+    for (int l = tid >> LT; l < ax.M; l += lstep) {
         cplx z = make_double2(0.0, 0.0);
-        if (l < N0 && c0 + c < ncols) {
-            z = src[(size_t)l * Nhp + c0 + c];
+        if (l < N0 && cok) {
+            z = gp[(size_t)(l * rs)];
             const double f = wx[l];
             z.x *= f; z.y *= f;
         }
-        s[c * MS + l] = z;
+        sp[l] = z;
     }
     __syncthreads();
     lds_dft(s, ax, TC, MS);
-    for (int e = tid; e < TC * N0; e += nt) {
-        const int l = e / TC, c = e - l * TC;
-        if (c0 + c < ncols) dst[(size_t)l * Nhp + c0 + c] = s[c * MS + l];
-    }
+    if (!cok) return;
+    cplx* __restrict__ dp = dst + co;
+#pragma unroll 4
+    for (int l = tid >> LT; l < N0; l += lstep) dp[(size_t)(l * rs)] = sp[l];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -173,25 +186,27 @@ __device__ __forceinline__ double bkg_eval(const BkgArgs& bk, const double (&c)[
     return B;
 }
 
+template <int NQ>
 __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_c2r_diff(const cplx* __restrict__ FD, const double* __restrict__ J,
                                                        const double* __restrict__ bpq, BkgArgs bk, double* __restrict__ DIFF,
-                                                       int N0, int N1, int Nh, int Nhp, AxisDev ax)
+                                                       int N0, int N1, int Nh, int Nhp, SpecLayout lay, AxisDev ax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* s = reinterpret_cast<cplx*>(smem_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
     const bool has1 = l1 < N0;
-    const cplx* f0 = FD + (size_t)l0 * Nhp;
-    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * Nhp;
+    const cplx* f0 = FD + (size_t)l0 * lay.rstride;
+    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * lay.rstride;
     const bool even = (N1 & 1) == 0;
     for (int m = tid; m < ax.M; m += nt) {
         cplx z = make_double2(0.0, 0.0);
         if (m < N1) {
             const bool mir = m >= Nh;
             const int mm = mir ? N1 - m : m;
-            cplx x0 = f0[mm];
-            cplx x1 = has1 ? f1[mm] : make_double2(0.0, 0.0);
+            const size_t mo = lay.col(mm);
+            cplx x0 = f0[mo];
+            cplx x1 = has1 ? f1[mo] : make_double2(0.0, 0.0);
             if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
             if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
             // Z = X0 + i X1, conjugated on input so that the forward transform acts as the inverse
@@ -201,13 +216,13 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_c2r_diff(const cplx
     }
     __syncthreads();
     lds_dft(s, ax, 1, ax.M);
-    double c0[SFFT_MAX_BQ], c1[SFFT_MAX_BQ];
-    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, l0, N0, c0);
-    bkg_row_coeffs<SFFT_MAX_BQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
+    double c0[NQ], c1[NQ];
+    bkg_row_coeffs<NQ>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<NQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
     for (int n = tid; n < N1; n += nt) {
         const cplx z = s[n];                 // conj(result): row0 = z.x, row1 = -z.y
-        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c0, n, N1) - z.x;
-        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
+        DIFF[(size_t)l0 * N1 + n] = J[(size_t)l0 * N1 + n] - bkg_eval<NQ>(bk, c0, n, N1) - z.x;
+        if (has1) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<NQ>(bk, c1, n, N1) + z.y;
     }
 }
 

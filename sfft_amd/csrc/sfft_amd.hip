@@ -296,6 +296,21 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
 // LDS elements one sequence of this axis needs
 static int axis_lds_len(const AxisHost& a) { return a.r16 ? a.M + a.M / 16 : a.M; }
 
+// threads of an on-chip FFT workgroup over `elems` LDS elements: one radix-16 butterfly each, whole waves
+static int fft_threads(int elems) { return std::min(SFFT_FFT_MAX_THREADS, ((elems + 15) / 16 + 63) / 64 * 64); }
+
+// Column tile: TC sequences side by side in LDS, sequence stride MS.  The load / store phases of the column kernels walk
+// (element, sequence) with the sequence index fastest, so MS = 16 / TC (mod 16) elements puts the 16 lanes of a quarter wave
+// on 16 different 16-byte bank groups.
+static void pick_col_tile(const AxisHost& a, int* TC, int* MS)
+{
+    const int len = (axis_lds_len(a) + 15) / 16 * 16;
+    for (int tc = 16; tc >= 1; tc >>= 1) {
+        const int ms = len + (tc == 1 ? 0 : 16 / tc);
+        if (tc == 1 || ((size_t)tc * ms <= LDS_COL_ELEMS && (tc * a.M + 15) / 16 <= SFFT_FFT_MAX_THREADS)) { *TC = tc; *MS = ms; return; }
+    }
+}
+
 static AxisDev axis_dev(const AxisHost& a)
 {
     AxisDev d; d.N = a.N; d.M = a.M; d.logM = a.logM; d.blue = a.blue; d.n3 = a.n3; d.r16 = a.r16; d.tw = a.tw; d.chirp = a.chirp; d.bf = a.bf; d.root = a.root;
@@ -426,12 +441,13 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_TRY(build_axis(p, p->ax0, N0));
     PLAN_TRY(build_axis(p, p->ax1, N1));
     p->lay = rowmajor_layout(p->Nhp);
-    {   // panel layout: only when both passes are the 4096-point fast kernels (the generic and four-step kernels are row-major)
+    {   // panel layout: whenever both passes run on chip (the four-step kernels are row-major)
         int pw = 4;     // measured at 4096^2: 2 is best for the column pass alone (0.60 -> 0.40 ms) but slows every row-wise
                         // consumer (32 lines per wave load); 4 keeps them at speed and still gives 0.60 -> 0.47 ms; 8 gains nothing
         if (const char* ev = getenv("SFFT_PANEL")) pw = atoi(ev);
         const bool both_fast = !p->no_fast_fft && !p->ax0.big && !p->ax0.blue && p->ax0.M == 4096 && !p->ax1.big && !p->ax1.blue && p->ax1.M == 4096;
-        if (both_fast && pw > 1 && is_pow2(pw) && p->Nhp % pw == 0) {
+        const bool both_onchip = !p->ax0.big && !p->ax1.big && !getenv("SFFT_PANEL_FAST_ONLY");
+        if ((both_fast || both_onchip) && pw > 1 && is_pow2(pw) && p->Nhp % pw == 0) {
             p->lay.shift = ilog2(pw); p->lay.mask = pw - 1; p->lay.rstride = pw; p->lay.pstride = (long long)N0 * pw;
         }
         // polynomial plans (DK >= 0: made by sfft_plan_create, REF_ij term order) with a stamp of at most 25 x 25 take the
@@ -446,14 +462,12 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     }
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
     if (!p->ax1.big) {
-        p->nt_rows = std::min(SFFT_FFT_MAX_THREADS, std::max(64, (p->ax1.M + 15) / 16));
+        p->nt_rows = fft_threads(p->ax1.M);
         p->lds_rows = (size_t)axis_lds_len(p->ax1) * sizeof(cplx);
     }
     if (!p->ax0.big) {
-        p->MS = axis_lds_len(p->ax0) + 1;
-        p->TC = 1;
-        while (p->TC < 16 && (size_t)(2 * p->TC) * p->MS <= LDS_COL_ELEMS && (2 * p->TC * p->ax0.M + 15) / 16 <= SFFT_FFT_MAX_THREADS) p->TC *= 2;
-        p->nt_cols = std::min(SFFT_FFT_MAX_THREADS, std::max(64, (p->TC * p->ax0.M + 15) / 16));
+        pick_col_tile(p->ax0, &p->TC, &p->MS);
+        p->nt_cols = fft_threads(p->TC * p->ax0.M);
         p->lds_cols = (size_t)p->TC * p->MS * sizeof(cplx);
     }
     PLAN_HIP(hipFuncSetAttribute((const void*)strided_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -470,7 +484,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)lu_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if ((size_t)(p->NEQfs + 2) * 8 + (size_t)CB * (CB + 1) * 8 > 150 * 1024) {
         sfft_plan_destroy(p);
@@ -845,10 +860,9 @@ static bool fast_axis(const AxisHost& a) { return !a.big && !a.blue && a.M == 40
 // one pass of batched strided sub-transforms
 static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, const AxisHost& sub, const cplx* rootN, hipStream_t s)
 {
-    const int MS = axis_lds_len(sub) + 1;
-    int TC = 1;
-    while (TC < 16 && (size_t)(2 * TC) * MS <= LDS_COL_ELEMS && (2 * TC * sub.M + 15) / 16 <= SFFT_FFT_MAX_THREADS) TC *= 2;
-    const int nt = std::min(SFFT_FFT_MAX_THREADS, std::max(64, (TC * sub.M + 15) / 16));
+    int TC, MS;
+    pick_col_tile(sub, &TC, &MS);
+    const int nt = fft_threads(TC * sub.M);
     const int ngroups = (d.mode == 2) ? (d.nlines + TC - 1) / TC : (d.J + TC - 1) / TC;
     const int gy = (d.mode == 2) ? d.J : d.nlines;
     hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, MS);
@@ -888,8 +902,8 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
     } else {
         const int G8 = 8 * (p->TC >= 8 ? 1 : 8 / p->TC);
         dim3 g2(((p->Nh + p->TC - 1) / p->TC + G8 - 1) / G8 * G8, nplanes);
-        hipLaunchKernelGGL(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, data, p->N0, p->Nh, p->Nhp, p->TC, p->MS,
-                           axis_dev(p->ax0), inverse, 1.0);
+        hipLaunchKernelGGL(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, data, p->N0, p->Nh, p->Nhp, p->TC, ilog2(p->TC), p->MS,
+                           p->lay, axis_dev(p->ax0), inverse, 1.0);
     }
 }
 
@@ -922,7 +936,7 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
     }
     else
         hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
-                           axis_dev(p->ax1), p->scale);
+                           p->lay, axis_dev(p->ax1), p->scale);
     LAUNCH_CHECK();
     if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
     if (rows_only) return SFFT_OK;
@@ -987,7 +1001,7 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             }
             if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
             hipLaunchKernelGGL(cols_fwd_weighted, dim3(8 * G * g.nout * ntg), dim3(p->nt_cols), p->lds_cols, s, p->d_stage, dst, g, p->N0, p->Nh,
-                               p->Nhp, p->TC, p->MS, axis_dev(p->ax0));
+                               p->Nhp, p->TC, ilog2(p->TC), p->MS, p->lay, axis_dev(p->ax0));
         }
         LAUNCH_CHECK();
         if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
@@ -1346,9 +1360,12 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
                 hipLaunchKernelGGL(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
         }
+        else if (p->nby <= 4)
+            hipLaunchKernelGGL(rows_c2r_diff<4>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
+                               d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, p->lay, axis_dev(p->ax1));
         else
-            hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
-                               d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, axis_dev(p->ax1));
+            hipLaunchKernelGGL(rows_c2r_diff<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
+                               d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, p->lay, axis_dev(p->ax1));
         if (p->mode == 3)
             hipLaunchKernelGGL(scaling_term, dim3((p->N1 + 255) / 256, p->N0), dim3(256), 0, s, d_I, d_solution, p->sa, d_diff,
                                p->N0, p->N1, p->scale);
@@ -1473,8 +1490,8 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
         hipLaunchKernelGGL(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, p->d_zero,
                            p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->lay, p->ax1.tw);
     else
-        hipLaunchKernelGGL(rows_c2r_diff, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, p->d_zero,
-                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->N1, p->Nh, p->Nhp, axis_dev(p->ax1));
+        hipLaunchKernelGGL(rows_c2r_diff<4>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, p->d_zero,
+                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->N1, p->Nh, p->Nhp, p->lay, axis_dev(p->ax1));
     const size_t n = (size_t)p->N0 * p->N1;
     hipLaunchKernelGGL(scale_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_real, -scale, n);
     LAUNCH_CHECK();
