@@ -19,29 +19,37 @@ struct PassDesc {
 };
 
 __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) strided_dft(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax,
-                                                     const cplx* __restrict__ rootN, int TC, int MS)
+                                                     const cplx* __restrict__ rootN, int TC, int LT, int MS)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* s = reinterpret_cast<cplx*>(smem_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int M = ax.M;
-    for (int x = tid; x < TC * M; x += nt) {
-        int c, e;
-        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
-        const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
-        const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
-        cplx z = make_double2(0.0, 0.0);
-        if (e < d.len && j < d.J && line < d.nlines) {
-            z = in[(long long)line * d.lst_in + (long long)j * d.js_in + (long long)e * d.es_in];
-            if (d.conj_in) z.y = -z.y;
+    {   // at most 16 elements per thread (the block has >= TC * M / 16 threads): every load is issued before the first use
+        cplx zz[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int x = tid + it * nt;
+            int c, e;
+            if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x >> LT; c = x & (TC - 1); }
+            const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
+            const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
+            const bool ok = x < TC * M && e < d.len && j < d.J && line < d.nlines;
+            zz[it] = ok ? in[(long long)line * d.lst_in + (long long)j * d.js_in + (long long)e * d.es_in] : make_double2(0.0, 0.0);
         }
-        s[c * MS + e] = z;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int x = tid + it * nt;
+            int c, e;
+            if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x >> LT; c = x & (TC - 1); }
+            if (x < TC * M) s[c * MS + e] = d.conj_in ? cconj(zz[it]) : zz[it];
+        }
     }
     __syncthreads();
     lds_dft(s, ax, TC, MS);
     for (int x = tid; x < TC * M; x += nt) {
         int c, e;
-        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x / TC; c = x - e * TC; }
+        if (d.mode == 0) { c = x / M; e = x - c * M; } else { e = x >> LT; c = x & (TC - 1); }
         const int j = (d.mode == 2) ? (int)blockIdx.y : (int)blockIdx.x * TC + c;
         const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
         if (e < d.len && j < d.J && line < d.nlines) {

@@ -27,14 +27,24 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_r2c(RowsArgs a, cpl
     const bool has1 = l1 < N0;
     const double cx0 = wx ? wx[l0] : 1.0;
     const double cx1 = (wx && has1) ? wx[l1] : 1.0;
-    for (int n = tid; n < ax.M; n += nt) {
-        cplx z = make_double2(0.0, 0.0);
-        if (n < N1) {
-            const double cyp = wy ? wy[n] : 1.0;
-            z.x = src[(size_t)l0 * N1 + n] * (cx0 * cyp);
-            if (has1) z.y = src[(size_t)l1 * N1 + n] * (cx1 * cyp);
+    {   // at most 16 elements per thread (the block has >= M / 16 threads): every load is issued before the first use
+        const double* __restrict__ r0p = src + (size_t)l0 * N1;
+        const double* __restrict__ r1p = src + (size_t)(has1 ? l1 : l0) * N1;
+        const double h1 = has1 ? cx1 : 0.0;
+        double x0[16], x1[16], wv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int n = tid + it * nt;
+            const bool ok = n < N1;
+            x0[it] = ok ? r0p[n] : 0.0;
+            x1[it] = ok ? r1p[n] : 0.0;
+            wv[it] = (ok && wy) ? wy[n] : 1.0;
         }
-        s[n] = z;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int n = tid + it * nt;
+            if (n < ax.M) s[n] = make_double2(x0[it] * (cx0 * wv[it]), x1[it] * (h1 * wv[it]));
+        }
     }
     __syncthreads();
     lds_dft(s, ax, 1, ax.M);
@@ -75,14 +85,19 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_c2c(cplx* __restric
     cplx* __restrict__ gp = base + lay.col(cok ? c0 + c : c0);
     cplx* __restrict__ sp = s + c * MS;
     const int rs = lay.rstride;
-#pragma unroll 4
-    for (int l = tid >> LT; l < ax.M; l += lstep) {
-        cplx z = make_double2(0.0, 0.0);
-        if (l < N0 && cok) {
-            z = gp[(size_t)(l * rs)];
-            if (inverse) z.y = -z.y;
+    // (a thread owns at most 16 elements -- the block has >= TC * M / 16 threads: all its loads are issued before the first use)
+    {
+        cplx zz[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int l = (tid >> LT) + it * lstep;
+            zz[it] = (l < N0 && cok) ? gp[(size_t)(l * rs)] : make_double2(0.0, 0.0);
         }
-        sp[l] = z;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int l = (tid >> LT) + it * lstep;
+            if (l < ax.M) sp[l] = inverse ? cconj(zz[it]) : zz[it];
+        }
     }
     __syncthreads();
     lds_dft(s, ax, TC, MS);
@@ -129,15 +144,21 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_fwd_weighted(const 
     const cplx* __restrict__ gp = src + co;
     cplx* __restrict__ sp = s + c * MS;
     const int rs = lay.rstride;
-#pragma unroll 4
-    for (int l = tid >> LT; l < ax.M; l += lstep) {
-        cplx z = make_double2(0.0, 0.0);
-        if (l < N0 && cok) {
-            z = gp[(size_t)(l * rs)];
-            const double f = wx[l];
-            z.x *= f; z.y *= f;
+    {
+        cplx zz[16];
+        double ff[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int l = (tid >> LT) + it * lstep;
+            const bool ok = l < N0 && cok;
+            zz[it] = ok ? gp[(size_t)(l * rs)] : make_double2(0.0, 0.0);
+            ff[it] = ok ? wx[l] : 0.0;
         }
-        sp[l] = z;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int l = (tid >> LT) + it * lstep;
+            if (l < ax.M) sp[l] = make_double2(zz[it].x * ff[it], zz[it].y * ff[it]);
+        }
     }
     __syncthreads();
     lds_dft(s, ax, TC, MS);
@@ -199,20 +220,31 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) rows_c2r_diff(const cplx
     const cplx* f0 = FD + (size_t)l0 * lay.rstride;
     const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * lay.rstride;
     const bool even = (N1 & 1) == 0;
-    for (int m = tid; m < ax.M; m += nt) {
-        cplx z = make_double2(0.0, 0.0);
-        if (m < N1) {
-            const bool mir = m >= Nh;
-            const int mm = mir ? N1 - m : m;
-            const size_t mo = lay.col(mm);
-            cplx x0 = f0[mo];
-            cplx x1 = has1 ? f1[mo] : make_double2(0.0, 0.0);
-            if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
-            if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
-            // Z = X0 + i X1, conjugated on input so that the forward transform acts as the inverse
-            z = make_double2(x0.x - x1.y, -(x0.y + x1.x));
+    {   // at most 16 elements per thread (the block has >= M / 16 threads): every load is issued before the first use
+        cplx a0[16], a1[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = tid + it * nt;
+            const int mm = (m >= Nh) ? N1 - m : m;
+            const size_t mo = lay.col(m < N1 ? mm : 0);
+            a0[it] = f0[mo];
+            a1[it] = f1[mo];
         }
-        s[m] = z;
+        const double h1 = has1 ? 1.0 : 0.0;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = tid + it * nt;
+            if (m < ax.M) {
+                const bool mir = m >= Nh;
+                const int mm = mir ? N1 - m : m;
+                cplx x0 = a0[it];
+                cplx x1 = make_double2(a1[it].x * h1, a1[it].y * h1);
+                if (mm == 0 || (even && mm == N1 / 2)) { x0.y = 0.0; x1.y = 0.0; }
+                if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
+                // Z = X0 + i X1, conjugated on input so that the forward transform acts as the inverse
+                s[m] = (m < N1) ? make_double2(x0.x - x1.y, -(x0.y + x1.x)) : make_double2(0.0, 0.0);
+            }
+        }
     }
     __syncthreads();
     lds_dft(s, ax, 1, ax.M);

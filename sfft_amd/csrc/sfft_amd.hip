@@ -865,7 +865,7 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
     const int nt = fft_threads(TC * sub.M);
     const int ngroups = (d.mode == 2) ? (d.nlines + TC - 1) / TC : (d.J + TC - 1) / TC;
     const int gy = (d.mode == 2) ? d.J : d.nlines;
-    hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, MS);
+    hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, ilog2(TC), MS);
 }
 
 // four-step transform of `nlines` lines of length ax.N; element stride st, line stride lst (complex elements).
