@@ -145,6 +145,7 @@ struct sfft_plan {
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
+    int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 1;                    // Omega passes on the matrix cores (greek_g1_mfma); env SFFT_G1_MFMA=0: vector kernel (A/B testing)
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
@@ -366,6 +367,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     p->dev = device;
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
+    if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -1143,14 +1145,34 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
     const int n = p->NEQfs;
     hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
     int step = 0;
-    int k_start = 0;
-    if (p->fused_step && n >= 2 * CB) {
-        // step 0: panel only; steps with a full block: one fused launch each (update with the previous panel + this panel)
-        {
-            const int rows_below = n + 1 - CB;
-            hipLaunchKernelGGL(chol_panel, dim3(1 + (rows_below + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, 0, p->d_dbuf, p->d_status, p->d_rd);
+    int kb = 0;                 // first column not yet factored
+    if (p->fused_step && n >= p->chol_outer_min) {
+        // outer blocks of 256 columns (see chol_syrk): the inner steps stay inside the block, one rank-256 update per block
+        const int OB = 4 * CB;
+        while (n - kb >= OB + CB) {
+            hipLaunchKernelGGL(chol_panel, dim3(1 + (n + 1 - kb - CB + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
+            for (int st = 1; st < 4; ++st) {
+                const int k = kb + st * CB;
+                const int ntile = (n + 1 - k + CB - 1) / CB;
+                if (++p->step_epoch == 0u) p->step_epoch = 1u;
+                hipLaunchKernelGGL(chol_step, dim3(4 - st, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
+                                   p->d_bflags + p->n_bflags - 1, p->step_epoch, p->d_status, p->d_rd);
+            }
+            const int r0 = kb + OB;
+            const int nt = (n + 1 - r0 + SYRK_T - 1) / SYRK_T;
+            hipLaunchKernelGGL(chol_syrk, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0);
+            kb = r0;
+            hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A + (size_t)kb * p->ld + kb, p->ld, std::min(CB, n - kb), p->d_dbuf);
         }
-        int k = CB;
+    }
+    int k_start = kb;
+    if (p->fused_step && n - kb >= 2 * CB) {
+        // first panel only; steps with a full block: one fused launch each (update with the previous panel + this panel)
+        {
+            const int rows_below = n + 1 - kb - CB;
+            hipLaunchKernelGGL(chol_panel, dim3(1 + (rows_below + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
+        }
+        int k = kb + CB;
         for (; n - k >= CB; k += CB) {
             const int ntile = (n + 1 - k + CB - 1) / CB;
             if (++p->step_epoch == 0u) p->step_epoch = 1u;

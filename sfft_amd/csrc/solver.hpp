@@ -428,6 +428,75 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
     }
 }
 
+// ---- outer blocking for large systems ----------------------------------------------------------------------------
+// With rank-64 updates every step reads and writes the whole trailing matrix: n^3 / 24 bytes in total (31 GB at n = 7231,
+// 12 ms).  For large n the factorisation therefore works on outer blocks of 256 columns: the four inner steps only update
+// the columns of their own outer block, and the rest of the trailing matrix receives all four panels at once from this
+// kernel: C -= L_K L_K^T with K = 256, 128 x 128 tiles on the matrix cores (one 64 x 64 quadrant per wave, sixteen 16 x 16
+// accumulators per lane), the panels staged through LDS sixteen columns at a time with the next chunk's loads in flight.
+#define SYRK_T 128
+#define SYRK_KC 16
+#define SYRK_S (SYRK_KC + 4)
+__global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int ld, int n, int K0, int KB, int r0)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    __shared__ double Li[SYRK_T][SYRK_S];
+    __shared__ double Lj[SYRK_T][SYRK_S];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int i0 = r0 + ti * SYRK_T, j0 = r0 + tj * SYRK_T;
+    // staging: thread loads rows (tid >> 3) + 32 u, u < 4, columns 2 (tid & 7) .. + 1 of the chunk, for both panels
+    const int sr = tid >> 3, sc = 2 * (tid & 7);
+    double2 pi[4], pj[4];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ri = i0 + sr + 32 * u, rj = j0 + sr + 32 * u;
+            pi[u] = (ri <= n) ? *reinterpret_cast<const double2*>(A + (size_t)ri * ld + K0 + kc + sc) : make_double2(0.0, 0.0);
+            pj[u] = (rj < n) ? *reinterpret_cast<const double2*>(A + (size_t)rj * ld + K0 + kc + sc) : make_double2(0.0, 0.0);
+        }
+    };
+    d4s c[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) c[it][jt] = (d4s){0.0, 0.0, 0.0, 0.0};
+    fetch(0);
+    for (int kc = 0; kc < KB; kc += SYRK_KC) {
+        __syncthreads();                    // the previous chunk has been consumed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Li[sr + 32 * u][sc] = pi[u].x; Li[sr + 32 * u][sc + 1] = pi[u].y;
+            Lj[sr + 32 * u][sc] = pj[u].x; Lj[sr + 32 * u][sc + 1] = pj[u].y;
+        }
+        __syncthreads();
+        if (kc + SYRK_KC < KB) fetch(kc + SYRK_KC);
+#pragma unroll
+        for (int ks = 0; ks < SYRK_KC / 4; ++ks) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = Li[64 * wr + 16 * t + ln][4 * ks + lk];
+                b[t] = Lj[64 * wc + 16 * t + ln][4 * ks + lk];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) c[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], c[it][jt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 64 * wr + 16 * it + lk + 4 * q, j = j0 + 64 * wc + 16 * jt + ln;
+                if (i <= n && j < n && j <= i) A[(size_t)i * ld + j] -= c[it][jt][q];
+            }
+}
+
 // ---- back substitution in two launches -----------------------------------------------------------------------
 // L^T x = y, y = border row of the factor.  A launch per 64-column block (the version above) costs ~20 us per block, almost
 // all of it launch and hand-off latency: 28 blocks -> 0.55 ms at n = 1735.  Instead:
