@@ -137,7 +137,7 @@ typedef double d4v __attribute__((ext_vector_type(4)));
 // vector kernel is as fast, so the host does not use it.  B of a pass may be a column factor (Gamma passes): H = A conj(Xp[l]).
 // Measured at 4096^2, KerHW 8 (21 Omega passes, 23.6 GFLOP): 0.53 ms = 45 TFLOP/s, against 0.65 ms for the vector kernel.
 template <int NT, bool PACK>
-__global__ void __launch_bounds__(64, (NT == 4 ? 2 : 4)) greek_g1_mfma(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+__global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
                                                                        cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
                                                                        int rows_per_chunk, const cplx* __restrict__ W0tab, int HM,
                                                                        const cplx* __restrict__ Xp, int ncb, int S, int npass)
@@ -177,44 +177,68 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 4)) greek_g1_mfma(const cpl
         for (int q = 0; q < NS; ++q) Sx[t][q] = (d4v){0.0, 0.0, 0.0, 0.0};
         g0x[t] = g0y[t] = 0.0;
     }
-    // software pipeline: the loads of step s + 1 are in flight while the MFMAs of step s run
-    cplx twn, avn[NT], bvn[NT];
-    {
-        const int rc = min(lb + kq, le - 1);
-        twn = W0tab[(size_t)rc * HM + tcol];
+    // Software pipeline, written out as two register sets that alternate (the compiler sinks a plain "load next, use
+    // current" formulation back to load-then-wait within one step, which left every step exposed to the L2 latency): the
+    // loads of step s + 1 are issued, a scheduling barrier pins them there, then the MFMAs of step s run.  Addresses are
+    // 32-bit byte offsets from wave-uniform plane bases (scalar base + vector offset loads), advanced by one add and one
+    // clamp per step; rows past the chunk are masked by vf, so the clamp only has to keep the reads inside the plane.
+    struct LoadSet { cplx tw, a[NT], b[NT]; };
+    const char* __restrict__ Ab = reinterpret_cast<const char*>(A);
+    const char* __restrict__ Bb = reinterpret_cast<const char*>(B);
+    const char* __restrict__ Xb = reinterpret_cast<const char*>(xp);
+    const char* __restrict__ Wb = reinterpret_cast<const char*>(W0tab) + (size_t)tcol * sizeof(cplx);
+    unsigned cob[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { avn[t] = A[co[t] + (size_t)rc * rs]; bvn[t] = colfac ? xp[rc] : B[co[t] + (size_t)rc * rs]; }
-    }
-    for (int l = lb; l < le; l += 4) {
-        const double vf = (l + kq < le) ? 1.0 : 0.0;
-        const cplx twv = twn;
-        cplx av[NT], bv[NT];
+    for (int t = 0; t < NT; ++t) cob[t] = (unsigned)(co[t] * sizeof(cplx));
+    const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
+    const unsigned rlast = (unsigned)(N0 - 1);
+    const unsigned r0 = min((unsigned)(lb + kq), rlast);
+    unsigned rowb = r0 * rsb, twb = r0 * hmb, xb = r0 * (unsigned)sizeof(cplx);
+    const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb, xb_max = rlast * (unsigned)sizeof(cplx);
+    auto run = [&](auto CF) {
+        constexpr bool cf = decltype(CF)::value;
+        auto issue = [&](LoadSet& L) {
+            L.tw = *reinterpret_cast<const cplx*>(Wb + twb);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { av[t] = avn[t]; bv[t] = bvn[t]; }
-        {
-            const int rc = min(l + 4 + kq, le - 1);                 // (the last step re-reads a valid row; unused)
-            twn = W0tab[(size_t)rc * HM + tcol];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { avn[t] = A[co[t] + (size_t)rc * rs]; bvn[t] = colfac ? xp[rc] : B[co[t] + (size_t)rc * rs]; }
-        }
-        const double wx = twv.x * vf, wy = twv.y * vf;
-        const double wp = (n < 8) ? wx : wy;                        // PACK: rows 0..7 of A are wx, rows 8..15 are wy
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const cplx H = cmulc(av[t], bv[t]);
-            g0x[t] = fma(H.x, vf, g0x[t]);
-            g0y[t] = fma(H.y, vf, g0y[t]);
-            if (PACK) {
-                Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.x, Sx[t][0], 0, 0, 0);      // S1 | S3
-                Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.y, Sx[t][1], 0, 0, 0);      // S4 | S2
-            } else {
-                Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.x, Sx[t][0], 0, 0, 0);      // S1
-                Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);      // S2
-                Sx[t][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.x, Sx[t][2], 0, 0, 0);      // S3
-                Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);      // S4
+            for (int t = 0; t < NT; ++t) {
+                L.a[t] = *reinterpret_cast<const cplx*>(Ab + (cob[t] + rowb));
+                L.b[t] = cf ? *reinterpret_cast<const cplx*>(Xb + xb) : *reinterpret_cast<const cplx*>(Bb + (cob[t] + rowb));
             }
+            rowb = min(rowb + 4u * rsb, rowb_max);
+            twb = min(twb + 4u * hmb, twb_max);
+            if (cf) xb = min(xb + 4u * (unsigned)sizeof(cplx), xb_max);
+        };
+        auto compute = [&](const LoadSet& L, double vf) {
+            const double wx = L.tw.x * vf, wy = L.tw.y * vf;
+            const double wp = (n < 8) ? wx : wy;                        // PACK: rows 0..7 of A are wx, rows 8..15 are wy
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const cplx H = cmulc(L.a[t], L.b[t]);
+                g0x[t] = fma(H.x, vf, g0x[t]);
+                g0y[t] = fma(H.y, vf, g0y[t]);
+                if (PACK) {
+                    Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.x, Sx[t][0], 0, 0, 0);      // S1 | S3
+                    Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.y, Sx[t][1], 0, 0, 0);      // S4 | S2
+                } else {
+                    Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.x, Sx[t][0], 0, 0, 0);      // S1
+                    Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);      // S2
+                    Sx[t][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.x, Sx[t][2], 0, 0, 0);      // S3
+                    Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);      // S4
+                }
+            }
+        };
+        LoadSet L0, L1;
+        issue(L0);
+        for (int l = lb; l < le; l += 8) {
+            issue(L1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(L0, (l + kq < le) ? 1.0 : 0.0);
+            issue(L0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(L1, (l + 4 + kq < le) ? 1.0 : 0.0);      // (a step past the chunk runs on zero weights)
         }
-    }
+    };
+    if (colfac) run(std::true_type{}); else run(std::false_type{});
     cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
