@@ -486,15 +486,26 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
                 for (int jt = 0; jt < 4; ++jt) c[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], c[it][jt], 0, 0, 0);
         }
     }
+    // read-modify-write of the tile, 16 elements at a time: all 16 loads first (written as `A[..] -= c` the compiler orders
+    // every load behind the previous store -- 64 dependent round trips per thread)
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < 4; ++it) {
+        double oldv[4][4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = i0 + 64 * wr + 16 * it + lk + 4 * q, j = j0 + 64 * wc + 16 * jt + ln;
-                if (i <= n && j < n && j <= i) A[(size_t)i * ld + j] -= c[it][jt][q];
+                oldv[jt][q] = (i <= n && j < n && j <= i) ? A[(size_t)i * ld + j] : 0.0;
             }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 64 * wr + 16 * it + lk + 4 * q, j = j0 + 64 * wc + 16 * jt + ln;
+                if (i <= n && j < n && j <= i) A[(size_t)i * ld + j] = oldv[jt][q] - c[it][jt][q];
+            }
+    }
 }
 
 // ---- back substitution in two launches -----------------------------------------------------------------------
