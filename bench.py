@@ -17,7 +17,7 @@ end (sfft_amd/sharding.py).
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
   roofline     -- the dominant KERNEL by time per pair.  Since the forward transforms were halved that is the Omega pass of the
                   Greek stage (greek_g1_mfma<2,false>: v_mfma_f64_16x16x4_f64), priced against the fp64 MFMA peak (bound "mfma"); `roofline_hbm` is the dominant HBM-bound kernel, the forward column pass
-                  (cols_fwd_weighted_4096): algorithmic bytes of the timed launch / its duration (HIP events on the launch
+                  (cols_fwd_weighted_4096_q): algorithmic bytes of the timed launch / its duration (HIP events on the launch
                   stream) against the 8 TB/s HBM3E peak; `roofline_greek` is the same for the second kernel, the Omega
                   pass of the Greek stage, which is bound by fp64 FMA issue, not by HBM
   cpu_baseline -- the numpy/scipy oracle (port of the reference's Numpy backend) timed on this host on a
@@ -206,7 +206,7 @@ def main():
         except Exception:
             pass
 
-        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096" if N == 4096 else "cols_c2c / strided_dft",
+        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if N == 4096 else "cols_fwd_weighted / strided_dft",
                      "fwd_rows": "rows_r2c_4096" if N == 4096 else "rows_r2c", "greek_g1": "greek_g1_mfma<2, false> (Omega passes)",
                      "greek_g1b": "greek_g1<8, 2> (Theta, Gamma passes)", "construct": "construct_fd"}
 

@@ -42,8 +42,8 @@ doc = {
               "streaming reads on gfx950, MI355X_MICROARCH.md), WRITE_SIZE unchanged (calibration: rows_c2r_diff_4096 writes "
               "131072.0 KB = exactly the 134217728-byte DIFF image).",
     "source_files": [sys.argv[1].split("/")[-1], sys.argv[2].split("/")[-1]],
-    # cols_fwd_weighted_4096: one launch per pair (solve pass: 4 stage planes in, 7 planes out); the apply pass has no column transform
-    "fwd_cols": entry(["cols_fwd_weighted_4096"]),
+    # cols_fwd_weighted_4096_q: one launch per pair (solve pass: 4 stage planes in, 7 planes out); the apply pass has no column transform
+    "fwd_cols": entry(["cols_fwd_weighted_4096_q"]),
     # rows_r2c_4096: solve launch (2 images in, 4 stage planes out) vs apply launch (1 in, 3 out)
     "fwd_rows": entry(["rows_r2c_4096"], (2 * img + 4 * spec) / (0.5 * (2 * img + 4 * spec + img + 3 * spec)),
                       "mean over the solve and apply launches scaled to the solve launch"),

@@ -174,6 +174,74 @@ __global__ void __launch_bounds__(512) cols_fwd_weighted_4096(const cplx* __rest
     for (int sx = 0; sx < 16; ++sx) dst[(size_t)(j + 256 * sx) * rs] = u[R16_OUT(sx)];
 }
 
+// The same pass with FOUR columns (one 64-byte row piece of a 4-column panel) per workgroup.  With two columns per workgroup
+// every load / store instruction touches 32 half-used 64-byte sectors and the L1 is the limit (PMC: TCP_PENDING_STALL 55 % of
+// the kernel, 29 M 32-byte write requests per launch).  Here a lane quad moves one whole 64-byte piece per instruction -- rows
+// 2p and 2p + 1 in two instructions -- and a 2 x 2 exchange between lane pairs (DPP quad_perm) turns that into the
+// (row, column pair) ownership of the transform: lane pair (4p, 4p + 1) owns row 2p, pair (4p + 2, 4p + 3) row 2p + 1, first of
+// columns (0, 1), then of columns (2, 3).  The two column pairs are transformed one after the other through the same LDS.
+__device__ __forceinline__ double dpp_swap2(double x)          // the value held by lane ^ 2
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cplx dpp_swap2(cplx v) { return make_double2(dpp_swap2(v.x), dpp_swap2(v.y)); }
+__device__ __forceinline__ cplx csel(bool p, cplx a, cplx b) { return make_double2(p ? a.x : b.x, p ? a.y : b.y); }
+
+__global__ void __launch_bounds__(512) cols_fwd_weighted_4096_q(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int Nhp,
+                                                                SpecLayout lay, const cplx* __restrict__ tw, int nquads)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
+    const int N0 = 4096;
+    const int tid = threadIdx.x, c = tid & 1, j = tid >> 1, q4 = tid & 3;
+    const bool even = q4 < 2;                                   // this lane's row j is the even one of its quad
+    const int total = nquads * g.nout;
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || logical >= total) return;
+    const int cq = logical / g.nout, o = logical - cq * g.nout;
+    // (the panel's padding columns beyond Nh exist in memory: they are transformed and stored like the others, nobody reads them)
+    const size_t plane_sz = (size_t)N0 * Nhp, cofs = (size_t)cq * (size_t)lay.pstride + q4;
+    const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * plane_sz + cofs;
+    const double* __restrict__ w = g.wx[o];
+    const int rowA = 2 * (j >> 1);
+    cplx u1[16], u2[16];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {        // two batches of 8 rows (16 + 8 loads in flight): bounds the registers of this phase
+        cplx la[8], lb[8];
+        double f[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            la[r] = src[(size_t)(rowA + 256 * (8 * hb + r)) * 4];
+            lb[r] = src[(size_t)(rowA + 1 + 256 * (8 * hb + r)) * 4];
+            f[r] = w[j + 256 * (8 * hb + r)];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const cplx got = dpp_swap2(csel(even, lb[r], la[r]));
+            const cplx h1 = csel(even, la[r], got), h2 = csel(even, got, lb[r]);
+            u1[8 * hb + r] = make_double2(h1.x * f[r], h1.y * f[r]);
+            u2[8 * hb + r] = make_double2(h2.x * f[r], h2.y * f[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    cplx* mylds = lds + c * (F4K_LDS + 4);
+    fft4096_core(u1, j, mylds, tw);
+    __syncthreads();                                            // the last exchange of the first pair has been read
+    fft4096_core(u2, j, mylds, tw);
+    cplx* __restrict__ dst = out + (size_t)g.out_plane[o] * plane_sz + cofs;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) {
+        const cplx o1 = u1[R16_OUT(sx)], o2 = u2[R16_OUT(sx)];
+        const cplx got = dpp_swap2(csel(even, o2, o1));
+        dst[(size_t)(rowA + 256 * sx) * 4] = csel(even, o1, got);
+        dst[(size_t)(rowA + 1 + 256 * sx) * 4] = csel(even, got, o2);
+    }
+}
+
 // rows, half complex -> real (N1 = 4096), two rows per transform, DIFF epilogue (see rows_c2r_diff)
 template <int NQ>
 __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict__ FD, const double* __restrict__ J,

@@ -146,6 +146,7 @@ struct sfft_plan {
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
+    int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 1;                    // Omega passes on the matrix cores (greek_g1_mfma); env SFFT_G1_MFMA=0: vector kernel (A/B testing)
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
@@ -369,6 +370,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
+    if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -482,6 +484,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096_q, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1037,6 +1040,13 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             ++k;
         }
         if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
+        if (p->colq && p->lay.rstride == 4 && p->lay.mask == 3) {      // four columns per workgroup: whole 64-byte pieces per lane quad
+            const int nquads = (p->Nh + 3) / 4;
+            const int total = nquads * g.nout;
+            hipLaunchKernelGGL(cols_fwd_weighted_4096_q, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
+                               p->Nhp, p->lay, p->ax0.tw, nquads);
+            continue;
+        }
         const int total = npairs * g.nout;
         hipLaunchKernelGGL(cols_fwd_weighted_4096, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
                            p->Nh, p->Nhp, p->lay, p->ax0.tw, npairs);
