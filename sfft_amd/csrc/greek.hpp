@@ -312,9 +312,15 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
         const int ne = min(16, h - e0);   // lags e0+1 .. e0+ne, plus lag 0 when e0 == 0
         for (int m = tid; m < Nh; m += 256) {
             double gx = 0.0, gy = 0.0;
-            for (int c = 0; c < S; ++c) {
-                const cplx v = g[(size_t)c * PH * Nhp + m];
-                gx += v.x; gy += v.y;
+            for (int c0 = 0; c0 < S; c0 += 8) {         // eight chunk partials per batch: the loads are independent and issue together
+                cplx v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = g[(size_t)min(c0 + c, S - 1) * PH * Nhp + m];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const double f = (c0 + c < S) ? 1.0 : 0.0;
+                    gx = fma(v[c].x, f, gx); gy = fma(v[c].y, f, gy);
+                }
             }
             if (yq) {
                 const cplx y = yq[m];
@@ -324,14 +330,27 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
             const double wgt = (m == 0 || (even && m == N1 / 2)) ? 1.0 : 2.0;
             gx *= wgt; gy *= wgt;
             if (e0 == 0) U[0] += gx;
-            int idx = (int)(((long long)m * e0) % N1);
+            // W1^(m (e0 + t)), t = 1 .. 16, from two table entries: products of at most five factors (16 scattered table reads
+            // per column were the cost of this kernel)
+            const cplx wb = root1[(int)(((long long)m * e0) % N1)];
+            cplx wq[5];
+            wq[0] = make_double2(1.0, 0.0);
+            wq[1] = root1[m];
+            wq[2] = cmul(wq[1], wq[1]);
+            wq[3] = cmul(wq[2], wq[1]);
+            wq[4] = cmul(wq[2], wq[2]);
+            cplx w4k = wb;                          // W1^(m (e0 + 4 k))
 #pragma unroll
-            for (int t = 1; t <= 16; ++t) {
-                if (t <= ne) {
-                    idx += m; if (idx >= N1) idx -= N1;
-                    const cplx w = root1[idx];
-                    U[t] = fma(gx, w.x, U[t]);
-                    V[t] = fma(gy, w.y, V[t]);
+            for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+                for (int rr = 1; rr <= 4; ++rr) {
+                    const int t = 4 * k4 + rr;
+                    const cplx w = cmul(w4k, wq[rr]);
+                    if (t <= ne) {
+                        U[t] = fma(gx, w.x, U[t]);
+                        V[t] = fma(gy, w.y, V[t]);
+                    }
+                    if (rr == 4) w4k = w;
                 }
             }
         }
