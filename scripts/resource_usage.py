@@ -8,7 +8,7 @@ keys = [('VGPRs', 'vgpr'), ('AGPRs', 'agpr'), (r'ScratchSize \[bytes/lane\]', 's
 for b in blocks:
     name = b.split(' [')[0]
     try:
-        name = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], capture_output=True, text=True).stdout.strip() or name
+        name = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip() or name
     except Exception:
         pass
     vals = []

@@ -143,7 +143,8 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = cg + 4 * q;
-        a[q] = (i < nb && c <= i) ? Dsrc[i * CB + c] : ((i == c) ? 1.0 : 0.0);   // identity padding beyond nb
+        const double dv = Dsrc[i * CB + c];                                       // (unconditional load, then masked)
+        a[q] = (i < nb && c <= i) ? dv : ((i == c) ? 1.0 : 0.0);                 // identity padding beyond nb
     }
     // this workgroup's panel rows are requested now, so that their latency hides behind the factorization of the diagonal
     // block (the barriers below would otherwise keep the loads after it)
@@ -153,7 +154,8 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = cg + 4 * q;
-        p[q] = (i < nr && c < nb) ? A[(size_t)(r0 + i) * ld + k + c] : 0.0;
+        const double pv = A[(size_t)min(r0 + i, n) * ld + k + min(c, nb - 1)];    // (clamped, then masked: no branch around the load)
+        p[q] = (i < nr && c < nb) ? pv : 0.0;
     }
     chol_factor_diag(a, L, tid, nb, blockIdx.x == 0, status);
     if (blockIdx.x == 0) {
@@ -189,8 +191,10 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
     for (int it = 0; it < 16; ++it) {                 // 32 independent loads in flight per thread
         const int e = tid + 256 * it;
         const int i = e >> 6, t = e & 63;
-        Li[i][t] = (i < ni && t < nb) ? A[(size_t)(i0 + i) * ld + k + t] : 0.0;
-        Lj[i][t] = (i < nj && t < nb) ? A[(size_t)(j0 + i) * ld + k + t] : 0.0;
+        const double vi = A[(size_t)(i0 + min(i, ni - 1)) * ld + k + min(t, nb - 1)];      // (clamped, then masked)
+        const double vj = A[(size_t)(j0 + min(i, nj - 1)) * ld + k + min(t, nb - 1)];
+        Li[i][t] = (i < ni && t < nb) ? vi : 0.0;
+        Lj[i][t] = (i < nj && t < nb) ? vj : 0.0;
     }
     const int tx = tid & 15, ty = tid >> 4;
     // the entries to be updated are requested before the barrier and the product loop, which then hide their latency
@@ -201,7 +205,8 @@ __global__ void __launch_bounds__(256) chol_update(double* __restrict__ A, int l
         for (int q = 0; q < 4; ++q) {
             const int i = ty + 16 * r, j = tx + 16 * q;
             const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
-            old[r][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
+            const double ov = A[(size_t)(i0 + min(i, ni - 1)) * ld + j0 + min(j, nj - 1)];      // (clamped, then masked)
+            old[r][q] = ok ? ov : 0.0;
         }
     __syncthreads();
     double c[4][4];
@@ -326,12 +331,24 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
     const int i0 = k + ti * CB, j0 = k + tj * CB;
     const int ni = min(CB, n + 1 - i0), nj = min(CB, n - j0);
     if (ni <= 0 || nj <= 0) return;
+    // (unconditional loads from clamped rows, masked afterwards: a `cond ? A[..] : 0` load is compiled as a branch around the
+    //  load with a full s_waitcnt behind it -- 32 dependent round trips per thread, most of the 39 us this kernel used to take)
+    {
+        double vi[16], vj[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it;
-        const int i = e >> 6, t = e & 63;
-        Li[i][t] = (i < ni) ? A[(size_t)(i0 + i) * ld + kp + t] : 0.0;
-        Lj[i][t] = (i < nj) ? A[(size_t)(j0 + i) * ld + kp + t] : 0.0;
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it;
+            const int i = e >> 6, t = e & 63;
+            vi[it] = A[(size_t)(i0 + min(i, ni - 1)) * ld + kp + t];
+            vj[it] = A[(size_t)(j0 + min(i, nj - 1)) * ld + kp + t];
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it;
+            const int i = e >> 6, t = e & 63;
+            Li[i][t] = (i < ni) ? vi[it] : 0.0;
+            Lj[i][t] = (i < nj) ? vj[it] : 0.0;
+        }
     }
     // rank-CB update on the matrix cores: wave wv owns rows 16 wv .. 16 wv + 15 of the tile, four 16 x 16 column tiles, 16
     // k-steps of v_mfma_f64_16x16x4_f64 each (A[i][k] = Li[16 wv + i][4 ks + k], B[k][j] = Lj[16 jt + j][4 ks + k]).
@@ -344,7 +361,8 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
         for (int q = 0; q < 4; ++q) {
             const int i = 16 * wv + lk + 4 * q, j = 16 * jt + ln;
             const bool ok = (i < ni) && (j < nj) && (j0 + j <= i0 + i);
-            old[jt][q] = ok ? A[(size_t)(i0 + i) * ld + j0 + j] : 0.0;
+            const double v = A[(size_t)(i0 + min(i, ni - 1)) * ld + j0 + min(j, nj - 1)];      // (clamped, then masked: see above)
+            old[jt][q] = ok ? v : 0.0;
         }
     __syncthreads();
     d4s c[4];
@@ -453,8 +471,10 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int ri = i0 + sr + 32 * u, rj = j0 + sr + 32 * u;
-            pi[u] = (ri <= n) ? *reinterpret_cast<const double2*>(A + (size_t)ri * ld + K0 + kc + sc) : make_double2(0.0, 0.0);
-            pj[u] = (rj < n) ? *reinterpret_cast<const double2*>(A + (size_t)rj * ld + K0 + kc + sc) : make_double2(0.0, 0.0);
+            const double2 qi = *reinterpret_cast<const double2*>(A + (size_t)min(ri, n) * ld + K0 + kc + sc);      // (clamped, then masked)
+            const double2 qj = *reinterpret_cast<const double2*>(A + (size_t)min(rj, n) * ld + K0 + kc + sc);
+            pi[u] = (ri <= n) ? qi : make_double2(0.0, 0.0);
+            pj[u] = (rj < n) ? qj : make_double2(0.0, 0.0);
         }
     };
     d4s c[4][4];
@@ -524,7 +544,8 @@ __global__ void __launch_bounds__(256) chol_inv_diag(const double* __restrict__ 
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int e = tid + 256 * it, r = e >> 6, q = e & 63;
-        Ls[r][q] = (r < nb && q <= r) ? A[(size_t)(kb + r) * ld + kb + q] : 0.0;
+        const double lv = A[(size_t)(kb + min(r, nb - 1)) * ld + kb + min(q, nb - 1)];      // (clamped, then masked: no branch around the load)
+        Ls[r][q] = (r < nb && q <= r) ? lv : 0.0;
         Ws[r][q] = 0.0;
     }
     __syncthreads();
