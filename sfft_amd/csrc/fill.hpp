@@ -141,11 +141,12 @@ __device__ double sys_group_element(const double* P, const double* phi, const do
 __global__ void __launch_bounds__(256) fill_system(const double* __restrict__ P, const double* __restrict__ phi,
                                                    const double* __restrict__ delta, FillArgs f, const int* __restrict__ idx,
                                                    int n, int NEQ, double* __restrict__ out, int ld,
-                                                   double* __restrict__ rhs_vec)
+                                                   double* __restrict__ rhs_vec, int lower_only)
 {
     const int Cp = blockIdx.x * 16 + (threadIdx.x & 15);
     const int Rp = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (Rp > n || Cp > n) return;
+    if (lower_only && Cp > Rp) return;          // the Cholesky path reads the lower triangle and the border row only
     if (Rp == n && Cp == n) { if (out) out[(size_t)n * ld + n] = 0.0; return; }
     if (Rp == n) {   // rhs row (and optional separate vector)
         const int C = idx ? idx[Cp] : Cp;

@@ -1141,12 +1141,12 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
     return SFFT_OK;
 }
 
-static int run_fill(sfft_plan* p, hipStream_t s)
+static int run_fill(sfft_plan* p, hipStream_t s, bool lower_only)
 {
     const int n = p->NEQfs;
     dim3 g((n + 1 + 15) / 16, (n + 1 + 15) / 16);
     hipLaunchKernelGGL(fill_system, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->d_idx, n, p->NEQ,
-                       p->d_A, p->ld, (double*)nullptr);
+                       p->d_A, p->ld, (double*)nullptr, lower_only ? 1 : 0);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -1301,7 +1301,7 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
         {
             StageTimer t(p, SFFT_ST_FILL, s);
             HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), s));
-            if ((rc = run_fill(p, s))) return rc;
+            if ((rc = run_fill(p, s, !use_lu))) return rc;
         }
         {
             StageTimer t(p, SFFT_ST_SOLVE, s);

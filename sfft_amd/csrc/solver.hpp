@@ -14,9 +14,16 @@
 // from A, because workgroup 0 overwrites A's diagonal block with the factor while the others may still start.
 __global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__ A, int ld, int nb, double* __restrict__ Dst)
 {
-    for (int e = threadIdx.x; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        Dst[i * CB + j] = A[(size_t)i * ld + j];
+    double v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {            // all 16 loads of a thread first (clamped), then the stores
+        const int e = threadIdx.x + 256 * it, i = e >> 6, j = e & 63;
+        v[it] = A[(size_t)min(i, nb - 1) * ld + min(j, nb - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = threadIdx.x + 256 * it, i = e >> 6, j = e & 63;
+        if (i < nb && j < nb) Dst[i * CB + j] = v[it];
     }
 }
 
