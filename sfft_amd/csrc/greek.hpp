@@ -376,29 +376,48 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
 
 // Delta: rowmom[l][q] = sum_n J[l][n] tby[q][n], then delta[t] = SCALE * sum_l tbx[p[t]][l] rowmom[l][q[t]]
 // (= PreDEL[pq][0][0], SFFTSubtract.py:706-729, evaluated in real space: only element [0][0] is ever read).
+// Four image rows per workgroup: a thread reads the nq table values of its column once for the four rows (with one row per
+// workgroup the table re-reads out of L2 were four times the image traffic).
+#define ROWMOM_R 4
 template <int NQ>
 __global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J, double* __restrict__ rowmom, int N0, int N1,
                                                    const double* __restrict__ tby, int nq)
 {
-    const int l = blockIdx.x, tid = threadIdx.x;
-    double acc[NQ];
+    const int l0 = blockIdx.x * ROWMOM_R, tid = threadIdx.x;
+    double acc[ROWMOM_R][NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-#pragma unroll 8                        // eight rows of loads in flight: the kernel is one streaming read of J
+    for (int rr = 0; rr < ROWMOM_R; ++rr)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[rr][q] = 0.0;
+    const double* __restrict__ jr[ROWMOM_R];
+#pragma unroll
+    for (int rr = 0; rr < ROWMOM_R; ++rr) jr[rr] = J + (size_t)min(l0 + rr, N0 - 1) * N1;      // (rows past the image: recomputed, not stored)
+#pragma unroll 4
     for (int n = tid; n < N1; n += 256) {
-        const double v = J[(size_t)l * N1 + n];
+        double t[NQ], v[ROWMOM_R];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = fma(v, tby[(size_t)min(q, nq - 1) * N1 + n], acc[q]);   // q >= nq: unused copies
-    }
-    __shared__ double red[4][NQ];
+        for (int rr = 0; rr < ROWMOM_R; ++rr) v[rr] = jr[rr][n];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        double u = acc[q];
-        for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
-        if ((tid & 63) == 0) red[tid >> 6][q] = u;
+        for (int q = 0; q < NQ; ++q) t[q] = tby[(size_t)min(q, nq - 1) * N1 + n];               // q >= nq: unused copies
+#pragma unroll
+        for (int rr = 0; rr < ROWMOM_R; ++rr)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[rr][q] = fma(v[rr], t[q], acc[rr][q]);
     }
+    __shared__ double red[4][ROWMOM_R][NQ];
+#pragma unroll
+    for (int rr = 0; rr < ROWMOM_R; ++rr)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            double u = acc[rr][q];
+            for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
+            if ((tid & 63) == 0) red[tid >> 6][rr][q] = u;
+        }
     __syncthreads();
-    if (tid < NQ) rowmom[(size_t)l * SFFT_MAX_BQ + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < ROWMOM_R * NQ) {
+        const int rr = tid / NQ, q = tid - rr * NQ;
+        if (l0 + rr < N0) rowmom[(size_t)(l0 + rr) * SFFT_MAX_BQ + q] = red[0][rr][q] + red[1][rr][q] + red[2][rr][q] + red[3][rr][q];
+    }
 }
 
 __global__ void __launch_bounds__(256) delta_finish(const double* __restrict__ rowmom, double* __restrict__ delta, int N0,

@@ -1260,8 +1260,8 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
         if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS))) return rc;
-        if (p->nby <= 4) hipLaunchKernelGGL(row_moments<4>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
-        else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3(p->N0), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
+        if (p->nby <= 4) hipLaunchKernelGGL(row_moments<4>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
+        else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
     }
