@@ -226,6 +226,93 @@ __global__ void __launch_bounds__(256, 4) vconv_mixed(const cplx* __restrict__ s
     }
 }
 
+// vconv_mixed2: the same walk two source rows at a time -- the FIJ table entries of a tap are read from LDS once and serve
+// both rows (row y feeds window slot q, row y + 1 slot q + 1), which halves the LDS traffic and doubles the arithmetic behind
+// every LDS round trip; the window has L + 1 slots and slides by two.
+template <int DK, int W, int KS>
+__global__ void __launch_bounds__(256, 3) vconv_mixed2(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+                                                       const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
+                                                       cplx* __restrict__ trash)
+{
+    constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2, NSRC = (KS * L + 1) / 2 * 2, R = KS * L - 2 * W;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* ctab = reinterpret_cast<cplx*>(smem_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cl = lane & 15, sl = lane >> 4;
+    const int m = blockIdx.x * 16 + cl;
+    const bool active = m < Nh;
+    const int mc = active ? m : Nh - 1;
+    for (int e = threadIdx.x; e < FIJ * L * 16; e += 256) {
+        const int ta = e >> 4, c = e & 15;
+        ctab[e] = Ctab[(size_t)ta * Nhp + (size_t)min((int)blockIdx.x * 16 + c, Nh - 1)];
+    }
+    __syncthreads();
+    const int x0 = ((blockIdx.y * 4 + wv) * 4 + sl) * R;
+    if (x0 >= N0) return;
+    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(mc), rs = (size_t)lay.rstride;
+    cplx acc[L + 1];
+#pragma unroll
+    for (int q = 0; q <= L; ++q) acc[q] = make_double2(0.0, 0.0);
+    int y = x0 - W;
+    if (y < 0) y += N0;
+#pragma unroll 1
+    for (int sI = 0; sI < NSRC; sI += 2) {
+        int opq;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+        const cplx* __restrict__ ct = ctab + cl + opq;
+        const int y1 = (y + 1 == N0) ? 0 : y + 1;
+        cplx S0[NJ], S1[NJ];
+        double f0[NJ], f1[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            S0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            S1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
+            f0[jj] = kbx[(size_t)jj * N0 + y];
+            f1[jj] = kbx[(size_t)jj * N0 + y1];
+        }
+#pragma unroll
+        for (int q = 0; q < L; ++q) {           // tap a = q - W
+            __builtin_amdgcn_sched_barrier(0);
+            double ax = acc[q].x, ay = acc[q].y, bx = acc[q + 1].x, by = acc[q + 1].y;
+#pragma unroll
+            for (int jj = 0; jj <= DK; ++jj) {
+                double ex = 0.0, ey = 0.0, gx = 0.0, gy = 0.0;
+#pragma unroll
+                for (int ii = 0; ii <= DK - jj; ++ii) {
+                    const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;
+                    const cplx c = ct[(t * L + q) * 16];
+                    ex = fma(f0[ii], c.x, ex); ey = fma(f0[ii], c.y, ey);
+                    gx = fma(f1[ii], c.x, gx); gy = fma(f1[ii], c.y, gy);
+                }
+                ax = fma(S0[jj].x, ex, fma(-S0[jj].y, ey, ax));
+                ay = fma(S0[jj].x, ey, fma(S0[jj].y, ex, ay));
+                bx = fma(S1[jj].x, gx, fma(-S1[jj].y, gy, bx));
+                by = fma(S1[jj].x, gy, fma(S1[jj].y, gx, by));
+            }
+            acc[q] = make_double2(ax, ay);
+            acc[q + 1] = make_double2(bx, by);
+        }
+        // the two output rows completed by these source rows (branch-free stores, see vconv_mixed)
+        const int xo = x0 - 2 * W + sI;
+        {
+            const unsigned long long ok64 = 0ULL - (unsigned long long)(sI >= 2 * W && xo < N0 && xo < x0 + R && active);
+            const unsigned long long a_ok = (unsigned long long)(D + mo + (size_t)max(xo, 0) * rs), a_tr = (unsigned long long)(trash + threadIdx.x);
+            *reinterpret_cast<cplx*>((a_ok & ok64) | (a_tr & ~ok64)) = acc[0];
+        }
+        {
+            const int x1 = xo + 1;
+            const unsigned long long ok64 = 0ULL - (unsigned long long)(sI + 1 >= 2 * W && x1 < N0 && x1 < x0 + R && active);
+            const unsigned long long a_ok = (unsigned long long)(D + mo + (size_t)max(x1, 0) * rs), a_tr = (unsigned long long)(trash + threadIdx.x);
+            *reinterpret_cast<cplx*>((a_ok & ok64) | (a_tr & ~ok64)) = acc[1];
+        }
+#pragma unroll
+        for (int q = 0; q + 2 <= L; ++q) acc[q] = acc[q + 2];
+        acc[L - 1] = make_double2(0.0, 0.0);
+        acc[L] = make_double2(0.0, 0.0);
+        y = (y1 + 1 == N0) ? 0 : y1 + 1;
+    }
+}
+
 // separately varying scaling: DIFF -= SCALE * I * sum_s a_s00 * sbx[sp[s]][row] * sby[sq[s]][col]  (the centre term of
 // Construct_FDIFF, BSplineSFFT.py:2489-2497, taken in real space: it is a plain product there)
 struct ScaArgs {

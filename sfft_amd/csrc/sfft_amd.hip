@@ -146,6 +146,7 @@ struct sfft_plan {
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
+    int vconv_rp = 2;                   // env SFFT_VCONV_RP=1: mixed-domain apply one source row at a time (KerHW <= 8 has the two-row kernel)
     int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 1;                    // Omega passes on the matrix cores (greek_g1_mfma); env SFFT_G1_MFMA=0: vector kernel (A/B testing)
@@ -371,6 +372,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
+    if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -1348,9 +1350,13 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         dim3 g((p->Nh + 15) / 16, (nstreams + 15) / 16);
         const size_t lds = (size_t)p->Fij * LT * 16 * sizeof(cplx);
 #define VCONV_LAUNCH(DKT, WT) do { \
+        if (p->vconv_rp == 2 && WT <= 8) { \
+        HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
+                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } else { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
-                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } while (0)
+                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } } while (0)
 #define VCONV_DK(WT) switch (p->DK) { case 0: VCONV_LAUNCH(0, WT); break; case 1: VCONV_LAUNCH(1, WT); break; case 2: VCONV_LAUNCH(2, WT); break; default: VCONV_LAUNCH(3, WT); }
         if (p->vw == 4) { VCONV_DK(4) } else if (p->vw == 8) { VCONV_DK(8) } else { VCONV_DK(12) }
 #undef VCONV_DK
