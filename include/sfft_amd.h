@@ -46,6 +46,7 @@ enum {
     SFFT_Q_LAST_SOLVER,             /* 1 = Cholesky, 2 = LU fallback, for the most recent solve */
     SFFT_Q_NUM_GREEK_PAIRS,         /* spectral products actually transformed per solve */
     SFFT_Q_SCAFIJ,                  /* scaling terms of a plan made by sfft_plan_create_varscale (0 otherwise) */
+    SFFT_Q_SOLVE_GRAPH,             /* 1 once the factorisation chain of this plan has been captured and replays as a hipGraph */
     SFFT_Q_COUNT
 };
 

@@ -135,9 +135,10 @@ struct sfft_plan {
     unsigned int* d_counter = nullptr;
     double* d_winv = nullptr;           // [nblk][CB][CB] inverses of the diagonal blocks of the Cholesky factor
     unsigned int* d_bflags = nullptr;   // [nblk] "x_b published" flags of the back substitution, stamped with the solve's epoch
-    unsigned int back_epoch = 0;
+    unsigned int* d_epoch = nullptr;    // solve counter behind the flag stamps (device resident: the launch chain has constant arguments)
+    hipGraphExec_t chol_exec = nullptr; // the factorisation + back substitution chain, captured once (env SFFT_NO_GRAPH=1: plain launches)
+    int use_graph = 1;
     int fused_step = 1;                 // env SFFT_FUSED_STEP=0: separate update / panel launches (A/B testing)
-    unsigned int step_epoch = 0;
     int n_bflags = 0;
     int back_variant = 1;               // env SFFT_BACK=0: one launch per block (A/B testing)
     double* d_sol = nullptr;            // [NEQ] internal solution copy
@@ -372,6 +373,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
+    if (getenv("SFFT_NO_GRAPH")) p->use_graph = 0;
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
@@ -645,6 +647,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->n_bflags = nblk_b + 1;                   // + 1: the hand-off flag of chol_step
         PLAN_TRY(dev_alloc(p, &p->d_bflags, (size_t)p->n_bflags));
         PLAN_HIP(hipMemset(p->d_bflags, 0, (size_t)p->n_bflags * sizeof(unsigned int)));
+        PLAN_TRY(dev_alloc(p, &p->d_epoch, (size_t)1));
+        PLAN_HIP(hipMemset(p->d_epoch, 0, sizeof(unsigned int)));
         if (const char* ev = getenv("SFFT_FUSED_STEP")) p->fused_step = atoi(ev);
         if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
         int ncu = 0;
@@ -800,7 +804,8 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch};
+    if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -836,6 +841,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_LAST_SOLVER: *v = p->last_solver; break;
         case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_dense_w); break;
         case SFFT_Q_SCAFIJ: *v = p->nsca; break;
+        case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
     return SFFT_OK;
@@ -1153,9 +1159,10 @@ static int run_fill(sfft_plan* p, hipStream_t s, bool lower_only)
     return SFFT_OK;
 }
 
-static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
+static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s)
 {
     const int n = p->NEQfs;
+    hipLaunchKernelGGL(chol_begin, dim3(1), dim3(1), 0, s, p->d_epoch);
     hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
     int step = 0;
     int kb = 0;                 // first column not yet factored
@@ -1167,9 +1174,8 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
             for (int st = 1; st < 4; ++st) {
                 const int k = kb + st * CB;
                 const int ntile = (n + 1 - k + CB - 1) / CB;
-                if (++p->step_epoch == 0u) p->step_epoch = 1u;
                 hipLaunchKernelGGL(chol_step, dim3(4 - st, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
-                                   p->d_bflags + p->n_bflags - 1, p->step_epoch, p->d_status, p->d_rd);
+                                   p->d_bflags + p->n_bflags - 1, p->d_epoch, (unsigned)((k / CB) % 255), p->d_status, p->d_rd);
             }
             const int r0 = kb + OB;
             const int nt = (n + 1 - r0 + SYRK_T - 1) / SYRK_T;
@@ -1188,9 +1194,8 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
         int k = kb + CB;
         for (; n - k >= CB; k += CB) {
             const int ntile = (n + 1 - k + CB - 1) / CB;
-            if (++p->step_epoch == 0u) p->step_epoch = 1u;
             hipLaunchKernelGGL(chol_step, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
-                               p->d_bflags + p->n_bflags - 1, p->step_epoch, p->d_status, p->d_rd);
+                               p->d_bflags + p->n_bflags - 1, p->d_epoch, (unsigned)((k / CB) % 255), p->d_status, p->d_rd);
         }
         // what is left: the update with the last full panel (it also hands over the raw diagonal block) and the partial block
         if (k < n) {
@@ -1217,8 +1222,7 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
     const int nblk = (n + CB - 1) / CB;
     if (p->back_variant == 1) {
         hipLaunchKernelGGL(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
-        if (++p->back_epoch == 0u) p->back_epoch = 1u;
-        hipLaunchKernelGGL(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->back_epoch, p->d_status);
+        hipLaunchKernelGGL(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->d_epoch, p->d_status);
     } else
     for (int b = nblk - 1; b >= 0; --b) {
         const int kb = b * CB, nb = std::min(CB, n - kb);
@@ -1229,6 +1233,35 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
     hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
                        p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
     LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
+// The factorisation and back substitution are ~35 dependent launches with constant arguments (the flag stamps come from a
+// device counter): captured once per plan and replayed as one hipGraph.  Streams that cannot be captured (the legacy default
+// stream) and any capture failure fall back to plain launches.
+static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
+{
+    if (!p->use_graph || s == nullptr || d_solution != p->d_sol) return run_cholesky_launches(p, d_solution, s);
+    if (!p->chol_exec) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            p->use_graph = 0;
+            return run_cholesky_launches(p, d_solution, s);
+        }
+        const int rc = run_cholesky_launches(p, d_solution, s);
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        hipError_t e2 = hipSuccess;
+        if (rc == SFFT_OK && e == hipSuccess && graph) e2 = hipGraphInstantiate(&p->chol_exec, graph, nullptr, nullptr, 0);
+        if (graph) hipGraphDestroy(graph);
+        if (rc != SFFT_OK || e != hipSuccess || e2 != hipSuccess || !p->chol_exec) {
+            (void)hipGetLastError();
+            p->chol_exec = nullptr;
+            p->use_graph = 0;
+            return run_cholesky_launches(p, d_solution, s);
+        }
+    }
+    HIPCHK(hipGraphLaunch(p->chol_exec, s));
     return SFFT_OK;
 }
 

@@ -37,6 +37,13 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return r;
 }
 
+// first node of a solve: a new stamp for this solve's flag hand-offs (never 0 in its upper 24 bits)
+__global__ void chol_begin(unsigned int* epoch_ctr)
+{
+    unsigned int v = (*epoch_ctr + 1u) & 0xFFFFFFu;
+    *epoch_ctr = v ? v : 1u;
+}
+
 // One panel step.  Every workgroup factors the 64x64 diagonal block (right-looking; thread (i, cg) owns elements
 // (i, cg + 4q), q < 16, in registers; four columns per pair of barriers; fully unrolled so that all register
 // indices are compile-time and only the triangular part is touched), workgroup 0 stores it, workgroups
@@ -325,10 +332,14 @@ __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__
 typedef double d4s __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld, int n, int kp, double* Draw, unsigned int* flag,
-                                                 unsigned int epoch, int* __restrict__ status, double* __restrict__ rd)
+                                                 const unsigned int* __restrict__ epoch_ctr, unsigned int step_id, int* __restrict__ status,
+                                                 double* __restrict__ rd)
 {
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;
+    // stamp of this hand-off: (solve counter, step) -- the counter lives in device memory and is bumped by chol_begin at the
+    // start of every solve, so that the whole chain of launches has constant arguments and replays as one hipGraph
+    const unsigned int epoch = (*epoch_ctr << 8) | step_id;
     __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16];
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // later: the updated tile T
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // later: start of the PanelLds
@@ -575,8 +586,10 @@ __global__ void __launch_bounds__(256) chol_inv_diag(const double* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256) chol_back_all(const double* __restrict__ A, int ld, int n, const double* __restrict__ Winv,
-                                                     double* xv, unsigned int* flags, unsigned int epoch, int* __restrict__ status)
+                                                     double* xv, unsigned int* flags, const unsigned int* __restrict__ epoch_ctr,
+                                                     int* __restrict__ status)
 {
+    const unsigned int epoch = (*epoch_ctr << 8) | 0xFFu;         // (step ids of chol_step stay below 255)
     __shared__ double Wb[CB][CB + 1];
     __shared__ double Ln[CB][CB + 1];
     __shared__ double xs[CB];

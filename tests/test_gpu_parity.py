@@ -830,3 +830,31 @@ def test_generic_fft_variants_agree(dev, shape, w):
     assert np.max(np.abs(new[2] - old[2])) <= 1e-11 * np.max(np.abs(old[2]))
     assert np.max(np.abs(new[3] - old[3])) <= 1e-11 * np.max(np.abs(old[3]))
     assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
+
+
+def test_solver_chain_replays_as_graph_on_a_side_stream(dev):
+    """On a capturable stream the ~35 launches of the factorisation and back substitution are captured once per plan and
+    replayed with hipGraphLaunch (flag stamps come from a device counter, so the arguments are constant).  Same solution as
+    the plain launches on the default stream, call after call."""
+    from sfft_amd.plan import Plan
+    from sfft_amd.utils.synthetic import make_pair
+    shape = (256, 320)
+    pair = make_pair(*shape, seed=8, mask=True)
+    I, J = _to(dev, pair["REF"]), _to(dev, pair["SCI"])
+    mI, mJ = _to(dev, pair["mREF"]), _to(dev, pair["mSCI"])
+    plan = Plan(shape[0], shape[1], 4, 2, 2, True, device=dev.index)
+    s0, d0 = plan.subtract(I, J, mI, mJ)                      # legacy default stream: plain launches
+    assert plan.query("SOLVE_GRAPH") == 0
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            s1, d1 = plan.subtract(I, J, mI, mJ)
+            outs.append((s1.clone(), d1.clone()))
+    side.synchronize()
+    assert plan.query("SOLVE_GRAPH") == 1
+    for s1, d1 in outs:
+        assert np.array_equal(s1.cpu().numpy(), s0.cpu().numpy())
+        assert np.array_equal(d1.cpu().numpy(), d0.cpu().numpy())
+    plan.close()
