@@ -138,6 +138,9 @@ struct sfft_plan {
     unsigned int* d_epoch = nullptr;    // solve counter behind the flag stamps (device resident: the launch chain has constant arguments)
     hipGraphExec_t chol_exec = nullptr; // the factorisation + back substitution chain, captured once (env SFFT_NO_GRAPH=1: plain launches)
     int use_graph = 1;
+    int* h_status = nullptr;            // pinned: status word of the most recent attempt
+    int test_fail_chol = 0;             // env SFFT_TEST_FAIL_CHOL=1 (tests): report the Cholesky attempt as failed, to exercise the LU redo path
+    bool attempt_lu = false;            // the most recent attempt used LU
     int fused_step = 1;                 // env SFFT_FUSED_STEP=0: separate update / panel launches (A/B testing)
     int n_bflags = 0;
     int back_variant = 1;               // env SFFT_BACK=0: one launch per block (A/B testing)
@@ -374,6 +377,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
     if (getenv("SFFT_NO_GRAPH")) p->use_graph = 0;
+    if (getenv("SFFT_TEST_FAIL_CHOL")) p->test_fail_chol = 1;
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
@@ -647,6 +651,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->n_bflags = nblk_b + 1;                   // + 1: the hand-off flag of chol_step
         PLAN_TRY(dev_alloc(p, &p->d_bflags, (size_t)p->n_bflags));
         PLAN_HIP(hipMemset(p->d_bflags, 0, (size_t)p->n_bflags * sizeof(unsigned int)));
+        PLAN_HIP(hipHostMalloc((void**)&p->h_status, sizeof(int), hipHostMallocDefault));
+        *p->h_status = 0;
         PLAN_TRY(dev_alloc(p, &p->d_epoch, (size_t)1));
         PLAN_HIP(hipMemset(p->d_epoch, 0, sizeof(unsigned int)));
         if (const char* ev = getenv("SFFT_FUSED_STEP")) p->fused_step = atoi(ev);
@@ -806,6 +812,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
                     p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
+    if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) if (q) hipFree(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
@@ -1286,10 +1293,50 @@ static int run_lu(sfft_plan* p, double* d_solution, hipStream_t s)
 
 static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t s);
 
-extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, double* d_solution, void* stream)
+// One attempt at the dense system, enqueued without a host sync: fill, factorisation (or pivoted LU), the status word read back
+// into pinned host memory, the solution copied out.
+static int solve_attempt(sfft_plan* p, bool use_lu, double* d_solution, hipStream_t s)
 {
-    if (!p || !d_I || !d_J || !d_solution) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
-    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    {
+        StageTimer t(p, SFFT_ST_FILL, s);
+        HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), s));
+        if ((rc = run_fill(p, s, !use_lu))) return rc;
+    }
+    {
+        StageTimer t(p, SFFT_ST_SOLVE, s);
+        if (use_lu) { if ((rc = run_lu(p, p->d_sol, s))) return rc; }
+        else { if ((rc = run_cholesky(p, p->d_sol, s))) return rc; }
+    }
+    if (!use_lu && p->test_fail_chol) HIPCHK(hipMemsetAsync(p->d_status, 1, sizeof(int), s));      // test hook: pretend a pivot failed
+    HIPCHK(hipMemcpyAsync(p->h_status, p->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(d_solution, p->d_sol, (size_t)p->NEQ * sizeof(double), hipMemcpyDeviceToDevice, s));
+    p->attempt_lu = use_lu;
+    return SFFT_OK;
+}
+
+// After the stream has been synchronised: if the Cholesky attempt met a non-positive pivot, redo the system with pivoted LU
+// like the reference's gesv (and wait for it); *redone tells the caller that d_solution has changed.  A system that LU
+// finds singular too is the reference's LinAlgError.
+static int solve_check(sfft_plan* p, double* d_solution, hipStream_t s, bool* redone)
+{
+    if (redone) *redone = false;
+    p->last_solver = p->attempt_lu ? 2 : 1;
+    if (*p->h_status == 0) return SFFT_OK;
+    if (p->attempt_lu) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+    int rc;
+    if ((rc = solve_attempt(p, true, d_solution, s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    p->last_solver = 2;
+    if (*p->h_status != 0) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+    if (redone) *redone = true;
+    return SFFT_OK;
+}
+
+// SingleSFFTConfigure + ESS(Subtract=False) on device images.  defer_check: return with everything enqueued and leave the
+// status check (solve_check, after a sync) to the caller -- sfft_subtract syncs once, at the end of the pair.
+static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double* d_solution, hipStream_t s, bool defer_check)
+{
     HIPCHK(hipSetDevice(p->dev));
     int rc;
     {
@@ -1330,29 +1377,16 @@ extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, do
         if ((rc = apply_prelim(p, dI, p->d_spec2, p->s2))) return rc;
         HIPCHK(hipEventRecord(p->ev_pre, p->s2));
     }
-    int status = 0;
-    bool use_lu = p->force_lu != 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        {
-            StageTimer t(p, SFFT_ST_FILL, s);
-            HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), s));
-            if ((rc = run_fill(p, s, !use_lu))) return rc;
-        }
-        {
-            StageTimer t(p, SFFT_ST_SOLVE, s);
-            if (use_lu) { if ((rc = run_lu(p, p->d_sol, s))) return rc; }
-            else { if ((rc = run_cholesky(p, p->d_sol, s))) return rc; }
-        }
-        HIPCHK(hipMemcpyAsync(&status, p->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        p->last_solver = use_lu ? 2 : 1;
-        if (status == 0) break;
-        if (use_lu) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
-        use_lu = true;   // Cholesky met a non-positive pivot: redo with pivoted LU like the reference's gesv
-    }
-    HIPCHK(hipMemcpyAsync(d_solution, p->d_sol, (size_t)p->NEQ * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if ((rc = solve_attempt(p, p->force_lu != 0, d_solution, s))) return rc;
+    if (defer_check) return SFFT_OK;
     HIPCHK(hipStreamSynchronize(s));
-    return SFFT_OK;
+    return solve_check(p, d_solution, s, nullptr);
+}
+
+extern "C" int sfft_solve(sfft_plan* p, const double* d_I, const double* d_J, double* d_solution, void* stream)
+{
+    if (!p || !d_I || !d_J || !d_solution) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    return solve_impl(p, d_I, d_J, d_solution, (hipStream_t)stream, false);
 }
 
 // forward spectra of the polynomial-weighted planes of I for the apply pass, into `dst` ([Fij][N0][Nhp])
@@ -1473,26 +1507,41 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
         HIPCHK(hipStreamSynchronize(s));
         return SFFT_OK;
     }
+    // One host sync per pair: the solve is enqueued without waiting for its status word, the apply pass follows on the stream, and
+    // the status is looked at after the final sync.  Only if the Cholesky attempt failed (LU fallback) is the apply pass redone.
+    bool redone = false;
     if (!p->use_vconv && !p->d_spec2) {      // (the mixed-domain apply keeps its DK + 1 stage planes in d_stage_a instead)
         if ((rc = dev_alloc(p, &p->d_spec2, (size_t)p->Fij * p->N0 * p->Nhp))) return rc;
     }
     if (d_I == d_mI) {
         // the caller passed the full image as its own mask ("'same' means it is identical with I",
         // SFFTSubtract.py:849): the spectra of the solve pass are the spectra of the apply pass
-        if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
+        if ((rc = solve_impl(p, d_mI, d_mJ, d_solution, s, true))) return rc;
         // (mixed-domain apply: a staged solve pass left the stage planes of I first in d_stage; otherwise they are made now)
         if (p->use_vconv && !p->staged_solve && (rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
-        if ((rc = apply_finish(p, p->use_vconv ? (p->staged_solve ? p->d_stage : p->d_stage_a) : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+        const cplx* FIa = p->use_vconv ? (p->staged_solve ? p->d_stage : p->d_stage_a) : p->d_spec;
+        if ((rc = apply_finish(p, FIa, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
         HIPCHK(hipStreamSynchronize(s));
+        if ((rc = solve_check(p, d_solution, s, &redone))) return rc;
+        if (redone) {
+            if ((rc = apply_finish(p, FIa, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+            HIPCHK(hipStreamSynchronize(s));
+        }
         return SFFT_OK;
     }
     p->overlap_I = d_I;
-    rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream);
+    rc = solve_impl(p, d_mI, d_mJ, d_solution, s, true);
     p->overlap_I = nullptr;
     if (rc) { hipStreamSynchronize(p->s2); return rc; }
     HIPCHK(hipStreamWaitEvent(s, p->ev_pre, 0));
-    if ((rc = apply_finish(p, p->use_vconv ? p->d_stage_a : p->d_spec2, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+    const cplx* FIb = p->use_vconv ? p->d_stage_a : p->d_spec2;
+    if ((rc = apply_finish(p, FIb, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
+    if ((rc = solve_check(p, d_solution, s, &redone))) return rc;
+    if (redone) {
+        if ((rc = apply_finish(p, FIb, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+    }
     return SFFT_OK;
 }
 

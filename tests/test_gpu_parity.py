@@ -858,3 +858,30 @@ def test_solver_chain_replays_as_graph_on_a_side_stream(dev):
         assert np.array_equal(s1.cpu().numpy(), s0.cpu().numpy())
         assert np.array_equal(d1.cpu().numpy(), d0.cpu().numpy())
     plan.close()
+
+
+def test_lu_redo_after_a_failed_cholesky_attempt_inside_subtract(dev):
+    """sfft_subtract enqueues solve and apply with one host sync at the end; when the status word then says that the Cholesky
+    attempt met a non-positive pivot, the system is redone with pivoted LU and the apply pass is run again.  The failure is
+    injected (SFFT_TEST_FAIL_CHOL); the result must be the ordinary one."""
+    from sfft_amd.utils.synthetic import make_pair
+    shape = (200, 168)
+    pair = make_pair(*shape, seed=12, mask=True)
+    ok = _subtract_with_env(dev, {}, shape, 3, 2, 1, pair)
+    from sfft_amd.plan import Plan
+    os.environ["SFFT_TEST_FAIL_CHOL"] = "1"
+    try:
+        plan = Plan(shape[0], shape[1], 3, 2, 1, True, device=dev.index)
+    finally:
+        os.environ.pop("SFFT_TEST_FAIL_CHOL", None)
+    I, J = _to(dev, pair["REF"]), _to(dev, pair["SCI"])
+    mI, mJ = _to(dev, pair["mREF"]), _to(dev, pair["mSCI"])
+    for masks in ((mI, mJ), (I, J)):                     # overlapped path, and the path that reuses the solve pass's spectra
+        sol, diff = plan.subtract(I, J, masks[0], masks[1])
+        assert plan.query("LAST_SOLVER") == 2
+        if masks[0] is mI:
+            assert np.linalg.norm(sol.cpu().numpy() - ok[0]) <= 1e-6 * np.linalg.norm(ok[0])
+            assert rms(diff.cpu().numpy() - ok[1]) <= 1e-7 * rms(ok[1])
+        else:
+            assert np.isfinite(diff.cpu().numpy()).all()
+    plan.close()
