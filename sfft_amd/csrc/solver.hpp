@@ -154,22 +154,29 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
     const int nb = min(CB, n - k);
     const int i = tid >> 2, cg = tid & 3;
     double a[16];
+    {   // (loads first, a scheduling fence, then the masks: see chol_inv_diag)
+        double dv[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        const double dv = Dsrc[i * CB + c];                                       // (unconditional load, then masked)
-        a[q] = (i < nb && c <= i) ? dv : ((i == c) ? 1.0 : 0.0);                 // identity padding beyond nb
+        for (int q = 0; q < 16; ++q) dv[q] = Dsrc[i * CB + cg + 4 * q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = cg + 4 * q;
+            a[q] = (i < nb && c <= i) ? dv[q] : ((i == c) ? 1.0 : 0.0);           // identity padding beyond nb
+        }
     }
     // this workgroup's panel rows are requested now, so that their latency hides behind the factorization of the diagonal
     // block (the barriers below would otherwise keep the loads after it)
     const int r0 = k + nb + ((int)blockIdx.x - 1) * CB;
     const int nr = blockIdx.x == 0 ? 0 : min(CB, n + 1 - r0);
     double p[16];
+    {
+        double pv[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cg + 4 * q;
-        const double pv = A[(size_t)min(r0 + i, n) * ld + k + min(c, nb - 1)];    // (clamped, then masked: no branch around the load)
-        p[q] = (i < nr && c < nb) ? pv : 0.0;
+        for (int q = 0; q < 16; ++q) pv[q] = A[(size_t)min(r0 + i, n) * ld + k + min(cg + 4 * q, nb - 1)];      // clamped
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) p[q] = (i < nr && cg + 4 * q < nb) ? pv[q] : 0.0;
     }
     chol_factor_diag(a, L, tid, nb, blockIdx.x == 0, status);
     if (blockIdx.x == 0) {
@@ -559,12 +566,21 @@ __global__ void __launch_bounds__(256) chol_inv_diag(const double* __restrict__ 
     __shared__ double Ls[CB][CB + 1];
     __shared__ double Ws[CB][CB + 1];
     const int tid = threadIdx.x, kb = blockIdx.x * CB, nb = min(CB, n - kb);
+    {   // all 16 loads (clamped), a scheduling fence, then the masked stores: in one loop the compiler sinks each load back into
+        // a branch of its own with a full wait behind it
+        double lv[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, r = e >> 6, q = e & 63;
-        const double lv = A[(size_t)(kb + min(r, nb - 1)) * ld + kb + min(q, nb - 1)];      // (clamped, then masked: no branch around the load)
-        Ls[r][q] = (r < nb && q <= r) ? lv : 0.0;
-        Ws[r][q] = 0.0;
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it, r = e >> 6, q = e & 63;
+            lv[it] = A[(size_t)(kb + min(r, nb - 1)) * ld + kb + min(q, nb - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it, r = e >> 6, q = e & 63;
+            Ls[r][q] = (r < nb && q <= r) ? lv[it] : 0.0;
+            Ws[r][q] = 0.0;
+        }
     }
     __syncthreads();
     // column j of W solves L w = e_j; four lanes per column split the dot product (same wave: tid = 4 j + g)
@@ -599,12 +615,21 @@ __global__ void __launch_bounds__(256) chol_back_all(const double* __restrict__ 
     const int tid = threadIdx.x, kb = b * CB, nb = min(CB, n - kb);
     const int jj = tid & 63, gg = tid >> 6;
     const double* W = Winv + (size_t)b * CB * CB;
+    {   // (loads first, a scheduling fence, then the masked stores: see chol_inv_diag)
+        double wv[16], lv[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, r = e >> 6, q = e & 63;
-        Wb[r][q] = W[e];
-        const int row = kb + CB + r;
-        Ln[r][q] = (b + 1 < nblk && row < n && q < nb) ? A[(size_t)row * ld + kb + q] : 0.0;
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it, r = e >> 6, q = e & 63;
+            wv[it] = W[e];
+            lv[it] = A[(size_t)min(kb + CB + r, n) * ld + kb + min(q, nb - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = tid + 256 * it, r = e >> 6, q = e & 63;
+            Wb[r][q] = wv[it];
+            Ln[r][q] = (b + 1 < nblk && kb + CB + r < n && q < nb) ? lv[it] : 0.0;
+        }
     }
     double acc = 0.0;                                   // threads tid < 64: sum_c (L_cb^T x_c)[tid]
     for (int c = nblk - 1; c > b; --c) {
