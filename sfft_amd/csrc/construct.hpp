@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) kernel_ctab_mixed(const double* __restric
 }
 
 template <int DK, int W, int KS>
-__global__ void __launch_bounds__(256, 4) vconv_mixed(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+__global__ void __launch_bounds__(256, (W > 8 ? 2 : 4)) vconv_mixed(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
                                                       const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
                                                       cplx* __restrict__ trash)
 {
