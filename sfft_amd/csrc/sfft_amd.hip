@@ -232,13 +232,27 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N);
 static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
 {
     const long double PI = acosl(-1.0L);
-    int a = 1;
-    while (N % (a * 2) == 0 && a * 2 <= 4096) a *= 2;
+    // any factorisation N = A * B with both factors on chip; cost per element ~ passes over LDS of the two sub-transforms
+    // (1 for a direct power-of-two / 2^a 3^b length, 4 M / len for Bluestein: two transforms of M >= 2 len - 1 plus products)
+    auto cost = [](int len) {
+        int e2, e3;
+        if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return 1.0;
+        int M = 1; while (M < 2 * len - 1) M <<= 1;
+        return 4.0 * M / len;
+    };
     int A = 0, B = 0;
-    for (; a >= 2; a /= 2) { if (fits_on_chip(N / a)) { A = a; B = N / a; break; } }
+    double best = 1e300;
+    for (int a = 2; (long long)a * a <= N; ++a) {
+        if (N % a) continue;
+        const int b = N / a;
+        if (!fits_on_chip(a) || !fits_on_chip(b)) continue;
+        auto padded = [](int len) { int e2, e3; if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return len; int M = 1; while (M < 2 * len - 1) M <<= 1; return M; };
+        const double c = cost(a) + cost(b) + 1e-6 * (padded(a) + padded(b));      // (ties: the smaller on-chip transforms)
+        if (c < best) { best = c; A = a; B = b; }
+    }
     if (!A) return set_err(SFFT_ERR_UNSUPPORTED_SIZE,
                            "image side not supported by this build: it must fit one on-chip transform (power of two <= 8192, "
-                           "any length <= 4096) or factor as 2^k * B with both factors on chip");
+                           "2^a 3^b <= 9216, any length <= 4096) or factor as A * B with both factors on chip");
     ax.N = N; ax.big = true; ax.A = A; ax.B = B; ax.M = 0; ax.logM = 0; ax.blue = 0;
     ax.subA = new AxisHost(); ax.subB = new AxisHost();
     int rc;
