@@ -139,7 +139,9 @@ __device__ __forceinline__ void lds_stage_small(cplx* s, int M, int nb, int stri
 }
 
 // one radix-3 stage on the padded layout (natural on the way out when `last`); p = product of the earlier radices
-__device__ __forceinline__ void lds_stage3_padded(cplx* s, int M, int p, int nb, int stride, const cplx* __restrict__ tw, bool padded_in, bool last)
+template <int POST>
+__device__ __forceinline__ void lds_stage3_padded(cplx* s, int M, int p, int nb, int stride, const cplx* __restrict__ tw, bool padded_in, bool last,
+                                                  const cplx* __restrict__ post, int npost)
 {
     constexpr int IT = 6;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -177,7 +179,16 @@ __device__ __forceinline__ void lds_stage3_padded(cplx* s, int M, int p, int nb,
             const int k = i % p;
             cplx* b = s + f * stride;
             const int o = (i - k) * 3 + k;
-            if (last) { b[o] = y[it][0]; b[o + p] = y[it][1]; b[o + 2 * p] = y[it][2]; }
+            if (last) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    cplx v = y[it][r];
+                    const int kk = o + r * p;
+                    if (POST == 1) v = cconj(cmul(v, post[kk]));
+                    if (POST == 2) v = cmul(post[min(kk, npost - 1)], cconj(v));
+                    b[kk] = v;
+                }
+            }
             else { b[pad16(o)] = y[it][0]; b[pad16(o + p)] = y[it][1]; b[pad16(o + 2 * p)] = y[it][2]; }
         }
     }
@@ -185,7 +196,7 @@ __device__ __forceinline__ void lds_stage3_padded(cplx* s, int M, int p, int nb,
 }
 
 // M = 2^log2p * 3^n3 (log2p >= 4 or n3 >= 1): leading radix-2/4/8 stage, radix-16 stages, then the radix-3 stages.
-// POST (applied to output k of the last stage, power-of-two M only): 1: conj(X[k] * post[k]) -- the Bluestein filter; the next
+// POST (applied to output k of the last stage): 1: conj(X[k] * post[k]) -- the Bluestein filter; the next
 // forward transform then acts as the inverse one;  2: post[k] * conj(X[k]) for k < npost -- the closing chirp
 template <bool PRE, int POST>
 __device__ __forceinline__ void lds_fft_r16(cplx* s, int M, int log2p, int n3, int nb, int stride, const cplx* __restrict__ tw,
@@ -243,7 +254,7 @@ __device__ __forceinline__ void lds_fft_r16(cplx* s, int M, int log2p, int n3, i
     }
     int p3 = 1 << log2p;
     for (int l = 0; l < n3; ++l, p3 *= 3) {
-        lds_stage3_padded(s, M, p3, nb, stride, tw, padded, l == n3 - 1);
+        lds_stage3_padded<POST>(s, M, p3, nb, stride, tw, padded, l == n3 - 1, post, npost);
         padded = true;
     }
 }
@@ -418,7 +429,7 @@ __device__ __forceinline__ void lds_fft_pow2(cplx* s, const AxisDev& ax, int nb,
 __device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int stride)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
-    if (ax.n3) {
+    if (ax.n3 && !ax.blue) {
         if (ax.r16) lds_fft_r16<false, 0>(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw, nullptr, 0, nullptr, 0);
         else lds_fft_mixed(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw);
         return;
@@ -427,8 +438,8 @@ __device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int 
     if (ax.r16) {
         // Bluestein with the three pointwise products folded into the transforms' first read / last write:
         //   a = x * chirp;  A = FFT(a);  c = conj(A * Bf);  C = FFT(c);  X[k] = chirp[k] * conj(C[k])
-        lds_fft_r16<true, 1>(s, ax.M, ax.logM, 0, nb, stride, ax.tw, ax.chirp, ax.N, ax.bf, ax.M);
-        lds_fft_r16<false, 2>(s, ax.M, ax.logM, 0, nb, stride, ax.tw, nullptr, 0, ax.chirp, ax.N);
+        lds_fft_r16<true, 1>(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw, ax.chirp, ax.N, ax.bf, ax.M);
+        lds_fft_r16<false, 2>(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw, nullptr, 0, ax.chirp, ax.N);
         return;
     }
     const int M = ax.M;

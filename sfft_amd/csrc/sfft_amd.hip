@@ -217,13 +217,53 @@ static bool is_2a3b(int N, int* a, int* b)
     return true;
 }
 
+// forward DFT of a length 2^a 3^b sequence on the host (long double; plan creation only)
+static void host_fft_23(std::vector<long double>& re, std::vector<long double>& im)
+{
+    const int n = (int)re.size();
+    if (n == 1) return;
+    const int f = (n % 2 == 0) ? 2 : 3, m = n / f;
+    std::vector<long double> sr[3], si[3];
+    for (int r = 0; r < f; ++r) {
+        sr[r].resize(m); si[r].resize(m);
+        for (int j = 0; j < m; ++j) { sr[r][j] = re[r + f * j]; si[r][j] = im[r + f * j]; }
+        host_fft_23(sr[r], si[r]);
+    }
+    const long double PI = acosl(-1.0L);
+    for (int k = 0; k < m; ++k)
+        for (int q = 0; q < f; ++q) {
+            const int o = k + m * q;
+            long double xr = 0.0L, xi = 0.0L;
+            for (int r = 0; r < f; ++r) {
+                const long double ang = -2.0L * PI * (long double)((long long)r * o % n) / n;
+                const long double wr = cosl(ang), wi = sinl(ang);
+                xr += sr[r][k] * wr - si[r][k] * wi;
+                xi += sr[r][k] * wi + si[r][k] * wr;
+            }
+            re[o] = xr; im[o] = xi;
+        }
+}
+
+static bool is_2a3b(int N, int* a, int* b);
+// Bluestein transform length for an N-point axis: the power of two >= 2 N - 1 when it fits on chip; beyond that (N in
+// 4097 .. 4608) the 9216-point mixed-radix transform.  (Shorter 2^a 3^b lengths were measured and lose to the next power of
+// two -- 577 points on 1296 instead of 2048: 19.8 -> 23.8 ms for config 5's columns -- the radix-3 stages and their general
+// index arithmetic cost more than the shorter length saves.)  0 if nothing fits.
+static int bluestein_len(int N)
+{
+    const int need = 2 * N - 1;
+    int p2 = 1; while (p2 < need) p2 <<= 1;
+    if ((size_t)p2 <= LDS_MAX_ELEMS) return p2;
+    if (need <= 9216 && !getenv("SFFT_NO_MIXED_RADIX") && !getenv("SFFT_NO_R16")) return 9216;
+    return 0;
+}
+
 static bool fits_on_chip(int N)
 {
     if (is_pow2(N)) return (size_t)N <= LDS_MAX_ELEMS;
     int a, b;
     if (is_2a3b(N, &a, &b) && (size_t)N <= LDS_MIXED_ELEMS && !getenv("SFFT_NO_MIXED_RADIX")) return true;
-    int M = 1; while (M < 2 * N - 1) M <<= 1;
-    return (size_t)M <= LDS_MAX_ELEMS;
+    return bluestein_len(N) != 0;
 }
 
 static int build_axis(sfft_plan* p, AxisHost& ax, int N);
@@ -237,8 +277,7 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
     auto cost = [](int len) {
         int e2, e3;
         if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return 1.0;
-        int M = 1; while (M < 2 * len - 1) M <<= 1;
-        return 4.0 * M / len;
+        return 4.0 * bluestein_len(len) / len;
     };
     int A = 0, B = 0;
     double best = 1e300;
@@ -246,7 +285,7 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
         if (N % a) continue;
         const int b = N / a;
         if (!fits_on_chip(a) || !fits_on_chip(b)) continue;
-        auto padded = [](int len) { int e2, e3; if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return len; int M = 1; while (M < 2 * len - 1) M <<= 1; return M; };
+        auto padded = [](int len) { int e2, e3; if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return len; return bluestein_len(len); };
         const double c = cost(a) + cost(b) + 1e-6 * (padded(a) + padded(b));      // (ties: the smaller on-chip transforms)
         if (c < best) { best = c; A = a; B = b; }
     }
@@ -276,7 +315,10 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
     int e2 = 0, e3 = 0;
     if (is_pow2(N)) { ax.M = N; ax.blue = 0; }
     else if (is_2a3b(N, &e2, &e3) && !getenv("SFFT_NO_MIXED_RADIX")) { ax.M = N; ax.blue = 0; ax.n3 = e3; }
-    else { int M = 1; while (M < 2 * N - 1) M <<= 1; ax.M = M; ax.blue = 1; }
+    else {
+        ax.M = bluestein_len(N); ax.blue = 1;
+        if (!is_pow2(ax.M)) { is_2a3b(ax.M, &e2, &e3); ax.n3 = e3; }
+    }
     ax.logM = ax.n3 ? e2 : ilog2(ax.M);
     ax.r16 = ((ax.n3 || ax.M >= 16) && !getenv("SFFT_NO_R16")) ? 1 : 0;
     int rc;
@@ -307,7 +349,7 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
         fr[k] = cosl(a2); fi[k] = sinl(a2);
         if (k > 0) { fr[ax.M - k] = fr[k]; fi[ax.M - k] = fi[k]; }
     }
-    host_fft_pow2(fr, fi);
+    if (is_pow2(ax.M)) host_fft_pow2(fr, fi); else host_fft_23(fr, fi);
     std::vector<cplx> bf(ax.M);
     for (int k = 0; k < ax.M; ++k) bf[k] = make_double2((double)(fr[k] / ax.M), (double)(fi[k] / ax.M));
     if ((rc = dev_alloc(p, &ax.bf, ax.M))) return rc;

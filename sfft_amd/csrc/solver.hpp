@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) chol_panel(double* __restrict__ A, int ld
     {
         double pv[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) pv[q] = A[(size_t)min(r0 + i, n) * ld + k + min(cg + 4 * q, nb - 1)];      // clamped
+        for (int q = 0; q < 16; ++q) pv[q] = A[(size_t)max(min(r0 + i, n), 0) * ld + k + min(cg + 4 * q, nb - 1)];      // clamped (workgroup 0 of a partial block: r0 < 0)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 16; ++q) p[q] = (i < nr && cg + 4 * q < nb) ? pv[q] : 0.0;

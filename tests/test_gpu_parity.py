@@ -46,7 +46,7 @@ NAMES = golden_names()
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(8, 8), (64, 64), (128, 32), (48, 40), (45, 35), (100, 96), (512, 256), (300, 500),
                                    (1024, 2048), (4096, 64), (64, 4096), (4096, 4096), (4095, 4096), (8192, 16),
-                                   (6144, 40), (40, 6144), (9232, 64), (64, 9216), (4100, 5000), (4097, 24), (16, 12261),     # big axes (12261 = 3 * 61 * 67)
+                                   (6144, 40), (40, 6144), (9232, 64), (64, 9216), (4100, 5000), (4097, 24), (16, 12261), (4513, 32), (40, 4603),     # big axes (12261 = 3 * 61 * 67); primes up to 4608 through Bluestein on 9216 points
                                    (12, 24), (9, 18), (27, 24), (81, 162), (96, 1536), (1536, 96), (8748, 16), (16, 8748),
                                    (9216, 24), (2304, 3072)])   # last rows: 2^a*3^b axes (mixed-radix on-chip transform)
 @pytest.mark.parametrize("ij", [(0, 0), (2, 1)])
