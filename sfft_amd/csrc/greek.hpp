@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
     const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz;
     const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz;
     const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
-    const int tcol = PACK ? 1 + (n & 7) : 1 + n;          // twiddle column (lag) this lane feeds into A
+    const int tcol = min(PACK ? 1 + (n & 7) : 1 + n, HM - 1);   // twiddle column (lag) this lane feeds into A (lags beyond the table: unused rows of D)
     size_t co[NT];
     bool act[NT];
 #pragma unroll

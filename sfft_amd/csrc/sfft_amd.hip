@@ -166,11 +166,42 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static SpecLayout rowmajor_layout(int ld) { SpecLayout L; L.shift = 31; L.mask = 0x7fffffff; L.rstride = ld; L.pstride = 0; return L; }
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Debug allocator (env SFFT_GUARD=1 | 2): every plan buffer is mapped on its own with unmapped address space on both sides
+// (HIP virtual-memory API), its END (1) or START (2) flush with the mapping, so that a kernel reading or writing out of
+// bounds faults instead of silently touching a neighbour.  Such buffers are never freed (debug runs only).
+static int guard_mode() { static int v = getenv("SFFT_GUARD") ? atoi(getenv("SFFT_GUARD")) : 0; return v; }
+static hipError_t guarded_malloc(void** out, size_t bytes, int dev)
+{
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    const size_t mapped = (bytes + gran - 1) / gran * gran;
+    void* va = nullptr;
+    if ((e = hipMemAddressReserve(&va, mapped + 2 * gran, gran, nullptr, 0)) != hipSuccess) return e;
+    hipMemGenericAllocationHandle_t h;
+    if ((e = hipMemCreate(&h, mapped, &prop, 0)) != hipSuccess) return e;
+    char* base = (char*)va + gran;
+    if ((e = hipMemMap(base, mapped, 0, h, 0)) != hipSuccess) return e;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(base, mapped, &acc, 1)) != hipSuccess) return e;
+    const size_t slack = (mapped - bytes) & ~(size_t)15;             // keep 16-byte alignment
+    *out = guard_mode() == 1 ? base + slack : base;
+    return hipSuccess;
+}
+static void dev_free(void* q) { if (q && !guard_mode()) hipFree(q); }
+
 template <typename T>
 static int dev_alloc(sfft_plan* p, T** ptr, size_t count)
 {
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+    hipError_t e = guard_mode() ? guarded_malloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16, p->dev)
+                                : hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
     if (e != hipSuccess) return set_err(SFFT_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
     *ptr = reinterpret_cast<T*>(q);
     p->ws_bytes += count * sizeof(T);
@@ -853,10 +884,10 @@ static void free_axis(AxisHost& a)
 {
     if (a.subA) { free_axis(*a.subA); delete a.subA; a.subA = nullptr; }
     if (a.subB) { free_axis(*a.subB); delete a.subB; a.subB = nullptr; }
-    if (a.tw) hipFree(a.tw);
-    if (a.root && !a.root_is_tw) hipFree(a.root);
-    if (a.chirp) hipFree(a.chirp);
-    if (a.bf) hipFree(a.bf);
+    dev_free(a.tw);
+    if (!a.root_is_tw) dev_free(a.root);
+    dev_free(a.chirp);
+    dev_free(a.bf);
     a.tw = a.root = a.chirp = a.bf = nullptr;
 }
 
@@ -870,7 +901,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
                     p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
-    for (void* q : ptrs) if (q) hipFree(q);
+    for (void* q : ptrs) dev_free(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
     if (p->ev_in) hipEventDestroy(p->ev_in);
@@ -1051,7 +1082,7 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
     std::stable_sort(stages.begin(), stages.end(), [&](const Stage& a, const Stage& b) { return (a.src == d_I) > (b.src == d_I); });
     const int nst = (int)stages.size();
     if (nst > p->n_stage_alloc) {
-        if (p->d_stage) { HIPCHK(hipStreamSynchronize(s)); hipFree(p->d_stage); p->d_stage = nullptr; }
+        if (p->d_stage) { HIPCHK(hipStreamSynchronize(s)); dev_free(p->d_stage); p->d_stage = nullptr; }
         int rc = dev_alloc(p, &p->d_stage, (size_t)nst * p->N0 * p->Nhp);
         if (rc) return rc;
         p->n_stage_alloc = nst;
