@@ -96,11 +96,18 @@ __device__ double sys_element(const double* P, const double* phi, const double* 
             if (c8) return sk_at(P, f, i8, ij, -a, -b) - sk_at(P, f, i8, ij, 0, 0) + reg;
             return sk_at(P, f, ij, i8, -a8, -b8) - sk_at(P, f, ij, i8, 0, 0) + reg;
         }
+        // the four-case centre rule without branches around the loads (all four lags are always inside the patch): the loads
+        // issue together and the case picks the coefficients
         const double o00 = omg_at(P, f, i8, ij, 0, 0);
-        if (c8 && c) return o00 + reg;
-        if (c8) return omg_at(P, f, i8, ij, -a, -b) - o00 + reg;
-        if (c) return omg_at(P, f, i8, ij, a8, b8) - o00 + reg;
-        return -omg_at(P, f, i8, ij, a8, b8) - omg_at(P, f, i8, ij, -a, -b) + omg_at(P, f, i8, ij, a8 - a, b8 - b) + o00 + reg;
+        const double o1 = omg_at(P, f, i8, ij, a8, b8);
+        const double o2 = omg_at(P, f, i8, ij, -a, -b);
+        const double o3 = omg_at(P, f, i8, ij, a8 - a, b8 - b);
+        const bool none = !c8 && !c;
+        const double k1 = none ? -1.0 : ((c && !c8) ? 1.0 : 0.0);
+        const double k2 = none ? -1.0 : ((c8 && !c) ? 1.0 : 0.0);
+        const double k3 = none ? 1.0 : 0.0;
+        const double k0 = (none || (c8 && c)) ? 1.0 : -1.0;
+        return fma(k1, o1, fma(k2, o2, fma(k3, o3, k0 * o00))) + reg;
     }
     if (R < f.Fijab) {          // GAM block
         const int pq = C - f.Fijab;
