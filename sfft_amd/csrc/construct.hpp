@@ -129,25 +129,37 @@ __global__ void __launch_bounds__(256) kernel_ctab_mixed(const double* __restric
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int LT = 2 * W + 1;
     const int t = blockIdx.y / LT, a = blockIdx.y % LT - W;
+    const int Fab = L0 * L1;
+    // centre row: S_off = sum of the term's off-centre coefficients, the same for every column -- reduced once per workgroup
+    // (every thread used to sum all Fab entries itself)
+    __shared__ double so_part[4];
+    double so = 0.0;
+    if (a == 0) {                                    // (uniform: blockIdx.y)
+        const int cen = w0 * L1 + w1;
+        const double* at = sol + (size_t)t * Fab;
+        double v = 0.0;
+        for (int ab = threadIdx.x; ab < Fab; ab += 256) v += (ab != cen) ? at[ab] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0) so_part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        so = so_part[0] + so_part[1] + so_part[2] + so_part[3];
+    }
     if (m >= Nhp) return;
     cplx* dst = Ctab + ((size_t)blockIdx.y) * Nhp + m;
     if (m >= Nh || a < -w0 || a > w0) { *dst = make_double2(0.0, 0.0); return; }
-    const int Fab = L0 * L1;
     const double* arow = sol + (size_t)t * Fab + (size_t)(a + w0) * L1;
-    double cx = 0.0, cy = 0.0;
-    for (int bb = 0; bb < L1; ++bb) {
-        long long q = ((long long)m * (bb - w1)) % N1; if (q < 0) q += N1;
-        const cplx w = root1[q];
-        cx = fma(arow[bb], w.x, cx);
-        cy = fma(arow[bb], w.y, cy);
+    // sum_b arow[b] W1^(m b), b = -w1 .. w1, as  a_0 + sum_{b >= 1} (a_b W^b + a_-b conj(W^b)):  one table entry per column and a
+    // running product instead of a 64-bit modulo and a scattered table read per tap (|W| = 1: the product drifts by ~1 ulp a step)
+    const cplx w1c = root1[m];                       // m < Nh <= N1
+    double cx = arow[w1], cy = 0.0;
+    cplx wb = make_double2(1.0, 0.0);
+    for (int b = 1; b <= w1; ++b) {
+        wb = cmul(wb, w1c);
+        const double ap = arow[w1 + b], am = arow[w1 - b];
+        cx = fma(ap + am, wb.x, cx);
+        cy = fma(ap - am, wb.y, cy);
     }
-    if (a == 0) {
-        double so = 0.0;
-        const int cen = w0 * L1 + w1;
-        const double* at = sol + (size_t)t * Fab;
-        for (int ab = 0; ab < Fab; ++ab) if (ab != cen) so += at[ab];
-        cx -= so;
-    }
+    if (a == 0) cx -= so;
     *dst = make_double2(f * cx, f * cy);
 }
 
