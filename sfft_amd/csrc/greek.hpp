@@ -392,17 +392,32 @@ __global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J,
     const double* __restrict__ jr[ROWMOM_R];
 #pragma unroll
     for (int rr = 0; rr < ROWMOM_R; ++rr) jr[rr] = J + (size_t)min(l0 + rr, N0 - 1) * N1;      // (rows past the image: recomputed, not stored)
+    if ((N1 & 1) == 0 && ((reinterpret_cast<unsigned long long>(J) | reinterpret_cast<unsigned long long>(tby)) & 15ULL) == 0) {      // 16-byte loads: two columns per lane and instruction
+#pragma unroll 2
+        for (int n = 2 * tid; n < N1; n += 512) {
+            double2 t[NQ], v[ROWMOM_R];
+#pragma unroll
+            for (int rr = 0; rr < ROWMOM_R; ++rr) v[rr] = *reinterpret_cast<const double2*>(jr[rr] + n);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t[q] = *reinterpret_cast<const double2*>(tby + (size_t)min(q, nq - 1) * N1 + n);
+#pragma unroll
+            for (int rr = 0; rr < ROWMOM_R; ++rr)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[rr][q] = fma(v[rr].y, t[q].y, fma(v[rr].x, t[q].x, acc[rr][q]));
+        }
+    } else {
 #pragma unroll 4
-    for (int n = tid; n < N1; n += 256) {
-        double t[NQ], v[ROWMOM_R];
+        for (int n = tid; n < N1; n += 256) {
+            double t[NQ], v[ROWMOM_R];
 #pragma unroll
-        for (int rr = 0; rr < ROWMOM_R; ++rr) v[rr] = jr[rr][n];
+            for (int rr = 0; rr < ROWMOM_R; ++rr) v[rr] = jr[rr][n];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) t[q] = tby[(size_t)min(q, nq - 1) * N1 + n];               // q >= nq: unused copies
+            for (int q = 0; q < NQ; ++q) t[q] = tby[(size_t)min(q, nq - 1) * N1 + n];               // q >= nq: unused copies
 #pragma unroll
-        for (int rr = 0; rr < ROWMOM_R; ++rr)
+            for (int rr = 0; rr < ROWMOM_R; ++rr)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[rr][q] = fma(v[rr], t[q], acc[rr][q]);
+                for (int q = 0; q < NQ; ++q) acc[rr][q] = fma(v[rr], t[q], acc[rr][q]);
+        }
     }
     __shared__ double red[4][ROWMOM_R][NQ];
 #pragma unroll
