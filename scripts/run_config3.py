@@ -18,11 +18,15 @@ cfg = SingleSFFTConfigure.SSC(N, N, KerHW=8, KerSpType='B-Spline', KerSpDegree=2
                               SEPARATE_SCALING=True, ScaSpDegree=0, BkgSpType='Polynomial', BkgSpDegree=2, VERBOSE_LEVEL=0)
 torch.cuda.synchronize(); print("plan: Fij=%d NEQ=%d  create %.2f s" % (cfg[0]['Fij'], cfg[0]['NEQ'], time.time() - t0))
 R, S = torch.from_numpy(REF).to(dev), torch.from_numpy(SCI).to(dev)
+# masked pair: the full pair with the faint background zeroed (distinct tensors, as in a real packet), or the pair itself (argv[2] = same)
+same = len(sys.argv) > 2 and sys.argv[2] == 'same'
+keep = torch.from_numpy(base > 0.5).to(dev)
+mR, mS = (R, S) if same else (torch.where(keep, R, torch.zeros_like(R)).contiguous(), torch.where(keep, S, torch.zeros_like(S)).contiguous())
 plan = cfg[1]['plan']
 plan.set_timing(True)
 for it in range(3):
     torch.cuda.synchronize(); t0 = time.time()
-    sol, diff, _ = GeneralSFFTSubtract_PureCupy.GSS(R, S, R, S, cfg, VERBOSE_LEVEL=0)
+    sol, diff, _ = GeneralSFFTSubtract_PureCupy.GSS(R, S, mR, mS, cfg, VERBOSE_LEVEL=0)
     torch.cuda.synchronize(); dt = time.time() - t0
     print("GSS %d: %.1f ms  stages %s solver %d" % (it, dt * 1e3, {k: round(v, 1) for k, v in plan.stage_ms().items()}, plan.query("LAST_SOLVER")))
 d = diff.cpu().numpy()
