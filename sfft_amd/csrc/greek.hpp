@@ -435,6 +435,109 @@ __global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gamma block for polynomial bases, without any transform.  PreGAM[ij, pq](r, e) = SCALE^2 * sum_x I_ij(x) T_pq(x + (r, e))
+// (circular) is a sum over pixels of I times polynomial weights:
+//     sum_x0 cx(x0)^i cx((x0 + r) mod N0)^p  R_{j,q,e}[x0],     R_{j,q,e}[x0] = sum_x1 I(x0, x1) cy(x1)^j cy((x1 + e) mod N1)^q.
+// Away from the wrap, cy(x1 + e) = cy(x1) + e / N1, so R is a binomial combination of the row moments mu_d[x0] = sum_x1 I cy^d
+// (d <= DK + DB, one streaming read of I: row_moments) plus a correction from the |e| columns that wrap.  This replaces the
+// Fij * (DB + 1) column-factor passes of greek_g1 (12 of the 18 short passes at orders 2/2) and their stage-2 jobs.
+// Two small kernels: gamma_rows (one thread per image row: every R_{j,q,e} of the row) and gamma_patches (one workgroup per
+// (ij, pq, e): the sum over rows for the 2 w + 1 row lags).
+// ------------------------------------------------------------------------------------------------
+#define GAMMA_MAXW 12
+#define GAMMA_ND SFFT_MAX_BQ             // row stride of the moment table (that of row_moments)
+struct GammaArgs {
+    int Fij, Fpq, w;
+    int ki[16], kj[16];                     // kernel term ij = cx^ki cy^kj
+    int bp[SFFT_MAX_PQ], bq[SFFT_MAX_PQ];   // background term pq = cx^bp cy^bq
+};
+
+// step 1: R_{j,q,e}[x0] for every row, every (j, q) with j <= DK, q <= DB and every column lag e: Rtab[(j * NQB + q)][e + w][x0]
+__global__ void __launch_bounds__(256) gamma_rows(const double* __restrict__ I, const double* __restrict__ mu, const double* __restrict__ tby,
+                                                  int DK, int DB, int w, int N0, int N1, double* __restrict__ Rtab)
+{
+    const int x0 = blockIdx.x * 256 + threadIdx.x;
+    if (x0 >= N0) return;
+    const int PH = 2 * w + 1, NQB = DB + 1;
+    double m[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) m[d] = (d <= DK + DB) ? mu[(size_t)x0 * GAMMA_ND + d] : 0.0;
+    // the w first and w last pixels of the row: the only ones whose shifted partner can wrap
+    double lo[GAMMA_MAXW], hi[GAMMA_MAXW];
+    const double* __restrict__ row = I + (size_t)x0 * N1;
+#pragma unroll
+    for (int t = 0; t < GAMMA_MAXW; ++t) {
+        lo[t] = (t < w) ? row[min(t, N1 - 1)] : 0.0;
+        hi[t] = (t < w) ? row[max(N1 - 1 - t, 0)] : 0.0;           // hi[t] = I(x0, N1 - 1 - t)
+    }
+    {
+            const int j = (int)blockIdx.y / NQB, q = (int)blockIdx.y - j * NQB;          // grid.y = (DK + 1) (DB + 1)
+            double* __restrict__ out = Rtab + (size_t)(j * NQB + q) * PH * N0 + x0;
+            for (int e = -w; e <= w; ++e) {
+                const double de = (double)e / (double)N1;
+                double R = 0.0, bin = 1.0, dk = 1.0;
+                for (int k = 0; k <= q; ++k) {              // sum_k C(q, k) de^k mu_{j + q - k}
+                    double mv = 0.0;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) mv = (d == j + q - k) ? m[d] : mv;
+                    R = fma(bin * dk, mv, R);
+                    bin = bin * (double)(q - k) / (double)(k + 1);
+                    dk *= de;
+                }
+                const double* __restrict__ tq = tby + (size_t)q * N1;
+                const int ne = e < 0 ? -e : e;
+#pragma unroll
+                for (int t = 0; t < GAMMA_MAXW; ++t) {
+                    if (t < ne) {
+                        // e > 0: the last e columns, x1 = N1 - 1 - t, wrap to x1 + e - N1;  e < 0: the first |e| columns, x1 = t, wrap to x1 + e + N1
+                        const int x1 = e > 0 ? N1 - 1 - t : t;
+                        const int xw = e > 0 ? x1 + e - N1 : x1 + e + N1;
+                        const double cy = (double)(x1 + 1) / (double)N1;
+                        const double pix = e > 0 ? hi[t] : lo[t];
+                        R = fma(pix * ipow(cy, j), tq[xw] - ipow(cy + de, q), R);
+                    }
+                }
+                out[(size_t)(e + w) * N0] = R;
+            }
+        }
+}
+
+// step 2: patch[ij, pq](r, e) = scale * sum_x0 cx(x0)^i cx((x0 + r) mod N0)^p R_{j,q,e}[x0]; one workgroup per (ij, pq, e)
+__global__ void __launch_bounds__(256) gamma_patches(const double* __restrict__ Rtab, const double* __restrict__ kbx, const double* __restrict__ tbx,
+                                                     GammaArgs ga, int NQB, int N0, double* __restrict__ patches, double scale)
+{
+    const int ij = blockIdx.x / ga.Fpq, pq = blockIdx.x - ij * ga.Fpq;
+    const int w = ga.w, PH = 2 * w + 1;
+    const int eI = blockIdx.y;
+    const int i = ga.ki[ij], j = ga.kj[ij], pp = ga.bp[pq], q = ga.bq[pq];
+    const int tid = threadIdx.x;
+    double acc[2 * GAMMA_MAXW + 1];
+#pragma unroll
+    for (int t = 0; t <= 2 * GAMMA_MAXW; ++t) acc[t] = 0.0;
+    const double* __restrict__ R = Rtab + ((size_t)(j * NQB + q) * PH + eI) * N0;
+    const double* __restrict__ tp = tbx + (size_t)pp * N0;
+    const double* __restrict__ ki = kbx + (size_t)i * N0;
+    for (int x0 = tid; x0 < N0; x0 += 256) {
+        const double wr = ki[x0] * R[x0];
+#pragma unroll
+        for (int t = 0; t <= 2 * GAMMA_MAXW; ++t) {             // row lag r = t - w (compile-time register indices)
+            int xr = x0 + t - w; if (xr < 0) xr += N0; else if (xr >= N0) xr -= N0;
+            const double tv = (t < PH) ? tp[xr] : 0.0;
+            acc[t] = fma(wr, tv, acc[t]);
+        }
+    }
+    __shared__ double red[4][2 * GAMMA_MAXW + 1];
+#pragma unroll
+    for (int t = 0; t <= 2 * GAMMA_MAXW; ++t) {
+        double u = acc[t];
+        for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
+        if ((tid & 63) == 0) red[tid >> 6][t] = u;
+    }
+    __syncthreads();
+    if (tid < PH) patches[(size_t)(ij * ga.Fpq + pq) * PH * PH + (size_t)tid * PH + eI] = scale * (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
 __global__ void __launch_bounds__(256) delta_finish(const double* __restrict__ rowmom, double* __restrict__ delta, int N0,
                                                     BkgArgs bk, double scale)
 {

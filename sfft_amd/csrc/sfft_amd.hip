@@ -106,6 +106,8 @@ struct sfft_plan {
     std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
     std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
+    // polynomial plans: the Gamma block straight from row moments of I (gamma_patches) instead of column-factor passes
+    int gamma_analytic = 0; double* d_cyp = nullptr; double* d_rowmomI = nullptr; double* d_gamR = nullptr; GammaArgs ga;
     int n_dense_w = 0, n_row0 = 0;      // passes of half width w through greek_g1 / through greek_g1_row0
 
     int S = 1, rows_per_chunk = 0;
@@ -628,6 +630,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_HIP(hipMemcpy(p->d_phi, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     // rank-1 spectra of T_pq: FT_pq[l][m] = SCALE * Xp[p][l] * Yq[q][m]
+    p->gamma_analytic = (DK >= 0 && DB >= 0 && p->mode != 3 && KerHW <= GAMMA_MAXW && DK + DB + 1 <= 8 && !getenv("SFFT_NO_ANALYTIC_GAMMA")) ? 1 : 0;
     std::vector<char> const_x(BS.nbx, 0);
     {
         PLAN_TRY(dev_alloc(p, &p->d_Xp, (size_t)BS.nbx * N0));
@@ -675,6 +678,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         for (int a = 0; a < p->Fij; ++a) the_pass.push_back(add_pass(a, JP, 0, hG));
         p->n_the = p->Fij;
         p->n_gamp = 0; p->n_gam0 = 0;
+        if (!p->gamma_analytic)
         for (int a = 0; a < p->Fij; ++a) for (int e = 0; e < BS.nbx; ++e) if (!const_x[e]) { gam_pass[(size_t)a * BS.nbx + e] = add_pass(a, -1, e, hG); ++p->n_gamp; }
         for (int sI = 0; sI < nsca; ++sI) for (int b = 0; b < p->Fij; ++b) sk_pass.push_back(add_pass(SP(sI), b, 0, hG));
         for (int sI = 0; sI < nsca; ++sI) for (int t = sI; t < nsca; ++t) ss_pass.push_back(add_pass(SP(sI), SP(t), 0, hG));
@@ -683,6 +687,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->n_dense_w = (int)p->passes.size() - dense0;
         // column factors that are the constant 1 (Xp = N0 * delta): only spectrum row 0 contributes (greek_g1_row0)
         const int row0 = (int)p->passes.size();
+        if (!p->gamma_analytic)
         for (int a = 0; a < p->Fij; ++a) for (int e = 0; e < BS.nbx; ++e) if (const_x[e]) { gam_pass[(size_t)a * BS.nbx + e] = add_pass(a, -1, e, hG); ++p->n_gam0; }
         for (int sI = 0; sI < nsca; ++sI) for (int e = 0; e < BS.nbx; ++e) if (const_x[e]) sg_pass[(size_t)sI * BS.nbx + e] = add_pass(SP(sI), -1, e, hG);
         p->n_row0 = (int)p->passes.size() - row0;
@@ -694,8 +699,10 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->fa.omg_off = poff;
         for (int k = 0; k < p->n_omg; ++k) add_job(omg_pass[k], -1, hO, p->scale * p->scale);   // PreOMG = SCALE*Re[SCALE*DFT] (SFFTSubtract.py:233-240)
         p->fa.gam_off = poff;
-        for (int a = 0; a < p->Fij; ++a) for (int q = 0; q < p->Fpq; ++q)
-            add_job(gam_pass[(size_t)a * BS.nbx + BS.bpair[2 * q]], BS.bpair[2 * q + 1], hG, p->scale);   // PreGAM = Re[SCALE*DFT] (:262-268)
+        for (int a = 0; a < p->Fij; ++a) for (int q = 0; q < p->Fpq; ++q) {
+            if (p->gamma_analytic) poff += (2 * hG + 1) * (2 * hG + 1);       // same patch slot, filled by gamma_patches
+            else add_job(gam_pass[(size_t)a * BS.nbx + BS.bpair[2 * q]], BS.bpair[2 * q + 1], hG, p->scale);   // PreGAM = Re[SCALE*DFT] (:262-268)
+        }
         p->n_gam = p->Fij * p->Fpq;
         p->fa.the_off = poff;
         for (int a = 0; a < p->Fij; ++a) add_job(the_pass[a], -1, hG, p->scale);                  // PreTHE = Re[SCALE*DFT] (:353-362)
@@ -722,6 +729,19 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_w0tab, (size_t)N0 * p->hm));
         hipLaunchKernelGGL(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
+        if (p->gamma_analytic) {
+            const int nd = DK + DB + 1;
+            std::vector<double> cyp((size_t)nd * N1);
+            for (int d = 0; d < nd; ++d) for (int x1 = 0; x1 < N1; ++x1) cyp[(size_t)d * N1 + x1] = ipow_host((x1 + 1.0) / N1, d);
+            PLAN_TRY(dev_alloc(p, &p->d_cyp, cyp.size()));
+            PLAN_HIP(hipMemcpy(p->d_cyp, cyp.data(), cyp.size() * sizeof(double), hipMemcpyHostToDevice));
+            PLAN_TRY(dev_alloc(p, &p->d_rowmomI, (size_t)N0 * GAMMA_ND));
+            PLAN_TRY(dev_alloc(p, &p->d_gamR, (size_t)(DK + 1) * (DB + 1) * (2 * KerHW + 1) * N0));
+            memset(&p->ga, 0, sizeof(p->ga));
+            p->ga.Fij = p->Fij; p->ga.Fpq = p->Fpq; p->ga.w = KerHW;
+            for (int k = 0; k < p->Fij; ++k) { p->ga.ki[k] = p->kpair[2 * k]; p->ga.kj[k] = p->kpair[2 * k + 1]; }
+            for (int q = 0; q < p->Fpq; ++q) { p->ga.bp[q] = BS.bpair[2 * q]; p->ga.bq[q] = BS.bpair[2 * q + 1]; }
+        }
         p->fa.Fij = p->Fij; p->fa.Fpq = p->Fpq; p->fa.Fab = p->Fab; p->fa.Fijab = p->Fijab; p->fa.L1 = p->L;
         p->fa.w0 = KerHW; p->fa.w1 = KerHW; p->fa.h_omg = hO; p->fa.h_gam = hG;
         p->fa.tie_first = KerHW * p->L + KerHW; p->fa.tie_stride = p->Fab; p->fa.tie_cnt = (p->mode == 2) ? p->Fij : 0;
@@ -898,7 +918,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_cyp, p->d_rowmomI, p->d_gamR};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1444,6 +1464,15 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
         if ((rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
+        if (p->gamma_analytic) {     // Gamma block: row moments of I, then the patches (no spectra involved)
+            hipLaunchKernelGGL(row_moments<8>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp,
+                               p->DK + p->DB + 1);
+            hipLaunchKernelGGL(gamma_rows, dim3((p->N0 + 255) / 256, (p->DK + 1) * (p->DB + 1)), dim3(256), 0, s, d_I, p->d_rowmomI, p->d_tby, p->DK, p->DB, p->w, p->N0, p->N1,
+                               p->d_gamR);
+            hipLaunchKernelGGL(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, s, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, p->DB + 1,
+                               p->N0, p->d_patches + p->fa.gam_off, p->scale * p->scale);
+            LAUNCH_CHECK();
+        }
         if (p->n_row0 > 0) {
             hipLaunchKernelGGL(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_row0), dim3(256), 0, s, p->d_spec, p->d_passes,
                                p->n_omg + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->lay, p->S);
