@@ -153,6 +153,8 @@ struct sfft_plan {
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
     int vconv_rp = 2;                   // env SFFT_VCONV_RP=1: mixed-domain apply one source row at a time (KerHW <= 8 has the two-row kernel)
+    int theta_mfma = 0;                 // env SFFT_THETA_MFMA=1: Theta passes in the Omega passes' matrix-core launch (3.13 -> 3.05 ms for one pair,
+                                        // but 488 -> 463 pairs/s pipelined: the vector launch overlaps better with the other pairs' kernels)
     int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 1;                    // Omega passes on the matrix cores (greek_g1_mfma); env SFFT_G1_MFMA=0: vector kernel (A/B testing)
@@ -466,6 +468,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
+    if (const char* ev = getenv("SFFT_THETA_MFMA")) p->theta_mfma = atoi(ev);
     if (getenv("SFFT_NO_GRAPH")) p->use_graph = 0;
     if (getenv("SFFT_TEST_FAIL_CHOL")) p->test_fail_chol = 1;
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
@@ -1457,13 +1460,18 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
     }
+    bool theta_with_omega = false;
     {
         StageTimer t(p, SFFT_ST_GREEK_G1, s);
-        if ((rc = greek_g1_group(p, 0, p->n_omg, 2 * p->w, s, true))) return rc;
+        // With the Gamma block taken out of the spectra (gamma_analytic) the short passes are the Fij Theta passes alone; they read
+        // the same kernel planes as the Omega passes and can ride in the same matrix-core launch (their lags beyond w are
+        // computed and dropped) when SFFT_THETA_MFMA=1: one launch, the planes shared through L2, 0.24 ms of vector passes for 0.13 ms more here
+        theta_with_omega = p->theta_mfma && p->gamma_analytic && p->g1_mfma && 2 * p->w >= 9 && 2 * p->w <= 16 && p->n_dense_w == p->n_the;
+        if ((rc = greek_g1_group(p, 0, p->n_omg + (theta_with_omega ? p->n_dense_w : 0), 2 * p->w, s, true))) return rc;
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
-        if ((rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
+        if (!theta_with_omega && (rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
         if (p->gamma_analytic) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             hipLaunchKernelGGL(row_moments<8>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp,
                                p->DK + p->DB + 1);
