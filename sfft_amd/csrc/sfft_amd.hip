@@ -1455,7 +1455,9 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
         if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS))) return rc;
-        if (p->nby <= 4) hipLaunchKernelGGL(row_moments<4>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
+#define ROWMOM_J(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby)
+        if (p->nby == 1) ROWMOM_J(1); else if (p->nby == 2) ROWMOM_J(2); else if (p->nby == 3) ROWMOM_J(3); else if (p->nby == 4) ROWMOM_J(4);
+#undef ROWMOM_J
         else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
@@ -1473,8 +1475,13 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
         if (!theta_with_omega && (rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
         if (p->gamma_analytic) {     // Gamma block: row moments of I, then the patches (no spectra involved)
-            hipLaunchKernelGGL(row_moments<8>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp,
-                               p->DK + p->DB + 1);
+            const int nd = p->DK + p->DB + 1;
+#define ROWMOM_I(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
+            switch (nd) {           // exactly nd table values per column (a larger template bound re-reads clamped copies)
+                case 1: ROWMOM_I(1); break; case 2: ROWMOM_I(2); break; case 3: ROWMOM_I(3); break; case 4: ROWMOM_I(4); break;
+                case 5: ROWMOM_I(5); break; case 6: ROWMOM_I(6); break; default: ROWMOM_I(7); break;
+            }
+#undef ROWMOM_I
             hipLaunchKernelGGL(gamma_rows, dim3((p->N0 + 255) / 256, (p->DK + 1) * (p->DB + 1)), dim3(256), 0, s, d_I, p->d_rowmomI, p->d_tby, p->DK, p->DB, p->w, p->N0, p->N1,
                                p->d_gamR);
             hipLaunchKernelGGL(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, s, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, p->DB + 1,
