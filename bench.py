@@ -65,7 +65,7 @@ def alg_bytes(N0, N1, w, DK, DB):
         # Greek stage 1 as built: all passes of a (64-column x row-chunk) tile run on one XCD back to back, so each of the
         # Fij (+ J) planes is streamed from HBM once and re-read from that XCD's L2; partial lag sums are written
         "greek_g1": Fij * spec,
-        "greek_g1b": (Fij + 1) * spec,
+        "greek_g1b": (Fij + 1) * spec + 8 * N0 * N1,      # Theta passes: Fij planes + FJ; Gamma block: one read of the masked image
         # fp64 flops of the Omega passes: per pass and spectrum element one complex product (6) + 4 real FMAs per lag
         "greek_g1_flops": n_omg * N0 * Nh * (6 + 2 * 4 * (2 * w)),
         # apply pass as built (polynomial kernel, KerHW <= 8): row pass into DK + 1 stage planes, mixed-domain column convolution
@@ -213,7 +213,7 @@ def main():
 
         KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if N == 4096 else "cols_fwd_weighted / strided_dft",
                      "fwd_rows": "rows_r2c_4096" if N == 4096 else "rows_r2c", "greek_g1": "greek_g1_mfma<2, false> (Omega passes)",
-                     "greek_g1b": "greek_g1<8, 2> (Theta, Gamma passes)", "construct": "construct_fd"}
+                     "greek_g1b": "greek_g1<8, 2> (Theta passes) + row_moments / gamma_rows / gamma_patches (Gamma block)", "construct": "construct_fd"}
 
         def roof(stages, dom="fwd_cols"):
             ach = ab[dom] / (stages[dom] * 1e-3) / 1e9
