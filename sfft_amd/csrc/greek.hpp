@@ -449,20 +449,23 @@ __global__ void __launch_bounds__(256) row_moments(const double* __restrict__ J,
 #define GAMMA_ND SFFT_MAX_BQ             // row stride of the moment table (that of row_moments)
 struct GammaArgs {
     int Fij, Fpq, w;
-    int ki[16], kj[16];                     // kernel term ij = cx^ki cy^kj
+    int ki[64], kj[64];                     // kernel term ij = (row factor ki) x (column factor kj): exponents, or table rows
     int bp[SFFT_MAX_PQ], bq[SFFT_MAX_PQ];   // background term pq = cx^bp cy^bq
 };
 
 // step 1: R_{j,q,e}[x0] for every row, every (j, q) with j <= DK, q <= DB and every column lag e: Rtab[(j * NQB + q)][e + w][x0]
+// kby != nullptr: tabulated column factors of the kernel basis (B-spline kernels): the moments are mu_{j,d} = sum_x1 I kby[j] cy^d at
+// index j * (DB + 1) + d, and kby[j][x1] replaces cy(x1)^j in the wrap correction (the background must still be polynomial)
 __global__ void __launch_bounds__(256) gamma_rows(const double* __restrict__ I, const double* __restrict__ mu, const double* __restrict__ tby,
-                                                  int DK, int DB, int w, int N0, int N1, double* __restrict__ Rtab)
+                                                  const double* __restrict__ kby, int nmu, int DB, int w, int N0, int N1,
+                                                  double* __restrict__ Rtab)
 {
     const int x0 = blockIdx.x * 256 + threadIdx.x;
     if (x0 >= N0) return;
     const int PH = 2 * w + 1, NQB = DB + 1;
-    double m[8];
+    double m[GAMMA_ND];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) m[d] = (d <= DK + DB) ? mu[(size_t)x0 * GAMMA_ND + d] : 0.0;
+    for (int d = 0; d < GAMMA_ND; ++d) m[d] = (d < nmu) ? mu[(size_t)x0 * GAMMA_ND + d] : 0.0;
     // the w first and w last pixels of the row: the only ones whose shifted partner can wrap
     double lo[GAMMA_MAXW], hi[GAMMA_MAXW];
     const double* __restrict__ row = I + (size_t)x0 * N1;
@@ -478,9 +481,10 @@ __global__ void __launch_bounds__(256) gamma_rows(const double* __restrict__ I, 
                 const double de = (double)e / (double)N1;
                 double R = 0.0, bin = 1.0, dk = 1.0;
                 for (int k = 0; k <= q; ++k) {              // sum_k C(q, k) de^k mu_{j + q - k}
+                    const int mi = kby ? j * NQB + (q - k) : j + q - k;
                     double mv = 0.0;
 #pragma unroll
-                    for (int d = 0; d < 8; ++d) mv = (d == j + q - k) ? m[d] : mv;
+                    for (int d = 0; d < GAMMA_ND; ++d) mv = (d == mi) ? m[d] : mv;
                     R = fma(bin * dk, mv, R);
                     bin = bin * (double)(q - k) / (double)(k + 1);
                     dk *= de;
@@ -495,7 +499,8 @@ __global__ void __launch_bounds__(256) gamma_rows(const double* __restrict__ I, 
                         const int xw = e > 0 ? x1 + e - N1 : x1 + e + N1;
                         const double cy = (double)(x1 + 1) / (double)N1;
                         const double pix = e > 0 ? hi[t] : lo[t];
-                        R = fma(pix * ipow(cy, j), tq[xw] - ipow(cy + de, q), R);
+                        const double fj = kby ? kby[(size_t)j * N1 + x1] : ipow(cy, j);
+                        R = fma(pix * fj, tq[xw] - ipow(cy + de, q), R);
                     }
                 }
                 out[(size_t)(e + w) * N0] = R;

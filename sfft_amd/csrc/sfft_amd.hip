@@ -108,6 +108,7 @@ struct sfft_plan {
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
     // polynomial plans: the Gamma block straight from row moments of I (gamma_patches) instead of column-factor passes
     int gamma_analytic = 0; double* d_cyp = nullptr; double* d_rowmomI = nullptr; double* d_gamR = nullptr; GammaArgs ga;
+    int gam_tab = 0, gam_nmu = 0, gam_db = 0;   // tabulated kernel column factors; moments per row; background degree
     int n_dense_w = 0, n_row0 = 0;      // passes of half width w through greek_g1 / through greek_g1_row0
 
     int S = 1, rows_per_chunk = 0;
@@ -633,7 +634,19 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_HIP(hipMemcpy(p->d_phi, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     // rank-1 spectra of T_pq: FT_pq[l][m] = SCALE * Xp[p][l] * Yq[q][m]
-    p->gamma_analytic = (DK >= 0 && DB >= 0 && p->mode != 3 && KerHW <= GAMMA_MAXW && DK + DB + 1 <= 8 && !getenv("SFFT_NO_ANALYTIC_GAMMA")) ? 1 : 0;
+    // Gamma block in real space (gamma_rows): needs a polynomial background (its factors' shift identity); the kernel basis may be
+    // polynomial (moments of combined degree) or tabulated (one moment per (column factor, background degree))
+    int bkg_deg = DB;
+    if (bkg_deg < 0 && BS.nby <= 4 && BS.nbx <= 4) {          // tabulated plan: is the background the power basis cx^p cy^q?
+        bool poly = true;
+        for (int q = 0; q < BS.nby && poly; ++q) for (int x = 0; x < N1; ++x) if (fabs(BS.tby[(size_t)q * N1 + x] - ipow_host((x + 1.0) / N1, q)) > 1e-14) { poly = false; break; }
+        for (int e = 0; e < BS.nbx && poly; ++e) for (int x = 0; x < N0; ++x) if (fabs(BS.tbx[(size_t)e * N0 + x] - ipow_host((x + 1.0) / N0, e)) > 1e-14) { poly = false; break; }
+        if (poly) bkg_deg = BS.nby - 1;
+    }
+    const int gam_nmu = (DK >= 0) ? DK + bkg_deg + 1 : BS.nky * (bkg_deg + 1);
+    p->gamma_analytic = (bkg_deg >= 0 && p->mode != 3 && KerHW <= GAMMA_MAXW && gam_nmu <= (DK >= 0 ? 7 : GAMMA_ND) && p->Fij <= 64 &&
+                         !getenv("SFFT_NO_ANALYTIC_GAMMA")) ? 1 : 0;
+    p->gam_tab = (DK >= 0) ? 0 : 1; p->gam_nmu = gam_nmu; p->gam_db = bkg_deg;
     std::vector<char> const_x(BS.nbx, 0);
     {
         PLAN_TRY(dev_alloc(p, &p->d_Xp, (size_t)BS.nbx * N0));
@@ -733,13 +746,15 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         hipLaunchKernelGGL(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
         if (p->gamma_analytic) {
-            const int nd = DK + DB + 1;
+            // moment weights: cy^d (polynomial kernel: d = combined degree) or kby[j] cy^d (tabulated kernel: index j (DB + 1) + d)
+            const int nd = p->gam_nmu, NQB = p->gam_db + 1;
             std::vector<double> cyp((size_t)nd * N1);
-            for (int d = 0; d < nd; ++d) for (int x1 = 0; x1 < N1; ++x1) cyp[(size_t)d * N1 + x1] = ipow_host((x1 + 1.0) / N1, d);
+            for (int d = 0; d < nd; ++d) for (int x1 = 0; x1 < N1; ++x1)
+                cyp[(size_t)d * N1 + x1] = p->gam_tab ? BS.kby[(size_t)(d / NQB) * N1 + x1] * ipow_host((x1 + 1.0) / N1, d % NQB) : ipow_host((x1 + 1.0) / N1, d);
             PLAN_TRY(dev_alloc(p, &p->d_cyp, cyp.size()));
             PLAN_HIP(hipMemcpy(p->d_cyp, cyp.data(), cyp.size() * sizeof(double), hipMemcpyHostToDevice));
             PLAN_TRY(dev_alloc(p, &p->d_rowmomI, (size_t)N0 * GAMMA_ND));
-            PLAN_TRY(dev_alloc(p, &p->d_gamR, (size_t)(DK + 1) * (DB + 1) * (2 * KerHW + 1) * N0));
+            PLAN_TRY(dev_alloc(p, &p->d_gamR, (size_t)(p->gam_tab ? BS.nky : DK + 1) * NQB * (2 * KerHW + 1) * N0));
             memset(&p->ga, 0, sizeof(p->ga));
             p->ga.Fij = p->Fij; p->ga.Fpq = p->Fpq; p->ga.w = KerHW;
             for (int k = 0; k < p->Fij; ++k) { p->ga.ki[k] = p->kpair[2 * k]; p->ga.kj[k] = p->kpair[2 * k + 1]; }
@@ -1475,16 +1490,16 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
         if (!theta_with_omega && (rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
         if (p->gamma_analytic) {     // Gamma block: row moments of I, then the patches (no spectra involved)
-            const int nd = p->DK + p->DB + 1;
+            const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
 #define ROWMOM_I(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
             switch (nd) {           // exactly nd table values per column (a larger template bound re-reads clamped copies)
                 case 1: ROWMOM_I(1); break; case 2: ROWMOM_I(2); break; case 3: ROWMOM_I(3); break; case 4: ROWMOM_I(4); break;
-                case 5: ROWMOM_I(5); break; case 6: ROWMOM_I(6); break; default: ROWMOM_I(7); break;
+                case 5: ROWMOM_I(5); break; case 6: ROWMOM_I(6); break; case 7: ROWMOM_I(7); break; default: ROWMOM_I(SFFT_MAX_BQ); break;
             }
 #undef ROWMOM_I
-            hipLaunchKernelGGL(gamma_rows, dim3((p->N0 + 255) / 256, (p->DK + 1) * (p->DB + 1)), dim3(256), 0, s, d_I, p->d_rowmomI, p->d_tby, p->DK, p->DB, p->w, p->N0, p->N1,
-                               p->d_gamR);
-            hipLaunchKernelGGL(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, s, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, p->DB + 1,
+            hipLaunchKernelGGL(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, s, d_I, p->d_rowmomI, p->d_tby,
+                               p->gam_tab ? p->d_kby : (const double*)nullptr, nd, p->gam_db, p->w, p->N0, p->N1, p->d_gamR);
+            hipLaunchKernelGGL(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, s, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, NQB,
                                p->N0, p->d_patches + p->fa.gam_off, p->scale * p->scale);
             LAUNCH_CHECK();
         }
