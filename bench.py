@@ -67,7 +67,8 @@ def alg_bytes(N0, N1, w, DK, DB):
         "greek_g1": Fij * spec,
         "greek_g1b": (Fij + 1) * spec + 8 * N0 * N1,      # Theta passes: Fij planes + FJ; Gamma block: one read of the masked image
         # fp64 flops of the Omega passes: per pass and spectrum element one complex product (6) + 4 real FMAs per lag
-        "greek_g1_flops": n_omg * N0 * Nh * (6 + 2 * 4 * (2 * w)),
+        # (the Fij diagonal passes have a real product: half the lag work)
+        "greek_g1_flops": N0 * Nh * ((n_omg - Fij) * (6 + 2 * 4 * (2 * w)) + Fij * (3 + 4 * (2 * w))),
         # apply pass as built (polynomial kernel, KerHW <= 8): row pass into DK + 1 stage planes, mixed-domain column convolution
         # (reads them, writes one plane), inverse row pass with the DIFF epilogue -- no column transforms
         "prelim_apply": r * P + (DK + 1) * spec,

@@ -195,14 +195,17 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
     const unsigned r0 = min((unsigned)(lb + kq), rlast);
     unsigned rowb = r0 * rsb, twb = r0 * hmb, xb = r0 * (unsigned)sizeof(cplx);
     const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb, xb_max = rlast * (unsigned)sizeof(cplx);
-    auto run = [&](auto CF) {
+    // DG: a plane with itself (the Fij diagonal Omega passes): H = |A|^2 is real, so the two products with H.y vanish and half the
+    // MFMAs of the pass are skipped
+    auto run = [&](auto CF, auto DGt) {
         constexpr bool cf = decltype(CF)::value;
+        constexpr bool DG = decltype(DGt)::value;
         auto issue = [&](LoadSet& L) {
             L.tw = *reinterpret_cast<const cplx*>(Wb + twb);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 L.a[t] = *reinterpret_cast<const cplx*>(Ab + (cob[t] + rowb));
-                L.b[t] = cf ? *reinterpret_cast<const cplx*>(Xb + xb) : *reinterpret_cast<const cplx*>(Bb + (cob[t] + rowb));
+                if (!DG) L.b[t] = cf ? *reinterpret_cast<const cplx*>(Xb + xb) : *reinterpret_cast<const cplx*>(Bb + (cob[t] + rowb));
             }
             rowb = min(rowb + 4u * rsb, rowb_max);
             twb = min(twb + 4u * hmb, twb_max);
@@ -213,17 +216,19 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
             const double wp = (n < 8) ? wx : wy;                        // PACK: rows 0..7 of A are wx, rows 8..15 are wy
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const cplx H = cmulc(L.a[t], L.b[t]);
+                const cplx H = DG ? make_double2(fma(L.a[t].x, L.a[t].x, L.a[t].y * L.a[t].y), 0.0) : cmulc(L.a[t], L.b[t]);
                 g0x[t] = fma(H.x, vf, g0x[t]);
-                g0y[t] = fma(H.y, vf, g0y[t]);
+                if (!DG) g0y[t] = fma(H.y, vf, g0y[t]);
                 if (PACK) {
                     Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.x, Sx[t][0], 0, 0, 0);      // S1 | S3
                     Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.y, Sx[t][1], 0, 0, 0);      // S4 | S2
                 } else {
                     Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.x, Sx[t][0], 0, 0, 0);      // S1
-                    Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);      // S2
                     Sx[t][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.x, Sx[t][2], 0, 0, 0);      // S3
-                    Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);      // S4
+                    if (!DG) {
+                        Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);  // S2
+                        Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);  // S4
+                    }
                 }
             }
         };
@@ -238,7 +243,10 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
             compute(L1, (l + 4 + kq < le) ? 1.0 : 0.0);      // (a step past the chunk runs on zero weights)
         }
     };
-    if (colfac) run(std::true_type{}); else run(std::false_type{});
+    const bool diag = !colfac && !PACK && pr.b_plane == pr.a_plane;
+    if (colfac) run(std::true_type{}, std::false_type{});
+    else if (diag) run(std::false_type{}, std::true_type{});
+    else run(std::false_type{}, std::false_type{});
     cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
