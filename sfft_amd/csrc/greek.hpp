@@ -17,6 +17,8 @@ struct G1Pass {
     int bp;
     int h;            // lag half width
     long long gp_off; // offset (cplx) of this pass's [S][2h+1][Nhp] partial buffer
+    long long gp_off2;// dual diagonal pass (b_plane >= 0, dual = 1): partial buffer of the second plane's self-product
+    int dual;         // 1: this pass is |A|^2 and |B|^2 side by side (two diagonal Omega passes in one wave)
 };
 
 struct PatchJob {
@@ -195,8 +197,10 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
     const unsigned r0 = min((unsigned)(lb + kq), rlast);
     unsigned rowb = r0 * rsb, twb = r0 * hmb, xb = r0 * (unsigned)sizeof(cplx);
     const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb, xb_max = rlast * (unsigned)sizeof(cplx);
-    // DG: a plane with itself (the Fij diagonal Omega passes): H = |A|^2 is real, so the two products with H.y vanish and half the
-    // MFMAs of the pass are skipped
+    // DG: two diagonal Omega passes side by side (plane A with itself, plane B with itself).  Their products |A|^2, |B|^2 are real,
+    // so each needs only two of the four sums: one wave does both with the loads and MFMAs of one ordinary pass -- and walks the
+    // rows at the pace of the ordinary passes, which the L2 sharing of a tile depends on (single diagonal passes at half the
+    // MFMAs ran ahead of the others and doubled the kernel's HBM traffic)
     auto run = [&](auto CF, auto DGt) {
         constexpr bool cf = decltype(CF)::value;
         constexpr bool DG = decltype(DGt)::value;
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 L.a[t] = *reinterpret_cast<const cplx*>(Ab + (cob[t] + rowb));
-                if (!DG) L.b[t] = cf ? *reinterpret_cast<const cplx*>(Xb + xb) : *reinterpret_cast<const cplx*>(Bb + (cob[t] + rowb));
+                L.b[t] = cf ? *reinterpret_cast<const cplx*>(Xb + xb) : *reinterpret_cast<const cplx*>(Bb + (cob[t] + rowb));
             }
             rowb = min(rowb + 4u * rsb, rowb_max);
             twb = min(twb + 4u * hmb, twb_max);
@@ -216,19 +220,19 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
             const double wp = (n < 8) ? wx : wy;                        // PACK: rows 0..7 of A are wx, rows 8..15 are wy
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const cplx H = DG ? make_double2(fma(L.a[t].x, L.a[t].x, L.a[t].y * L.a[t].y), 0.0) : cmulc(L.a[t], L.b[t]);
+                // DG: H.x = |a|^2, H.y = |b|^2 (two real products; g0x / g0y are their lag-0 sums)
+                const cplx H = DG ? make_double2(fma(L.a[t].x, L.a[t].x, L.a[t].y * L.a[t].y), fma(L.b[t].x, L.b[t].x, L.b[t].y * L.b[t].y))
+                                  : cmulc(L.a[t], L.b[t]);
                 g0x[t] = fma(H.x, vf, g0x[t]);
-                if (!DG) g0y[t] = fma(H.y, vf, g0y[t]);
+                g0y[t] = fma(H.y, vf, g0y[t]);
                 if (PACK) {
                     Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.x, Sx[t][0], 0, 0, 0);      // S1 | S3
                     Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.y, Sx[t][1], 0, 0, 0);      // S4 | S2
                 } else {
-                    Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.x, Sx[t][0], 0, 0, 0);      // S1
-                    Sx[t][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.x, Sx[t][2], 0, 0, 0);      // S3
-                    if (!DG) {
-                        Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);  // S2
-                        Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);  // S4
-                    }
+                    Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.x, Sx[t][0], 0, 0, 0);      // S1            (DG: S1 of |A|^2)
+                    Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);      // S2            (DG: S3 of |B|^2)
+                    Sx[t][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.x, Sx[t][2], 0, 0, 0);      // S3            (DG: S3 of |A|^2)
+                    Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);      // S4            (DG: S1 of |B|^2)
                 }
             }
         };
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
             compute(L1, (l + 4 + kq < le) ? 1.0 : 0.0);      // (a step past the chunk runs on zero weights)
         }
     };
-    const bool diag = !colfac && !PACK && pr.b_plane == pr.a_plane;
+    const bool diag = !colfac && !PACK && pr.dual;
     if (colfac) run(std::true_type{}, std::false_type{});
     else if (diag) run(std::false_type{}, std::true_type{});
     else run(std::false_type{}, std::false_type{});
@@ -255,6 +259,21 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
         sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
         const int m = m0 + 16 * t + n;
         if (!act[t]) continue;
+        if (diag) {     // two real, even sequences: G(+-r) = S1 +- i S3 for |A|^2 (Sx[0], Sx[2]) and for |B|^2 (Sx[3], Sx[1])
+            cplx* g2 = Gp + pr.gp_off2 + (size_t)chunk * PH * Nhp;
+            if (kq == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = kq + 4 * q + 1;
+                if (r <= h) {
+                    g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[t][0][q], Sx[t][2][q]);
+                    g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[t][0][q], -Sx[t][2][q]);
+                    g2[(size_t)(h + r) * Nhp + m] = make_double2(Sx[t][3][q], Sx[t][1][q]);
+                    g2[(size_t)(h - r) * Nhp + m] = make_double2(Sx[t][3][q], -Sx[t][1][q]);
+                }
+            }
+            continue;
+        }
         if (kq == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
 #pragma unroll
         for (int q = 0; q < (PACK ? 2 : 4); ++q) {

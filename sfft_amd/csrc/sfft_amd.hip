@@ -106,6 +106,7 @@ struct sfft_plan {
     std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
     std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
+    int n_omg_launch = 0;               // Omega pass records that are launched (the rest are partners of dual diagonal passes)
     // polynomial plans: the Gamma block straight from row moments of I (gamma_patches) instead of column-factor passes
     int gamma_analytic = 0; double* d_cyp = nullptr; double* d_rowmomI = nullptr; double* d_gamR = nullptr; GammaArgs ga;
     int gam_tab = 0, gam_nmu = 0, gam_db = 0;   // tabulated kernel column factors; moments per row; background degree
@@ -681,13 +682,33 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->rows_per_chunk = (N0 + S - 1) / S;
         long long goff = 0;
         auto add_pass = [&](int a, int b, int bp, int h) {
-            G1Pass d; d.a_plane = a; d.b_plane = b; d.bp = bp; d.h = h; d.gp_off = goff;
+            G1Pass d; d.a_plane = a; d.b_plane = b; d.bp = bp; d.h = h; d.gp_off = goff; d.gp_off2 = 0; d.dual = 0;
             p->passes.push_back(d); goff += (long long)S * (2 * h + 1) * p->Nhp;
             return (int)p->passes.size() - 1;
         };
         std::vector<int> omg_pass, the_pass, gam_pass((size_t)p->Fij * BS.nbx);
         std::vector<int> sk_pass, ss_pass, st_pass, sg_pass((size_t)nsca * BS.nbx);
-        for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) omg_pass.push_back(add_pass(a, b, 0, hO));
+        // Omega passes.  On the matrix-core path the diagonal passes (a, a) go in pairs: one "dual" pass carries |A_a|^2 and |A_b|^2
+        // (greek_g1_mfma, DG) and the partner's record only owns its partial buffer; partner records sit behind the launched ones.
+        const bool dual_diag = p->g1_mfma && hO >= 9 && hO <= 16 && p->Fij >= 2 && !getenv("SFFT_NO_DUAL_DIAG");
+        omg_pass.assign((size_t)p->Fij * (p->Fij + 1) / 2, -1);
+        auto okey = [&](int a, int b) { return a * p->Fij - (a * (a - 1)) / 2 + (b - a); };      // (a <= b) -> k, the job / patch order
+        std::vector<std::pair<int, int>> partners;     // (leader pass, partner plane)
+        for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) {
+            if (a != b || !dual_diag) { omg_pass[okey(a, b)] = add_pass(a, b, 0, hO); continue; }
+            if (a % 2 == 0 && a + 1 < p->Fij) {          // leader of the pair (a, a + 1)
+                const int lead = add_pass(a, a + 1, 0, hO);
+                p->passes[lead].dual = 1;
+                omg_pass[okey(a, a)] = lead;
+                partners.push_back({lead, a + 1});
+            } else if (a % 2 == 0) omg_pass[okey(a, a)] = add_pass(a, a, 0, hO);      // odd Fij: the last diagonal stays an ordinary pass
+        }
+        p->n_omg_launch = (int)p->passes.size();
+        for (auto& pr : partners) {
+            const int rec = add_pass(pr.second, pr.second, 0, hO);
+            p->passes[pr.first].gp_off2 = p->passes[rec].gp_off;
+            omg_pass[okey(pr.second, pr.second)] = rec;
+        }
         p->n_omg = (int)omg_pass.size();
         // passes of half width w through greek_g1: Theta, dense Gamma column factors, then the scaling planes' passes
         const int dense0 = (int)p->passes.size();
@@ -1483,8 +1504,9 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         // With the Gamma block taken out of the spectra (gamma_analytic) the short passes are the Fij Theta passes alone; they read
         // the same kernel planes as the Omega passes and can ride in the same matrix-core launch (their lags beyond w are
         // computed and dropped) when SFFT_THETA_MFMA=1: one launch, the planes shared through L2, 0.24 ms of vector passes for 0.13 ms more here
-        theta_with_omega = p->theta_mfma && p->gamma_analytic && p->g1_mfma && 2 * p->w >= 9 && 2 * p->w <= 16 && p->n_dense_w == p->n_the;
-        if ((rc = greek_g1_group(p, 0, p->n_omg + (theta_with_omega ? p->n_dense_w : 0), 2 * p->w, s, true))) return rc;
+        theta_with_omega = p->theta_mfma && p->gamma_analytic && p->g1_mfma && 2 * p->w >= 9 && 2 * p->w <= 16 && p->n_dense_w == p->n_the &&
+                           p->n_omg_launch == p->n_omg;
+        if ((rc = greek_g1_group(p, 0, theta_with_omega ? p->n_omg + p->n_dense_w : p->n_omg_launch, 2 * p->w, s, true))) return rc;
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
