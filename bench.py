@@ -228,7 +228,9 @@ def main():
             return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_flops"],
                     "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
-                    "note": "v_mfma_f64_16x16x4_f64 (the fp64 matrix and vector peaks are equal on MI355X); HBM side: "
+                    "sustained_peak_measured": 47.4,     # profiles/r01_mfma_f64_peak.txt: a loop of independent MFMAs, TFLOP/s
+                    "note": "v_mfma_f64_16x16x4_f64 (the fp64 matrix and vector peaks are equal on MI355X); a loop of nothing but independent "
+                            "MFMAs sustains 47.4 TFLOP/s on this device (scripts/micro/mfma_f64_peak.hip); HBM side: "
                             "%.0f GB/s of algorithmic bytes" % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
         out = {
             "metric": "image-pairs/sec, %dx%d, KerHW=%d polyOrd=%d" % (N, N, args.kerhw, args.dk),
