@@ -220,6 +220,7 @@ def main():
             ach = ab[dom] / (stages[dom] * 1e-3) / 1e9
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if (N, args.kerhw, args.dk, args.db) == (4096, 8, 2, 2) else None
             return {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "sustained_peak_measured": 5000.0,   # profiles/r01_hbm_stream.txt: a plain copy kernel on this device, GB/s
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": stages[dom]}
 
         def roof_flops(stages):
