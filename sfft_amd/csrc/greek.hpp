@@ -133,11 +133,13 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
 // scalar-register bottleneck), and the 64 accumulators per lane of the vector version become 16 four-vectors.
 typedef double d4v __attribute__((ext_vector_type(4)));
 
-// NT = 16-column tiles per wave (2: 110 registers, four waves per SIMD, measured best; 4: two waves per SIMD).
+// NT = 16-column tiles per wave (2: 142 registers with the two load sets of the pipelined loop, three waves per SIMD, measured
+// best; 1 and 4 are slower).
 // PACK (h <= 8): the 16 rows of A hold wx of lags 1..8 and then wy of lags 1..8, so two MFMAs per tile give all four sums
-// (A Hx -> S1 in rows 0..7, S3 in rows 8..15; A Hy -> S4, S2); correct, but those short passes are not FMA bound and the
-// vector kernel is as fast, so the host does not use it.  B of a pass may be a column factor (Gamma passes): H = A conj(Xp[l]).
-// Measured at 4096^2, KerHW 8 (21 Omega passes, 23.6 GFLOP): 0.53 ms = 45 TFLOP/s, against 0.65 ms for the vector kernel.
+// (A Hx -> S1 in rows 0..7, S3 in rows 8..15; A Hy -> S4, S2); correct, but measured no faster than the vector kernel for the
+// short passes, so the host does not use it.  B of a pass may be a column factor (Gamma passes of plans that keep them).
+// Measured at 4096^2, KerHW 8 (15 ordinary + 3 dual diagonal Omega passes, 9.58 M MFMAs): 0.45 ms = 44 - 47 TFLOP/s, which is what a
+// loop of nothing but this instruction sustains on the device (scripts/micro/mfma_f64_peak.hip); the vector kernel: 0.65 ms.
 template <int NT, bool PACK>
 __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
                                                                        cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
