@@ -15,6 +15,8 @@ host like the reference does and handed to `sfft_plan_set_regularization`; the d
 import os.path as pa
 import time
 
+import threading
+
 import numpy as np
 import torch
 
@@ -112,6 +114,7 @@ def _axis_tables(N0, N1, SpType, Degree, IntKnotX, IntKnotY):
 
 
 _PLANS = {}
+_PLANS_LOCK = threading.Lock()
 
 
 class SingleSFFTConfigure:
@@ -182,23 +185,26 @@ class SingleSFFTConfigure:
         key = (device, N0, N1, w0, KerSpType, DK, tuple(KerIntKnotX), tuple(KerIntKnotY), BkgSpType, DB,
                tuple(BkgIntKnotX), tuple(BkgIntKnotY), mode,
                (ScaSpType, DS, tuple(ScaIntKnotX), tuple(ScaIntKnotY)) if mode == 3 else None)
-        plan = _PLANS.get(key)
-        if plan is None:
-            if VERBOSE_LEVEL in [1, 2]:
-                print('\n --//--//--//--//-- TRIGGER SFFT COMPILATION [HIP] --//--//--//--//-- ')
-            bdict = dict(kbx=kbx, kby=kby, ker_pairs=kpairs, tbx=tbx, tby=tby, bkg_pairs=bpairs, scaling_mode=mode)
-            if mode == 3:
-                bdict.update(sbx=sbx, sby=sby, sca_pairs=spairs)
-            plan = Plan(N0, N1, w0, device=device, basis=bdict)
-            if len(_PLANS) >= 3:
-                _PLANS.pop(next(iter(_PLANS)))
-            _PLANS[key] = plan
+        with _PLANS_LOCK:
+            plan = _PLANS.get(key)
+            if plan is None:
+                if VERBOSE_LEVEL in [1, 2]:
+                    print('\n --//--//--//--//-- TRIGGER SFFT COMPILATION [HIP] --//--//--//--//-- ')
+                bdict = dict(kbx=kbx, kby=kby, ker_pairs=kpairs, tbx=tbx, tby=tby, bkg_pairs=bpairs, scaling_mode=mode)
+                if mode == 3:
+                    bdict.update(sbx=sbx, sby=sby, sca_pairs=spairs)
+                plan = Plan(N0, N1, w0, device=device, basis=bdict)
+                if len(_PLANS) >= 3:
+                    _PLANS.pop(next(iter(_PLANS)))
+                _PLANS[key] = plan
 
         L0 = L1 = 2 * w0 + 1
         Fab = L0 * L1
         Fij, Fpq = len(kpairs), len(bpairs)
 
-        # kernel regularisation: the plan is shared by later calls, so it is (re)set on every SSC
+        # kernel regularisation belongs to THIS config, not to the plan (plans are shared between configs of one geometry):
+        # the small matrices are kept in the module dictionary and put on the plan right before every solve made through
+        # this config (sfftcore.SFFTSubtract._bound_plan), as the reference derives them per config at ESS time
         if REGULARIZE_KERNEL:
             NREG = XY_REGULARIZE.shape[0]
             CX_REG, CY_REG = XY_REGULARIZE[:, 0] / N0, XY_REGULARIZE[:, 1] / N1
@@ -215,9 +221,9 @@ class SingleSFFTConfigure:
                     ScaSPMAT = np.concatenate((ScaSPMAT, np.zeros((Fij - ScaSPMAT.shape[0], NREG))), axis=0)
                 CSST = (SPMAT * WS) @ ScaSPMAT.T
                 DSST = (ScaSPMAT * WS) @ ScaSPMAT.T
-            plan.set_regularization(float(LAMBDA_REGULARIZE), _laplacian_iregmat(w0, w0, IGNORE_LAPLACIAN_KERCENT), SST, CSST, DSST)
+            regularization = (float(LAMBDA_REGULARIZE), _laplacian_iregmat(w0, w0, IGNORE_LAPLACIAN_KERCENT), SST, CSST, DSST)
         else:
-            plan.set_regularization(0.0)
+            regularization = (0.0,)
         P = {}
         P['KerHW'], P['KerSpType'], P['KerSpDegree'] = KerHW, KerSpType, KerSpDegree
         P['KerIntKnotX'], P['KerIntKnotY'] = KerIntKnotX, KerIntKnotY
@@ -247,7 +253,7 @@ class SingleSFFTConfigure:
             P['ScaFij'] = len(spairs)
             P['NEQt'] = P['NEQ'] - (Fij - P['ScaFij'])
         P['ConstPhotRatio'] = mode in (1, 2)
-        return (P, {'plan': plan, 'backend': 'HIP'})
+        return (P, {'plan': plan, 'backend': 'HIP', 'regularization': regularization})
 
 
 class BSpline_Packet:

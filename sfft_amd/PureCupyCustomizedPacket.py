@@ -16,8 +16,10 @@ __all__ = ["PureCupy_Customized_Packet"]
 
 
 def _t(x, dev):
+    """Everything the packet computes (NaN mask, role swap, DIFF) lives on CUDA_DEVICE_4SUBTRACT: inputs on another
+    device, or on the host, are moved there first."""
     if isinstance(x, torch.Tensor):
-        return x
+        return x if x.device == dev else x.to(dev)
     return torch.as_tensor(x, device=dev)
 
 

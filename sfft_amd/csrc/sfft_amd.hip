@@ -42,6 +42,32 @@ static int set_err(int code, const std::string& msg) { g_last_error = msg; retur
         }                                                                                         \
     } while (0)
 
+// Every entry point runs on the plan's device and leaves the calling thread's current device as it found it (a host thread that
+// drives several GPUs, or torch code that reads the current device afterwards, must not see it change behind its back).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == dev) prev = -1;
+        else ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(dev)                                                                            \
+    DeviceGuard device_guard_(dev);                                                               \
+    if (!device_guard_.ok) return set_err(SFFT_ERR_HIP, "hipSetDevice failed")
+// the stateless helpers take no plan: they run on the device their stream belongs to (the current device for the null stream)
+static int stream_device(hipStream_t s)
+{
+    int dev = 0;
+    if (s) { hipDevice_t d; if (hipStreamGetDevice(s, &d) == hipSuccess) return (int)d; }
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return dev;
+}
+
 extern "C" const char* sfft_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 
@@ -463,7 +489,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (KerHW < 0 || KerHW > 32) return set_err(SFFT_ERR_INVALID_ARG, "KerHW must be in [0, 32]");
     if (BS.Fij < 1 || BS.Fij > 64 || BS.Fpq < 1 || BS.Fpq > SFFT_MAX_PQ || BS.nby > SFFT_MAX_BQ || BS.nbx > 16 || BS.nkx > 16 || BS.nky > 16)
         return set_err(SFFT_ERR_INVALID_ARG, "spatial basis too large: at most 64 kernel terms, 64 background terms, 16 factors per axis");
-    HIPCHK(hipSetDevice(device));
+    ON_DEVICE(device);
     sfft_plan* p = new sfft_plan();
     p->dev = device;
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
@@ -918,7 +944,7 @@ extern "C" int sfft_plan_set_regularization(sfft_plan* p, double lambda, const d
                                             const double* csst, const double* dsst)
 {
     if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan");
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     if (lambda == 0.0 || !ireg) { p->fa.reg_coef = 0.0; return SFFT_OK; }
     if (!sst) return set_err(SFFT_ERR_INVALID_ARG, "NULL SSTMAT");
     if (p->mode == 3 && (!csst || !dsst)) return set_err(SFFT_ERR_INVALID_ARG, "separately varying scaling needs CSSTMAT and DSSTMAT");
@@ -953,7 +979,7 @@ static void free_axis(AxisHost& a)
 extern "C" int sfft_plan_destroy(sfft_plan* p)
 {
     if (!p) return SFFT_OK;
-    hipSetDevice(p->dev);
+    DeviceGuard device_guard_(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
@@ -1486,7 +1512,7 @@ static int solve_check(sfft_plan* p, double* d_solution, hipStream_t s, bool* re
 // status check (solve_check, after a sync) to the caller -- sfft_subtract syncs once, at the end of the pair.
 static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double* d_solution, hipStream_t s, bool defer_check)
 {
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     int rc;
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
@@ -1656,7 +1682,7 @@ extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, co
 {
     if (!p || !d_I || !d_J || !d_solution || !d_diff) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     int rc;
     if ((rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
     return apply_finish(p, p->use_vconv ? p->d_stage_a : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s);
@@ -1670,7 +1696,7 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
 {
     if (!p || !d_I || !d_J || !d_mI || !d_mJ || !d_solution || !d_diff) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     int rc;
     if (p->no_overlap) {
         if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
@@ -1721,7 +1747,7 @@ extern "C" int sfft_get_system(sfft_plan* p, double* d_LHMAT, double* d_RHb, voi
     if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan");
     if (!p->have_system) return set_err(SFFT_ERR_INVALID_ARG, "no linear system yet: call sfft_solve first");
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     dim3 g((p->NEQ + 15) / 16, (p->NEQ + 15) / 16);
     hipLaunchKernelGGL(fill_plain, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->NEQ, d_LHMAT, d_RHb);
     LAUNCH_CHECK();
@@ -1740,7 +1766,7 @@ extern "C" int sfft_fft2_r2c(sfft_plan* p, const double* d_real, double* d_spec,
 {
     if (!p || !d_real || !d_spec) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     RowsArgs ra;
     for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.wx[k] = nullptr; ra.wy[k] = nullptr; }
     ra.src[0] = d_real;
@@ -1758,7 +1784,7 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
 {
     if (!p || !d_real || !d_spec) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     int rc;
     if (!p->d_zero) {
         if ((rc = dev_alloc(p, &p->d_zero, (size_t)p->N0 * p->N1))) return rc;
@@ -1794,6 +1820,7 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
 extern "C" int sfft_spec_abs2_accumulate(const double* d_a, const double* d_b, double coeff, double* d_acc, long long n, void* stream)
 {
     if (!d_a || !d_acc || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    ON_DEVICE(stream_device((hipStream_t)stream));
     hipLaunchKernelGGL(spec_abs2_acc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a, (const cplx*)d_b,
                        coeff, d_acc, (size_t)n);
     LAUNCH_CHECK();
@@ -1804,6 +1831,7 @@ extern "C" int sfft_spec_abs2_accumulate(const double* d_a, const double* d_b, d
 extern "C" int sfft_real_rsqrt(const double* d_acc, double* d_out, long long n, void* stream)
 {
     if (!d_acc || !d_out || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    ON_DEVICE(stream_device((hipStream_t)stream));
     hipLaunchKernelGGL(real_rsqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_acc, d_out, (size_t)n);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -1813,6 +1841,7 @@ extern "C" int sfft_real_rsqrt(const double* d_acc, double* d_out, long long n, 
 extern "C" int sfft_spec_multiply(const double* d_a, const double* d_b, int b_is_real, double* d_out, long long n, void* stream)
 {
     if (!d_a || !d_b || !d_out || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    ON_DEVICE(stream_device((hipStream_t)stream));
     hipLaunchKernelGGL(spec_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a,
                        b_is_real ? (const cplx*)nullptr : (const cplx*)d_b, b_is_real ? d_b : (const double*)nullptr, (cplx*)d_out, (size_t)n);
     LAUNCH_CHECK();
@@ -1823,6 +1852,7 @@ extern "C" int sfft_spec_multiply(const double* d_a, const double* d_b, int b_is
 extern "C" int sfft_half_to_full_real(const double* d_half, double* d_full, int N0, int N1, void* stream)
 {
     if (!d_half || !d_full) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    ON_DEVICE(stream_device((hipStream_t)stream));
     hipLaunchKernelGGL(half_to_full_real, dim3((N1 + 255) / 256, N0), dim3(256), 0, (hipStream_t)stream, d_half, d_full, N0, N1, N1 / 2 + 1);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -1836,7 +1866,7 @@ extern "C" int sfft_grid_convolve(const double* d_in, const int* d_labels, const
     if (N0 < 1 || N1 < 1 || Nseg < 1 || L0 < 1 || L1 < 1) return set_err(SFFT_ERR_INVALID_ARG, "bad size");
     const size_t lds = (size_t)(16 + L0 - 1) * (16 + L1 - 1) * sizeof(double);
     if (lds > 150 * 1024) return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "kernel stamp too large for the on-chip tile of this build");
-    HIPCHK(hipSetDevice(device));
+    ON_DEVICE(device);
     HIPCHK(hipFuncSetAttribute((const void*)grid_convolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(grid_convolve, dim3((N1 + 15) / 16, (N0 + 15) / 16), dim3(256), lds, (hipStream_t)stream, d_in, d_labels, d_kerstack,
                        N0, N1, Nseg, L0, L1, d_out);
@@ -1849,7 +1879,7 @@ extern "C" int sfft_dbg_forward_spectrum(sfft_plan* p, const double* d_I, int i,
     if (!p || !d_I || !d_spec_out) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
     if (i < 0 || j < 0 || i >= p->nkx || j >= p->nky) return set_err(SFFT_ERR_INVALID_ARG, "basis factor index out of range for this plan");
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(p->dev));
+    ON_DEVICE(p->dev);
     RowsArgs ra;
     for (int k = 0; k < SFFT_MAX_PLANES; ++k) { ra.src[k] = nullptr; ra.wx[k] = nullptr; ra.wy[k] = nullptr; }
     ra.src[0] = d_I; ra.wx[0] = p->d_kbx + (size_t)i * p->N0; ra.wy[0] = p->d_kby + (size_t)j * p->N1;

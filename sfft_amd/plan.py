@@ -1,10 +1,23 @@
 """Plan handle: Python owner of one `sfft_plan` (the cacheable replacement of SingleSFFTConfigure's JIT step)."""
 import collections
 import ctypes
+import functools
+import threading
 
 import torch
 
 from . import _lib
+
+
+def _locked(fn):
+    """A plan owns one set of workspaces, a second stream and one pinned status word: one call at a time.  Host threads that
+    share a Plan object (same geometry through the plan cache) are serialised here; threads that want pairs in flight
+    concurrently take plans of their own (`get_plan(..., slot=k)`)."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self.lock:
+            return fn(self, *a, **k)
+    return wrapper
 
 
 class Plan:
@@ -16,6 +29,8 @@ class Plan:
         (sfft_plan_create_varscale; scaling_mode is ignored)."""
         self._h = ctypes.c_void_p()
         self.device = int(device)
+        self.lock = threading.RLock()
+        self._reg_token = None          # which SFFTConfig's regularisation the plan currently carries (BSplineSFFT.SSC)
         if basis is None:
             rc = _lib.lib().sfft_plan_create(ctypes.byref(self._h), int(N0), int(N1), int(KerHW), int(DK), int(DB),
                                              1 if ConstPhotRatio else 0, int(device))
@@ -68,12 +83,14 @@ class Plan:
                             % (name, self.N0, self.N1, self.device))
 
     # -- C ABI calls ---------------------------------------------------------------------------
+    @_locked
     def solve(self, I, J):
         self._check_img(I, "PixA_I"); self._check_img(J, "PixA_J")
         sol = torch.empty(self.NEQ, dtype=torch.float64, device=self._dev())
         _lib.check(_lib.lib().sfft_solve(self._h, I.data_ptr(), J.data_ptr(), sol.data_ptr(), self._stream_ptr(self._dev())))
         return sol
 
+    @_locked
     def apply(self, I, J, solution):
         self._check_img(I, "PixA_I"); self._check_img(J, "PixA_J")
         sol = solution.to(device=self._dev(), dtype=torch.float64).contiguous()
@@ -84,6 +101,7 @@ class Plan:
                                          self._stream_ptr(self._dev())))
         return diff
 
+    @_locked
     def subtract(self, I, J, mI, mJ, out_solution=None, out_diff=None):
         for t, n in ((I, "PixA_I"), (J, "PixA_J"), (mI, "PixA_mI"), (mJ, "PixA_mJ")):
             self._check_img(t, n)
@@ -93,12 +111,14 @@ class Plan:
                                             sol.data_ptr(), diff.data_ptr(), self._stream_ptr(self._dev())))
         return sol, diff
 
+    @_locked
     def get_system(self):
         LH = torch.empty((self.NEQ, self.NEQ), dtype=torch.float64, device=self._dev())
         rhs = torch.empty(self.NEQ, dtype=torch.float64, device=self._dev())
         _lib.check(_lib.lib().sfft_get_system(self._h, LH.data_ptr(), rhs.data_ptr(), self._stream_ptr(self._dev())))
         return LH, rhs
 
+    @_locked
     def forward_spectrum(self, I, i, j):
         self._check_img(I, "PixA_I")
         out = torch.empty((self.N0, self.N1 // 2 + 1), dtype=torch.complex128, device=self._dev())
@@ -106,6 +126,7 @@ class Plan:
                                                         self._stream_ptr(self._dev())))
         return out
 
+    @_locked
     def set_regularization(self, lam, ireg=None, sst=None, csst=None, dsst=None):
         """LHMAT += lam * SCALE^2 * S (x) ireg on every later solve (sfft_plan_set_regularization); lam = 0 switches it off."""
         import numpy as np
@@ -120,6 +141,7 @@ class Plan:
     def set_force_lu(self, enable=True):
         _lib.check(_lib.lib().sfft_set_force_lu(self._h, 1 if enable else 0))
 
+    @_locked
     def stage_ms(self):
         out = {}
         for k, name in enumerate(_lib.STAGES):
@@ -129,9 +151,10 @@ class Plan:
         return out
 
     def close(self):
-        if self._h:
-            _lib.lib().sfft_plan_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        with self.lock:
+            if self._h:
+                _lib.lib().sfft_plan_destroy(self._h)
+                self._h = ctypes.c_void_p()
 
     def __del__(self):
         try:
@@ -142,6 +165,7 @@ class Plan:
 
 _CACHE = collections.OrderedDict()
 _CACHE_MAX = 6
+_CACHE_LOCK = threading.Lock()
 
 
 def get_plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device=0, slot=0):
@@ -150,18 +174,20 @@ def get_plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device=0, slot=0):
     `slot` distinguishes independent plans of the same geometry (one per host thread / stream when several pairs
     are pipelined on one GPU)."""
     key = (int(device), int(N0), int(N1), int(KerHW), int(DK), int(DB), bool(ConstPhotRatio), int(slot))
-    p = _CACHE.get(key)
-    if p is not None:
-        _CACHE.move_to_end(key)
+    with _CACHE_LOCK:
+        p = _CACHE.get(key)
+        if p is not None:
+            _CACHE.move_to_end(key)
+            return p
+        p = Plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device)
+        _CACHE[key] = p
+        while len(_CACHE) > _CACHE_MAX:
+            _CACHE.popitem(last=False)      # freed when the last SFFTConfig holding it goes away
         return p
-    p = Plan(N0, N1, KerHW, DK, DB, ConstPhotRatio, device)
-    _CACHE[key] = p
-    while len(_CACHE) > _CACHE_MAX:
-        _CACHE.popitem(last=False)      # freed when the last SFFTConfig holding it goes away
-    return p
 
 
 def clear_plan_cache():
-    while _CACHE:
-        _, old = _CACHE.popitem()
-        old.close()
+    """Drop the cache's references.  A plan is destroyed (Plan.__del__) once the last SFFTConfig that holds it is gone, so
+    configs made before the call stay usable."""
+    with _CACHE_LOCK:
+        _CACHE.clear()

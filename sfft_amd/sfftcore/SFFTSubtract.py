@@ -3,6 +3,7 @@
 All numerics run in libsfft_amd.so; these classes only move data, check shapes with the reference's
 error texts, and sequence solve/apply like the reference's two-pass GSS.
 """
+import contextlib
 import time
 
 import numpy as np
@@ -16,6 +17,22 @@ def _plan(SFFTConfig):
         return SFFTConfig[1]['plan']
     except Exception:
         raise Exception('MeLOn ERROR: SFFTConfig was not produced by sfft_amd SingleSFFTConfigure.SSC')
+
+
+@contextlib.contextmanager
+def _bound_plan(SFFTConfig):
+    """The config's plan, held for the duration of one ESS / GSS.  Plans are shared between configs of the same geometry
+    (plan cache), so what belongs to the *config* -- the kernel-regularisation term of BSplineSFFT.SSC, which the reference
+    derives from each config's own SFFTParam_dict at ESS time (BSplineSFFT.py:3293-3330) -- is put on the plan here, under
+    the plan's lock, before anything is solved through this config."""
+    plan = _plan(SFFTConfig)
+    with plan.lock:
+        if 'regularization' in SFFTConfig[1]:
+            reg = SFFTConfig[1]['regularization']
+            if plan._reg_token is not reg:
+                plan.set_regularization(*reg)
+                plan._reg_token = reg
+        yield plan
 
 
 def _as_device(x, plan, name):
@@ -47,13 +64,14 @@ class ElementalSFFTSubtract_PureCupy:
             raise Exception('MeLOn ERROR: %s' % _error_message)
         I = _as_device(PixA_I_GPU, plan, 'PixA_I')
         J = _as_device(PixA_J_GPU, plan, 'PixA_J')
-        if SFFTSolution_GPU is None:
-            Solution_GPU = plan.solve(I, J)
-        else:
-            Solution_GPU = _as_device(SFFTSolution_GPU, plan, 'SFFTSolution')
-        PixA_DIFF_GPU = None
-        if Subtract:
-            PixA_DIFF_GPU = plan.apply(I, J, Solution_GPU)
+        with _bound_plan(SFFTConfig):
+            if SFFTSolution_GPU is None:
+                Solution_GPU = plan.solve(I, J)
+            else:
+                Solution_GPU = _as_device(SFFTSolution_GPU, plan, 'SFFTSolution')
+            PixA_DIFF_GPU = None
+            if Subtract:
+                PixA_DIFF_GPU = plan.apply(I, J, Solution_GPU)
         if VERBOSE_LEVEL in [1, 2]:
             torch.cuda.synchronize(plan.device)
             print('\nMeLOn CheckPoint: SFFT-SUBTRACTION takes [%.4fs]' % (time.time() - ta))
@@ -94,19 +112,20 @@ class GeneralSFFTSubtract_PureCupy:
         J = _as_device(PixA_J_GPU, plan, 'PixA_J')
         mI = _as_device(PixA_mI_GPU, plan, 'PixA_mI')
         mJ = _as_device(PixA_mJ_GPU, plan, 'PixA_mJ')
-        Solution_GPU, PixA_DIFF_GPU = plan.subtract(I, J, mI, mJ)
-        # * Identify propagated contamination region through convolving I (SFFTSubtract.py:907-921, 1432-1448):
-        #   apply the kernel-only solution (b_pq = 0) to the mask with J = 0 and threshold the result.
-        ContamMask_CI_GPU = None
-        if ContamMask_I_GPU is not None:
-            Fpq = SFFTConfig[0]['Fpq']
-            tSolution = Solution_GPU.clone()
-            tSolution[-Fpq:] = 0.0
-            _tmpI = _as_device(ContamMask_I_GPU, plan, 'ContamMask_I')
-            _tmpJ = torch.zeros_like(J)
-            _tmpD = plan.apply(_tmpI, _tmpJ, tSolution)
-            FTHRESH = -0.001  # Emperical (reference value)
-            ContamMask_CI_GPU = _tmpD < FTHRESH
+        with _bound_plan(SFFTConfig):
+            Solution_GPU, PixA_DIFF_GPU = plan.subtract(I, J, mI, mJ)
+            # * Identify propagated contamination region through convolving I (SFFTSubtract.py:907-921, 1432-1448):
+            #   apply the kernel-only solution (b_pq = 0) to the mask with J = 0 and threshold the result.
+            ContamMask_CI_GPU = None
+            if ContamMask_I_GPU is not None:
+                Fpq = SFFTConfig[0]['Fpq']
+                tSolution = Solution_GPU.clone()
+                tSolution[-Fpq:] = 0.0
+                _tmpI = _as_device(ContamMask_I_GPU, plan, 'ContamMask_I')
+                _tmpJ = torch.zeros_like(J)
+                _tmpD = plan.apply(_tmpI, _tmpJ, tSolution)
+                FTHRESH = -0.001  # Emperical (reference value)
+                ContamMask_CI_GPU = _tmpD < FTHRESH
         return Solution_GPU, PixA_DIFF_GPU, ContamMask_CI_GPU
 
 

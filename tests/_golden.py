@@ -32,6 +32,11 @@ def load_golden(name):
     meta = ast.literal_eval(str(z["meta"][0]))
     g = {k: z[k] for k in z.files if k != "meta"}
     g["meta"] = meta
+    if "LHMAT_tril" in g:           # big systems are stored as the packed lower triangle (asymmetry of the original in meta)
+        n = g["Solution"].shape[0]
+        LH = np.zeros((n, n))
+        LH[np.tril_indices(n)] = g.pop("LHMAT_tril")
+        g["LHMAT"] = LH + np.tril(LH, -1).T
     if "REF" not in g:
         pair = make_pair(meta["N0"], meta["N1"], seed=meta["seed"], mask=bool(meta["mask"]),
                          nan_pixels=meta["nan_pixels"], sky=meta["sky"], bkg_scale=meta["bkg_scale"])

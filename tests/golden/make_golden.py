@@ -61,9 +61,10 @@ def load_reference():
     return mods["SFFTConfigure"], mods["SFFTSubtract"]
 
 
-def C(name, N0, N1, w, DK, DB, CPR=True, FC="REF", seed=0, mask=True, nan=0, store=True, sky=0.0, bkg=0.05):
+def C(name, N0, N1, w, DK, DB, CPR=True, FC="REF", seed=0, mask=True, nan=0, store=True, sky=0.0, bkg=0.05,
+      contam=False, tril=False):
     return dict(name=name, N0=N0, N1=N1, w=w, DK=DK, DB=DB, CPR=CPR, FC=FC, seed=seed, mask=mask,
-                nan=nan, store=store, sky=sky, bkg=bkg)
+                nan=nan, store=store, sky=sky, bkg=bkg, contam=contam, tril=tril)
 
 
 # masked cases mimic sky-subtracted frames (sky 0, faint differential background); unmasked ones
@@ -80,6 +81,13 @@ CASES = [
     C("c128x96_w4_k2b2_cpr", 128, 96, 4, 2, 2, seed=19),
     # BASELINE.json config 1: 512x512, KerHW 4, constant kernel, flat background
     C("c512x512_w4_k0b0_cpr", 512, 512, 4, 0, 0, seed=20, store=False),
+    # BASELINE.json config 2's kernel geometry (KerHW 8, orders 2/2, NEQ 1740) on a small frame; LHMAT is stored as its
+    # packed lower triangle (the asymmetry of the reference's matrix is recorded in meta).  Several minutes each in pure Python.
+    C("c96x80_w8_k2b2_cpr", 96, 80, 8, 2, 2, seed=21, tril=True, contam=True),
+    C("c96x80_w8_k2b2_cpr_sci", 96, 80, 8, 2, 2, FC="SCI", seed=22, tril=True),
+    # contamination-mask propagation through GSS (SFFTSubtract.py:907-921)
+    C("c64x64_w3_k2b2_cpr_contam", 64, 64, 3, 2, 2, seed=23, contam=True),
+    C("c48x40_w2_k1b1_free_contam", 48, 40, 2, 1, 1, CPR=False, seed=24, mask=False, sky=100.0, bkg=1.0, contam=True),
 ]
 
 
@@ -123,10 +131,31 @@ def run_case(cfgmod, submod, case):
         I[NaNmask_U] = mI[NaNmask_U]
         J[NaNmask_U] = mJ[NaNmask_U]
 
+    # contamination mask of image I (saturated cores and a bad column), propagated by GSS itself; the third ESS call of
+    # GSS returns the convolved mask the threshold is applied to: it is captured (not altered) so that the test can
+    # leave out pixels that sit on the threshold
+    ContamMask_I = None
+    ess_out = []
+    if case["contam"]:
+        ContamMask_I = I > np.percentile(I, 99.0)
+        ContamMask_I[:, N1 // 3] = True
+        ContamMask_I[N0 // 2, N1 // 2:N1 // 2 + 5] = True
+        orig_ess = submod.ElementalSFFTSubtract.ESS
+
+        def cap_ess(*a, **k):
+            out = orig_ess(*a, **k)
+            ess_out.append(out)
+            return out
+        submod.ElementalSFFTSubtract.ESS = staticmethod(cap_ess)
+
     t0 = time.time()
-    Solution, DIFF, _ = submod.GeneralSFFTSubtract.GSS(
-        PixA_I=I, PixA_J=J, PixA_mI=mI, PixA_mJ=mJ, SFFTConfig=cfg, ContamMask_I=None,
-        BACKEND_4SUBTRACT="Numpy", NUM_CPU_THREADS_4SUBTRACT=1, VERBOSE_LEVEL=0)
+    try:
+        Solution, DIFF, ContamMask_CI = submod.GeneralSFFTSubtract.GSS(
+            PixA_I=I, PixA_J=J, PixA_mI=mI, PixA_mJ=mJ, SFFTConfig=cfg, ContamMask_I=ContamMask_I,
+            BACKEND_4SUBTRACT="Numpy", NUM_CPU_THREADS_4SUBTRACT=1, VERBOSE_LEVEL=0)
+    finally:
+        if case["contam"]:
+            submod.ElementalSFFTSubtract.ESS = staticmethod(orig_ess)
     if NaNmask_U is not None:
         DIFF[NaNmask_U] = np.nan
     if FC == "SCI":
@@ -138,11 +167,19 @@ def run_case(cfgmod, submod, case):
                 checksum=pair_checksum(pair))
     out = dict(meta=np.array([repr(meta)]), Solution=Solution, DIFF=DIFF,
                RHb=cap["RHb"])
-    if store:
-        out.update(REF=REFa, SCI=SCIa, mREF=mREF, mSCI=mSCI, LHMAT=cap["LHMAT"])
+    LH = cap["LHMAT"]
+    if case["contam"]:
+        assert len(ess_out) == 3 and ContamMask_CI is not None
+        out.update(ContamMask_I=ContamMask_I, ContamMask_CI=ContamMask_CI, ContamD=np.array(ess_out[2][1], copy=True))
+    if case["tril"]:
+        meta["LHMAT_asym"] = float(np.max(np.abs(LH - LH.T)) / np.max(np.abs(LH)))
+        out["meta"] = np.array([repr(meta)])
+        out["LHMAT_tril"] = LH[np.tril_indices(LH.shape[0])]
     else:
-        # large case: inputs regenerate from the seed (checksum in meta)
-        out.update(LHMAT=cap["LHMAT"])
+        out["LHMAT"] = LH
+    if store:
+        out.update(REF=REFa, SCI=SCIa, mREF=mREF, mSCI=mSCI)
+    # else: large case, inputs regenerate from the seed (checksum in meta)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     cond = np.linalg.cond(cap["LHMAT"])
     print("%-28s NEQ=%4d  cond=%.2e  rms(DIFF)=%.4g  %.1fs" %

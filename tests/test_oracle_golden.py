@@ -49,6 +49,25 @@ def test_end_to_end(name):
     assert Solution.shape == g["Solution"].shape
 
 
+@pytest.mark.parametrize("name", [n for n in NAMES if "contam" in n or n == "c96x80_w8_k2b2_cpr"])
+def test_contamination_mask_matches_reference(name):
+    """GSS's ContamMask_I -> ContamMask_CI branch (SFFTSubtract.py:907-921) against the reference's own output: identical
+    masks on every pixel whose convolved-mask value (stored from the reference's third ESS call) is not on the threshold."""
+    g = load_golden(name)
+    p = _params(g["meta"])
+    I, J, mI, mJ, _ = packet_roles(g)
+    D_ref, cm_ref = g["ContamD"], g["ContamMask_CI"]
+    tsol = g["Solution"].copy()
+    tsol[-p["Fpq"]:] = 0.0
+    D = O.ESS(g["ContamMask_I"].astype(np.float64), np.zeros(J.shape), p, tsol, True)[1]
+    assert np.max(np.abs(D - D_ref)) <= 1e-10 * np.max(np.abs(D_ref))
+    clear = np.abs(D_ref + 0.001) >= 1e-9
+    assert np.array_equal((D < -0.001)[clear], cm_ref[clear]) and clear.mean() > 0.99
+    cmask = O.GSS(I, J, mI, mJ, p, ContamMask_I=g["ContamMask_I"])[2]
+    clear = np.abs(D_ref + 0.001) >= 1e-6 * max(1.0, float(np.max(np.abs(D_ref))))
+    assert np.array_equal(cmask[clear], cm_ref[clear]) and clear.mean() > 0.98
+
+
 @pytest.mark.parametrize("name", [n for n in NAMES if "48x40" in n or "45x35" in n])
 def test_construct_fdiff_literal_equals_matmul_form(name):
     g = load_golden(name)
