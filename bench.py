@@ -1,27 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the SFFT subtraction hot path on MI355X.
+"""bench.py -- benchmark of the SFFT subtraction hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                  BASELINE configs[1] (the headline; default)
+    python bench.py --config 3|5 ...                               configs[2] (B-spline, 6144^2) / configs[4] (9232 x 9216, KerHW 12)
+    python bench.py --pairs 62 ...                                 configs[3]: a fixed batch of independent pairs dealt to the ranks
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one GSS-equivalent pass (solve on the masked pair + apply to the full pair, the body of
-sfft.PureCupy_Customized_Packet.PCCP) over one batch of synthetic 4096 x 4096 image pairs, KerHW 8,
-KerPolyOrder 2, BGPolyOrder 2, ConstPhotRatio, fp64 -- BASELINE.json configs[1].  The batch is `--streams` pairs
-per GPU (default 3), each on its own plan, HIP stream and host thread: the dense solve of one pair is latency
-bound and leaves most CUs idle, so independent pairs are pipelined on one GPU exactly as the reference's
-multi-task packet pipelines them with one thread per device queue.  Inputs are resident in HBM when the timed
-region starts; plans (tables + workspaces) are created before it.  With N ranks every rank runs its own batch
-per step (weak scaling, no data-path collective); the only collective is the gather of per-pair records at the
-end (sfft_amd/sharding.py).
+sfft.PureCupy_Customized_Packet.PCCP) over one BATCH of distinct synthetic image pairs that are resident in HBM when the
+timed region starts.  Default: every rank holds `--batch` pairs (64 at config 2) and subtracts each once per step with
+`--streams` pairs in flight (one plan + HIP stream + host thread each, static deal) -- weak scaling, no data-path
+collective.  `--pairs M`: M pairs in total, dealt round-robin to the ranks (uneven shards), every rank's worker threads pull
+from the shard's queue like the reference's multi-task packet (sfft/MultiEasyCrowdedPacket.py:361-399); a step is the whole
+batch -- strong scaling.  Plans (tables + workspaces) are created before the timed region.  The only collective is the gather
+of one [pair_id, status, ms, Solution] record per pair at the end (sfft_amd/sharding.py).
+
+After the timed region every checked pair is subtracted again with ONE pair in flight into fresh buffers and the result of
+the pipelined run must equal it bit for bit (`post_check`); the same isolated launches give the per-kernel durations of the
+`roofline` objects (HIP events on the launch stream).
 
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
-  roofline     -- the dominant KERNEL by time per pair.  Since the forward transforms were halved that is the Omega pass of the
-                  Greek stage (greek_g1_mfma<2,false>: v_mfma_f64_16x16x4_f64), priced against the fp64 MFMA peak (bound "mfma"); `roofline_hbm` is the dominant HBM-bound kernel, the forward column pass
-                  (cols_fwd_weighted_4096_q): algorithmic bytes of the timed launch / its duration (HIP events on the launch
-                  stream) against the 8 TB/s HBM3E peak; `roofline_greek` is the same for the second kernel, the Omega
-                  pass of the Greek stage, which is bound by fp64 FMA issue, not by HBM
-  cpu_baseline -- the numpy/scipy oracle (port of the reference's Numpy backend) timed on this host on a
-                  bounded sample (smaller image, same kernel geometry), converted to 4096^2-pairs/s by pixel count
+  roofline      the dominant KERNEL by time per pair: the Omega passes of the Greek stage (v_mfma_f64_16x16x4_f64) against
+                the fp64 MFMA peak; roofline_hbm: the dominant HBM-bound kernel, the forward column pass
+  cpu_baseline  the CPU restatement of the reference's Numpy path timed on this host (N = 1, config 2 only)
+  host_arrays   the same workload with CP semantics: host (pinned) arrays in, host arrays out, PCIe both ways -- never `value`
 """
 import argparse
 import json
@@ -41,40 +43,48 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_PEAK_TFLOPS = 78.6    # same guide: fp64 vector = fp64 matrix (MFMA) peak on MI355X
+FP64_PEAK_TFLOPS = 78.6    # fp64 vector = fp64 matrix (MFMA) peak on MI355X (public spec; the guide has no fp64 MFMA row)
+
+CONFIGS = {
+    2: dict(N0=4096, N1=4096, w=8, DK=2, DB=2, batch=64, streams=4,
+            name="BASELINE configs[1]: 4096x4096 pairs, KerHW 8, KerPolyOrder 2, BGPolyOrder 2, ConstPhotRatio, fp64"),
+    3: dict(N0=6144, N1=6144, w=8, DK=2, DB=2, batch=4, streams=2, bspline=True,
+            name="BASELINE configs[2]: BSplineSFFT, 6144x6144 pairs, KerHW 8, B-spline kernel degree 2 with 2x2 internal knots "
+                 "(Fij 25, NEQ 7231), constant scaling, polynomial background degree 2, fp64"),
+    5: dict(N0=9232, N1=9216, w=12, DK=3, DB=3, batch=2, streams=1,
+            name="BASELINE configs[4]: 9232x9216 pairs, KerHW 12, KerPolyOrder 3, BGPolyOrder 3, ConstPhotRatio, fp64"),
+}
 
 
-def alg_bytes(N0, N1, w, DK, DB):
+def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply):
     """Algorithmic HBM bytes per stage for ONE pair (solve + apply), as built, and the
-    canonical reference-algorithm figure B_alg of SURVEY.md 8(d)."""
+    canonical reference-algorithm figure B_alg of SURVEY.md 8(d).  n_colfac = distinct column factors of the kernel basis
+    (DK + 1 for a polynomial, Fj for a B-spline tensor basis): one row transform each."""
     P = N0 * N1
     Nh = N1 // 2 + 1
-    Fij = (DK + 1) * (DK + 2) // 2
-    Fpq = (DB + 1) * (DB + 2) // 2
     c, r = 16, 8
     spec = c * N0 * Nh                                  # one half-spectrum plane
-    fwd_plane = r * P + spec + 2 * spec                 # rows: read image, write spectrum; columns: read + write
-    n_omg, n_gam, n_the = Fij * (Fij + 1) // 2, Fij * Fpq, Fij
-    n_gamp = Fij * DB                                   # dense Gamma column-factor passes (p >= 1); they read A only
+    n_omg = Fij * (Fij + 1) // 2
     out = {
-        "prelim_solve": (Fij + 1) * fwd_plane + r * P,  # + row moments of J
-        # forward transforms of the solve pass as built: one row transform per distinct column factor (DK + 1 of them, + J) into
-        # stage planes; the column pass reads every stage plane (from HBM once, its other readers hit L2) and writes Fij + 1 planes
-        "fwd_rows": 2 * r * P + (DK + 2) * spec,
-        "fwd_cols": (DK + 2) * spec + (Fij + 1) * spec,
+        # forward transforms of the solve pass as built: one row transform per distinct column factor (+ J) into stage planes;
+        # the column pass reads every stage plane (from HBM once, its other readers hit L2) and writes Fij + 1 planes
+        "fwd_rows": 2 * r * P + (n_colfac + 1) * spec,
+        "fwd_cols": (n_colfac + 1) * spec + (Fij + 1) * spec,
         # Greek stage 1 as built: all passes of a (64-column x row-chunk) tile run on one XCD back to back, so each of the
-        # Fij (+ J) planes is streamed from HBM once and re-read from that XCD's L2; partial lag sums are written
+        # Fij planes is streamed from HBM once and re-read from that XCD's L2; the per-chunk partial lag sums are written
         "greek_g1": Fij * spec,
-        "greek_g1b": (Fij + 1) * spec + 8 * N0 * N1,      # Theta passes: Fij planes + FJ; Gamma block: one read of the masked image
+        "greek_g1b": (Fij + 1) * spec + r * P,          # Theta passes: Fij planes + FJ; Gamma block: one read of the masked image
         # fp64 flops of the Omega passes: per pass and spectrum element one complex product (6) + 4 real FMAs per lag
         # (the Fij diagonal passes have a real product: half the lag work)
         "greek_g1_flops": N0 * Nh * ((n_omg - Fij) * (6 + 2 * 4 * (2 * w)) + Fij * (3 + 4 * (2 * w))),
-        # apply pass as built (polynomial kernel, KerHW <= 8): row pass into DK + 1 stage planes, mixed-domain column convolution
-        # (reads them, writes one plane), inverse row pass with the DIFF epilogue -- no column transforms
-        "prelim_apply": r * P + (DK + 1) * spec,
-        "construct": (DK + 1) * spec + spec,
-        "inverse": spec + r * P + r * P,                # rows read, J read, DIFF write
     }
+    if mixed_apply:
+        # polynomial kernel: row pass into stage planes, mixed-domain column convolution (reads them, writes one plane),
+        # inverse row pass with the DIFF epilogue -- no column transforms
+        out.update(prelim_apply=r * P + n_colfac * spec, construct=n_colfac * spec + spec, inverse=spec + 2 * r * P)
+    else:
+        # Fourier-domain apply: Fij forward plane transforms, construct_fd reads them and writes one, inverse column + row pass
+        out.update(prelim_apply=r * P + n_colfac * spec + (n_colfac + Fij) * spec, construct=(Fij + 1) * spec, inverse=3 * spec + 2 * r * P)
     n_pre = 1 + Fij + Fpq
     n_greek = Fij * Fij + 2 * Fij * Fpq + Fpq * Fpq + Fij + Fpq
     n_fft = 2 * n_pre + n_greek + 1
@@ -83,43 +93,69 @@ def alg_bytes(N0, N1, w, DK, DB):
     return out
 
 
-def cpu_baseline(w, DK, DB, full_pixels, sample_side):
-    """Time the oracle's GSS on a bounded sample: a sample_side^2 pair with the same kernel geometry."""
-    from oracle import sfft_oracle as O
-    from sfft_amd.utils.synthetic import make_pair
-    cores = os.cpu_count() or 1
-    pair = make_pair(sample_side, sample_side, seed=4321, mask=True, sky=0.0, bkg_scale=0.05)
-    p = O.SSC(sample_side, sample_side, w, DK, DB, True)
-    t0 = time.perf_counter()
-    O.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], p, workers=cores)
-    dt = time.perf_counter() - t0
-    mpix_s = sample_side * sample_side / 1e6 / dt
-    return {"value": mpix_s * 1e6 / full_pixels, "unit": "image-pairs/s", "mpix_per_s": mpix_s, "cores": cores,
-            "kind": "port",
-            "sample": "one GSS (solve+apply) on a %dx%d synthetic pair, KerHW %d, orders %d/%d, numpy oracle with "
-                      "scipy.fft workers=%d; %.1f s; scaled to 4096^2 pairs by pixel count"
-                      % (sample_side, sample_side, w, DK, DB, cores, dt)}
+def cpu_baseline(cfg, quick):
+    """The CPU restatement of the reference's Numpy path on this host (oracle/: test infrastructure; timed here, never shipped).
+    Config 2 only.  See oracle/cpu_baseline.py for the protocol."""
+    from oracle import cpu_baseline as CB
+    return CB.measure(cfg["N0"], cfg["N1"], cfg["w"], cfg["DK"], cfg["DB"], quick=quick)
+
+
+def blob_pair_device(torch, N0, N1, seed, dev, ratio=1.25):
+    """Cheap synthetic pair made on the device (the star renderer of utils/synthetic.py takes half a minute at 85 Mpix):
+    smooth blobs + noise; SCI = ratio * (REF blurred by a 3-tap kernel) + sky + noise; the masked pair keeps the blobs."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.linspace(0, N0 / 100.0 * np.pi, N0, dtype=torch.float64, device=dev)[:, None]
+    y = torch.linspace(0, N1 / 110.0 * np.pi, N1, dtype=torch.float64, device=dev)[None, :]
+    base = 80.0 * (torch.sin(x + 0.37 * seed) * torch.cos(y - 0.11 * seed)) ** 8
+    REF = base + torch.randn((N0, N1), dtype=torch.float64, device=dev, generator=g)
+    SCI = ratio * (0.6 * base + 0.2 * torch.roll(base, 1, 0) + 0.2 * torch.roll(base, -1, 1)) + 2.0 \
+        + torch.randn((N0, N1), dtype=torch.float64, device=dev, generator=g)
+    keep = base > 0.5
+    z = torch.zeros((), dtype=torch.float64, device=dev)
+    return {"REF": REF.contiguous(), "SCI": SCI.contiguous(), "mREF": torch.where(keep, REF, z).contiguous(),
+            "mSCI": torch.where(keep, SCI, z).contiguous()}
+
+
+def derive_pair(torch, base, k, dev):
+    """Pair k of a batch from a seeded star-field pair: circular shift (the SFFT model is periodic, so a shifted field is as
+    good a field) + fresh N(0, 0.5) noise in both frames; the star mask moves along.  k = 0 is the base pair itself."""
+    if k == 0:
+        return base
+    N0, N1 = base["REF"].shape
+    sh = ((131 * k) % N0, (977 * k) % N1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7000 + k)
+    keep = torch.roll(base["mREF"] != 0, sh, (0, 1))
+    REF = torch.roll(base["REF"], sh, (0, 1)) + 0.5 * torch.randn((N0, N1), dtype=torch.float64, device=dev, generator=g)
+    SCI = torch.roll(base["SCI"], sh, (0, 1)) + 0.5 * torch.randn((N0, N1), dtype=torch.float64, device=dev, generator=g)
+    z = torch.zeros((), dtype=torch.float64, device=dev)
+    return {"REF": REF.contiguous(), "SCI": SCI.contiguous(), "mREF": torch.where(keep, REF, z).contiguous(),
+            "mSCI": torch.where(keep, SCI, z).contiguous()}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--kerhw", type=int, default=8)
-    ap.add_argument("--dk", type=int, default=2)
-    ap.add_argument("--db", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=4,
-                    help="independent pairs in flight per GPU (one plan + stream + host thread each); a step = this many pairs")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="side of the CPU-baseline sample image (0 = skip)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE config (1-based as in SURVEY 8d): 2 = headline")
+    ap.add_argument("--pairs", type=int, default=0, help="config-4 mode: a fixed batch of this many config-2 pairs dealt round-robin "
+                    "to the ranks (62 = one DECam focal plane); a step = the whole batch")
+    ap.add_argument("--batch", type=int, default=0, help="distinct pairs per GPU and step (default: 64 / 4 / 2 for config 2 / 3 / 5)")
+    ap.add_argument("--streams", type=int, default=0, help="independent pairs in flight per GPU (one plan + stream + host thread each)")
+    ap.add_argument("--size", type=int, default=0, help="override the image side (square), e.g. for a quick run")
+    ap.add_argument("--kerhw", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline with the full protocol (3 warm-ups, median of 10) instead of the bounded one")
+    ap.add_argument("--no-host-arrays", action="store_true", help="skip the host-array (PCIe-inclusive) variant")
     args = ap.parse_args()
 
     import threading
     import torch
     import torch.distributed as dist
-    from sfft_amd.plan import get_plan
-    from sfft_amd.sharding import pack_record, gather_records
+    from sfft_amd.plan import Plan
+    from sfft_amd.sharding import shard_pair_ids, pack_record, gather_records, run_shard
     from sfft_amd.utils.synthetic import make_pair
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,99 +169,211 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    N, S = args.size, max(1, args.streams)
+    cfg = dict(CONFIGS[args.config])
+    if args.size:
+        cfg["N0"] = cfg["N1"] = args.size
+    if args.kerhw:
+        cfg["w"] = args.kerhw
+    N0, N1, w, DK, DB = cfg["N0"], cfg["N1"], cfg["w"], cfg["DK"], cfg["DB"]
+    bspline = bool(cfg.get("bspline"))
+    S = max(1, args.streams or cfg["streams"])
+    batch_mode = args.pairs > 0
+    if batch_mode:
+        assert args.config == 2, "--pairs is config 4: a batch of config-2 pairs"
+        my_ids = shard_pair_ids(args.pairs, rank, world)          # global pair ids of this rank's shard (uneven shards)
+        n_total = args.pairs
+    else:
+        B = max(1, args.batch or cfg["batch"])
+        my_ids = list(range(rank * B, (rank + 1) * B))
+        n_total = world * B
+    S = min(S, max(1, len(my_ids)))
+
+    # ---- plans: one per pair in flight ----------------------------------------------------------------------------
     t0 = time.perf_counter()
-    plans = [get_plan(N, N, args.kerhw, args.dk, args.db, True, local_rank, slot=i) for i in range(S)]
+    if bspline:
+        from sfft_amd.BSplineSFFT import _axis_tables
+        kx, ky = [N0 / 3 + 0.5, 2 * N0 / 3 + 0.5], [N1 / 3 + 0.5, 2 * N1 / 3 + 0.5]
+        kbx, kby, kpairs = _axis_tables(N0, N1, "B-Spline", DK, kx, ky)
+        tbx, tby, bpairs = _axis_tables(N0, N1, "Polynomial", DB, [], [])
+        bdict = dict(kbx=kbx, kby=kby, ker_pairs=kpairs, tbx=tbx, tby=tby, bkg_pairs=bpairs, scaling_mode=2)
+        plans = [Plan(N0, N1, w, device=local_rank, basis=bdict) for _ in range(S)]
+        n_colfac = kby.shape[0]
+    else:
+        plans = [Plan(N0, N1, w, DK, DB, True, device=local_rank) for _ in range(S)]
+        n_colfac = DK + 1
     torch.cuda.synchronize(dev)
     plan_s = (time.perf_counter() - t0) / S
+    NEQ, Fij, Fpq = plans[0].NEQ, plans[0].query("Fij"), plans[0].Fpq
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
-    # one synthetic pair per stream (pair id = rank * S + i), resident in HBM before the timed region
-    pairs = [make_pair(N, N, seed=1234 + rank * S + i, mask=True, sky=0.0, bkg_scale=0.05) for i in range(S)]
-    g = [{k: torch.from_numpy(v).to(dev) for k, v in pr.items()} for pr in pairs]
-    sols = [torch.empty(plans[0].NEQ, dtype=torch.float64, device=dev) for _ in range(S)]
-    diffs = [torch.empty((N, N), dtype=torch.float64, device=dev) for _ in range(S)]
-    stage_acc = {}
 
-    def run(i, n, timed):
-        torch.cuda.set_device(local_rank)
-        with torch.cuda.stream(streams[i]):
-            for _ in range(n):
-                plans[i].subtract(g[i]["REF"], g[i]["SCI"], g[i]["mREF"], g[i]["mSCI"], out_solution=sols[i], out_diff=diffs[i])
-                if timed and i == 0:
-                    for k, v in plans[0].stage_ms().items():
-                        stage_acc[k] = stage_acc.get(k, 0.0) + v
+    # ---- the batch: distinct pairs, resident in HBM before the timed region ------------------------------------------
+    if args.config == 2:
+        nbase = min(2, len(my_ids))
+        bases = []
+        for b in range(nbase):   # seeded star fields (SURVEY 8d recipe); pair ids b, b + nbase, ... derive from base b
+            pr = make_pair(N0, N1, seed=1234 + 16 * rank + b, mask=True, sky=0.0, bkg_scale=0.05)
+            bases.append({k: torch.from_numpy(v).to(dev) for k, v in pr.items()})
+        pairs = [derive_pair(torch, bases[k % nbase], k // nbase, dev) for k in range(len(my_ids))]
+    else:
+        pairs = [blob_pair_device(torch, N0, N1, 100 * rank + k + 3, dev) for k in range(len(my_ids))]
+    sols = [torch.zeros(NEQ, dtype=torch.float64, device=dev) for _ in my_ids]
+    diffs = [torch.empty((N0, N1), dtype=torch.float64, device=dev) for _ in my_ids]
+    torch.cuda.synchronize(dev)
 
-    def run_all(n, timed):
-        if S == 1:
-            run(0, n, timed)
+    def subtract(wi, k):
+        """pair k of this rank's shard on worker wi's plan and stream"""
+        g = pairs[k]
+        plans[wi].subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"], out_solution=sols[k], out_diff=diffs[k])
+        return sols[k]
+
+    last_records = [None]
+
+    def run_steps(n):
+        def static_worker(wi):
+            torch.cuda.set_device(local_rank)
+            with torch.cuda.stream(streams[wi]):
+                for _ in range(n):
+                    for k in range(wi, len(my_ids), S):
+                        subtract(wi, k)
+        if not batch_mode:
+            if S == 1:
+                static_worker(0)
+            else:
+                th = [threading.Thread(target=static_worker, args=(i,)) for i in range(S)]
+                [t.start() for t in th]
+                [t.join() for t in th]
             return
-        th = [threading.Thread(target=run, args=(i, n, timed)) for i in range(S)]
-        [t.start() for t in th]
-        [t.join() for t in th]
+        for _ in range(n):          # config 4: the shard's queue, workers pull (run_shard), per-pair status and time recorded
 
-    run_all(args.warmup, False)
-    plans[0].set_timing(True)
+            def work(wi, pid):
+                torch.cuda.set_device(local_rank)
+                with torch.cuda.stream(streams[wi]):
+                    return subtract(wi, my_ids.index(pid))
+            last_records[0] = run_shard(my_ids, S, work, NEQ, dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    run_steps(args.warmup)
     torch.cuda.synchronize(dev)
     barrier()
     t_start = time.perf_counter()
-    run_all(args.steps, True)
+    run_steps(args.steps)
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t_start
-
-    # isolated pass (one pair in flight) for per-kernel roofline numbers that are not inflated by the other streams
-    iso_acc = {}
-    n_iso = min(5, max(2, args.steps))
-    with torch.cuda.stream(streams[0]):
-        t_iso = time.perf_counter()
-        for _ in range(n_iso):
-            plans[0].subtract(g[0]["REF"], g[0]["SCI"], g[0]["mREF"], g[0]["mSCI"], out_solution=sols[0], out_diff=diffs[0])
-            for k, v in plans[0].stage_ms().items():
-                iso_acc[k] = iso_acc.get(k, 0.0) + v
-        torch.cuda.synchronize(dev)
-        iso_ms = (time.perf_counter() - t_iso) * 1e3 / n_iso
-    plans[0].set_timing(False)
-
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # gather one record per pair: the only collective of the data path
-    recs = [pack_record(rank * S + i, 0, elapsed * 1e3 / max(args.steps, 1), sols[i]) for i in range(S)]
-    table = gather_records(recs, world * S, plans[0].NEQ, dev)
+
+    # ---- post-run check + isolated per-kernel durations: ONE pair in flight, fresh output buffers -----------------------
+    check_ids = sorted(set([0, len(my_ids) // 2, len(my_ids) - 1]))
+    iso_acc, iso_ms = {}, []
+    post = {"pairs_checked": [my_ids[k] for k in check_ids], "bitwise_equal": True, "max_rel_diff": 0.0}
+    plans[0].set_timing(True)
+    with torch.cuda.stream(streams[0]):
+        fresh_s = torch.empty(NEQ, dtype=torch.float64, device=dev)
+        fresh_d = torch.empty((N0, N1), dtype=torch.float64, device=dev)
+        for k in check_ids * (2 if len(check_ids) < 3 else 1):
+            g = pairs[k]
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            plans[0].subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"], out_solution=fresh_s, out_diff=fresh_d)
+            torch.cuda.synchronize(dev)
+            iso_ms.append((time.perf_counter() - t1) * 1e3)
+            for kk, v in plans[0].stage_ms().items():
+                iso_acc[kk] = iso_acc.get(kk, 0.0) + v
+            same = bool(torch.equal(fresh_s, sols[k])) and bool(torch.equal(fresh_d, diffs[k]))
+            post["bitwise_equal"] = post["bitwise_equal"] and same
+            if not same:
+                rel = float(((fresh_d - diffs[k]).abs().max() / fresh_d.abs().max()).item())
+                post["max_rel_diff"] = max(post["max_rel_diff"], rel)
+            assert bool(torch.isfinite(fresh_d).all()), "non-finite DIFF"
+        n_iso = len(iso_ms)
+    plans[0].set_timing(False)
+    assert post["bitwise_equal"] or post["max_rel_diff"] <= 1e-12, "pipelined result differs from the single-stream result: %r" % post
+
+    # ---- records: the only collective of the data path -------------------------------------------------------------------
+    if batch_mode:
+        recs = last_records[0]
+    else:
+        recs = [pack_record(my_ids[k], 0, elapsed * 1e3 / max(args.steps * len(my_ids), 1), sols[k]) for k in range(len(my_ids))]
+    table = gather_records(recs, n_total, NEQ, dev)
+    n_failed = int((table[:, 1] != 0).sum().item())
+
+    # ---- host-array variant (CP semantics): pinned host arrays in, host arrays out, H2D / D2H overlapped across streams ----
+    host = None
+    if world == 1 and args.config == 2 and not batch_mode and not args.no_host_arrays:
+        nh = min(len(my_ids), 2 * S)
+        hin = [{k: v.cpu().pin_memory() for k, v in pairs[k].items()} for k in range(nh)]
+        hout = [torch.empty((N0, N1), dtype=torch.float64).pin_memory() for _ in range(nh)]
+        hsol = [torch.empty(NEQ, dtype=torch.float64).pin_memory() for _ in range(nh)]
+        dbuf = [{k: torch.empty((N0, N1), dtype=torch.float64, device=dev) for k in ("REF", "SCI", "mREF", "mSCI")} for _ in range(S)]
+        dd = [torch.empty((N0, N1), dtype=torch.float64, device=dev) for _ in range(S)]
+        ds = [torch.empty(NEQ, dtype=torch.float64, device=dev) for _ in range(S)]
+
+        def host_worker(wi, reps):
+            torch.cuda.set_device(local_rank)
+            with torch.cuda.stream(streams[wi]):
+                for _ in range(reps):
+                    for k in range(wi, nh, S):
+                        for name in ("REF", "SCI", "mREF", "mSCI"):
+                            dbuf[wi][name].copy_(hin[k][name], non_blocking=True)
+                        plans[wi].subtract(dbuf[wi]["REF"], dbuf[wi]["SCI"], dbuf[wi]["mREF"], dbuf[wi]["mSCI"], out_solution=ds[wi], out_diff=dd[wi])
+                        hout[k].copy_(dd[wi], non_blocking=True)
+                        hsol[k].copy_(ds[wi], non_blocking=True)
+                streams[wi].synchronize()
+
+        def host_run(reps):
+            th = [threading.Thread(target=host_worker, args=(i, reps)) for i in range(S)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        host_run(1)
+        torch.cuda.synchronize(dev)
+        reps = 6
+        t1 = time.perf_counter()
+        host_run(reps)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        ok = all(bool(torch.equal(hout[k], diffs[k].cpu())) for k in (0, nh - 1))
+        moved = (4 + 1) * 8 * N0 * N1
+        host = {"value": reps * nh / dt, "unit": "image-pairs/s", "pairs": reps * nh, "seconds": dt,
+                "pcie_GBs": reps * nh * moved / dt / 1e9, "bytes_per_pair": moved, "matches_device_resident_run": ok,
+                "note": "CP / GSS semantics: 4 pinned host images in (H2D), DIFF + Solution out (D2H), per pair, %d pairs in flight; "
+                        "never `value`" % S}
+        del hin, hout, dbuf, dd
 
     if rank == 0:
-        npairs = world * S * args.steps
-        value = npairs / elapsed
+        value = n_total * args.steps / elapsed
         ms_step = elapsed * 1e3 / args.steps
-        stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
         iso_stage = {k: v / n_iso for k, v in iso_acc.items()}
-        ab = alg_bytes(N, N, args.kerhw, args.dk, args.db)
+        mixed = (not bspline) and w <= 12
+        ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed)
+        headline = (args.config == 2 and (N0, N1, w) == (4096, 4096, 8))
 
         pmc = {}
         try:   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json; see profiles/README.md)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         except Exception:
             pass
-
-        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if N == 4096 else "cols_fwd_weighted / strided_dft",
-                     "fwd_rows": "rows_r2c_4096" if N == 4096 else "rows_r2c", "greek_g1": "greek_g1_mfma<2, false> (Omega passes)",
-                     "greek_g1b": "greek_g1<8, 2> (Theta passes) + row_moments / gamma_rows / gamma_patches (Gamma block)", "construct": "construct_fd"}
+        fast = (N0 == 4096 and N1 == 4096)
+        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if fast else "cols_fwd_weighted / strided_dft",
+                     "fwd_rows": "rows_r2c_4096" if fast else "rows_r2c", "greek_g1": "greek_g1_mfma<2, false> (Omega passes)",
+                     "greek_g1b": "greek_g1<8, 2> (Theta passes) + row_moments / gamma_rows / gamma_patches (Gamma block)",
+                     "construct": "vconv_mixed2<2, 8, 4>" if mixed and w <= 8 else ("vconv_mixed" if mixed else "construct_fd")}
 
         def roof(stages, dom="fwd_cols"):
             ach = ab[dom] / (stages[dom] * 1e-3) / 1e9
-            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if (N, args.kerhw, args.dk, args.db) == (4096, 8, 2, 2) else None
+            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if headline else None
             return {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "sustained_peak_measured": 5000.0,   # profiles/r01_hbm_stream.txt: a plain copy kernel on this device, GB/s
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": stages[dom]}
 
         def roof_flops(stages):
             tf = ab["greek_g1_flops"] / (stages["greek_g1"] * 1e-3) / 1e12
-            traffic = pmc.get("greek_g1", {}).get("hbm_bytes_per_launch") if (N, args.kerhw, args.dk, args.db) == (4096, 8, 2, 2) else None
+            traffic = pmc.get("greek_g1", {}).get("hbm_bytes_per_launch") if headline else None
             return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_flops"],
                     "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
@@ -233,40 +381,51 @@ def main():
                     "note": "v_mfma_f64_16x16x4_f64 (the fp64 matrix and vector peaks are equal on MI355X); a loop of nothing but independent "
                             "MFMAs sustains 47.4 TFLOP/s on this device (scripts/micro/mfma_f64_peak.hip); HBM side: "
                             "%.0f GB/s of algorithmic bytes" % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
+        per_pair_keys = [k for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse") if k in ab]
+        if batch_mode:
+            workload = ("BASELINE configs[3]: a batch of %d independent 4096x4096 pairs (config-2 geometry) dealt round-robin to %d rank(s): "
+                        "shards of %s pairs, %d worker threads per GPU pull from the shard's queue; a step = the whole batch"
+                        % (n_total, world, sorted(set(len(shard_pair_ids(n_total, r, world)) for r in range(world)), reverse=True), S))
+        else:
+            workload = ("%s; GSS = solve(masked pair) + apply(full pair); %d distinct pairs per GPU and step, %d in flight per GPU "
+                        "(one plan + stream each)" % (cfg["name"] if not (args.size or args.kerhw) else
+                                                      "%dx%d pairs, KerHW %d (config %d geometry)" % (N0, N1, w, args.config), len(my_ids), S))
         out = {
-            "metric": "image-pairs/sec, %dx%d, KerHW=%d polyOrd=%d" % (N, N, args.kerhw, args.dk),
-            "value": value, "unit": "image-pairs/s", "mpix_per_s": value * N * N / 1e6,
+            "metric": "image-pairs/sec, %dx%d, KerHW=%d polyOrd=%d" % (N0, N1, w, DK),
+            "value": value, "unit": "image-pairs/s", "mpix_per_s": value * N0 * N1 / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %dx%d pairs, KerHW %d, KerPolyOrder %d, BGPolyOrder %d, "
-                                   "ConstPhotRatio, fp64; GSS = solve(masked pair) + apply(full pair); "
-                                   "%d independent pairs in flight per GPU (one plan + stream each), a step = %d pairs"
-                                   % (N, N, args.kerhw, args.dk, args.db, S, world * S),
-                       "pairs_per_step": world * S, "pairs_in_flight_per_gpu": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "plan_create_s": plan_s,
+            "higher_is_better": True, "scaling": "strong" if batch_mode else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "baseline_config": 4 if batch_mode else args.config,
+                       "pairs_per_step": n_total, "pairs_in_flight_per_gpu": S, "timed_region_s": elapsed,
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "plan_create_s": plan_s, "NEQ": NEQ,
                        "solver": {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")},
-            "stage_ms": stage_ms,
-            # the dominant kernel by time per pair: the Omega pass of the Greek stage (one launch per pair) since the forward
-            # transforms were halved; it is bound by fp64 FMA issue.  The dominant HBM-bound kernel (forward column pass) follows.
             "roofline": dict(roof_flops(iso_stage) if iso_stage["greek_g1"] >= iso_stage["fwd_cols"] else roof(iso_stage),
                              measured="HIP events on the launch stream around the kernel, %d launches with one pair in flight right after "
                              "the timed region (same process, same buffers)" % n_iso,
-                             kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "construct")}),
+                             kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "construct", "solve")}),
             "roofline_hbm": dict(roof(iso_stage), measured="same events, same launches (the forward column launch of the solve pass: "
-                                 "%d stage planes in, %d planes out)" % (args.dk + 2, (args.dk + 1) * (args.dk + 2) // 2 + 1)),
+                                 "%d stage planes in, %d planes out)" % (n_colfac + 1, Fij + 1)),
             "roofline_greek": dict(roof_flops(iso_stage), measured="same events, same launches"),
-            "roofline_timed_region": dict(roof(stage_ms), measured="same events on stream 0 inside the timed region; durations "
-                                          "include time sliced to the other %d streams' kernels" % (S - 1)),
-            "single_pair": {"ms": iso_ms, "pairs_per_s": 1e3 / iso_ms, "stage_ms": iso_stage,
+            "single_pair": {"ms": float(np.median(iso_ms)), "pairs_per_s": 1e3 / float(np.median(iso_ms)), "stage_ms": iso_stage,
                             "note": "one pair in flight: latency of one GSS and per-stage times without interleaving"},
+            "post_check": dict(post, note="after the timed region each listed pair is subtracted again alone (one pair in flight, fresh "
+                               "output buffers); Solution and DIFF of the pipelined run must be bit-identical"),
             "pair_effective": {"B_alg_reference_bytes": ab["B_alg_reference"], "n_fft_reference": ab["n_fft_reference"],
                                "effective_GBs_per_gpu": ab["B_alg_reference"] * (value / world) / 1e9,
-                               "as_built_bytes_per_pair": sum(ab[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse")),
+                               "as_built_bytes_per_pair": sum(ab[k] for k in per_pair_keys),
                                "note": "reference-algorithm bytes (SURVEY 8d) x pairs/s per GPU; context, not the roofline: the build's own "
                                        "algorithmic bytes per pair are listed beside it"},
-            "gathered_pairs": int(table.shape[0]),
+            "gathered_pairs": int(table.shape[0]), "failed_pairs": n_failed,
         }
-        if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.kerhw, args.dk, args.db, N * N, args.cpu_sample)
+        if batch_mode:
+            ms = table[:, 2].cpu().numpy()
+            out["per_pair_ms"] = {"median": float(np.median(ms)), "max": float(ms.max()),
+                                  "note": "host time of each pair's sfft_subtract call in the last step (S pairs in flight share the GPU)"}
+            assert int(table.shape[0]) == args.pairs
+        if host is not None:
+            out["host_arrays"] = host
+        if world == 1 and headline and not batch_mode and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(cfg, quick=not args.cpu_full)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

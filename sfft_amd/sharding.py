@@ -7,10 +7,17 @@ job and the only collective is an all_gather of one fixed-size record per pair
     [pair_id, status, milliseconds, Solution[NEQ]]
 (RCCL over xGMI on GPUs, gloo on CPU in the tests).  Difference images never leave their GPU.
 """
+import itertools
+import threading
+import time
+
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_pair_ids", "pack_record", "gather_records"]
+__all__ = ["shard_pair_ids", "pack_record", "gather_records", "run_shard", "STATUS_OK", "STATUS_SINGULAR", "STATUS_ERROR"]
+
+# per-pair status in the gathered record: the C ABI's return code of the pair's sfft_subtract (include/sfft_amd.h)
+STATUS_OK, STATUS_ERROR, STATUS_SINGULAR = 0, -1, -4
 
 
 def shard_pair_ids(n_pairs, rank, world_size):
@@ -49,3 +56,43 @@ def gather_records(local_records, n_pairs, neq, device):
     if not bool(seen.all()):
         raise RuntimeError("gather_records: missing pairs %s" % (torch.where(~seen)[0].tolist(),))
     return table
+
+
+def run_shard(pair_ids, n_workers, work_fn, neq, device):
+    """Process this rank's shard with `n_workers` host threads that pull the next pair id from a shared queue -- the
+    reference's scheme (one thread per device queue taking tasks from a shared status table,
+    sfft/MultiEasyCrowdedPacket.py:361-399, 698-710), with several queues on one GPU.
+
+    work_fn(worker_index, pair_id) -> Solution tensor [neq]; it raises on failure (numpy.linalg.LinAlgError for a singular
+    system, as the operators do).  A failed pair does not stop the shard: its record carries the status code and a zero
+    solution, and the worker's plan goes on to the next pair.  Returns one record per pair, in shard order."""
+    import numpy as np
+    pair_ids = list(pair_ids)
+    records = [None] * len(pair_ids)
+    nxt = itertools.count()
+    lock = threading.Lock()
+
+    def worker(wi):
+        while True:
+            with lock:
+                k = next(nxt)
+            if k >= len(pair_ids):
+                return
+            pid = pair_ids[k]
+            t0 = time.perf_counter()
+            try:
+                sol = work_fn(wi, pid)
+                status = STATUS_OK
+            except np.linalg.LinAlgError:
+                sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_SINGULAR
+            except Exception:
+                sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_ERROR
+            records[k] = pack_record(pid, status, (time.perf_counter() - t0) * 1e3, sol)
+
+    if n_workers <= 1:
+        worker(0)
+    else:
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(n_workers)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    return records

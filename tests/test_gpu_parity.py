@@ -427,6 +427,148 @@ def test_large_shapes_properties(dev, cfg):
 
 
 # ------------------------------------------------------------------------------------------------
+# (d2) BASELINE config 3: B-spline kernel, degree 2 with 2 x 2 internal knots (Fij = 25, NEQ 7231, 7207 solved), constant
+# scaling, polynomial background of degree 2, KerHW 8 -- at 6144 x 6144 by properties, and on a 6144 x 96 strip (same system
+# size: the 256-column outer-blocked Cholesky with the rank-256 chol_syrk update, 325 Omega passes) against the oracle.
+# ------------------------------------------------------------------------------------------------
+def _config3(N0, N1, dev):
+    from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC
+    kx, ky = [N0 / 3 + 0.5, 2 * N0 / 3 + 0.5], [N1 / 3 + 0.5, 2 * N1 / 3 + 0.5]
+    cfg = BSSC.SSC(NX=N0, NY=N1, KerHW=8, KerSpType="B-Spline", KerSpDegree=2, KerIntKnotX=kx, KerIntKnotY=ky,
+                   SEPARATE_SCALING=True, ScaSpDegree=0, BkgSpType="Polynomial", BkgSpDegree=2, VERBOSE_LEVEL=0,
+                   CUDA_DEVICE_4SUBTRACT=dev.index)
+    assert (cfg[0]["Fij"], cfg[0]["NEQ"], cfg[0]["NEQt"], cfg[0]["SCALING_MODE"]) == (25, 7231, 7207, "SEPARATE-CONSTANT")
+    return cfg, kx, ky
+
+
+def _blob_pair(N0, N1, seed, ratio=1.25, sky=2.0):
+    rng = np.random.default_rng(seed)
+    x = np.linspace(0, N0 / 100.0 * np.pi, N0)[:, None]
+    y = np.linspace(0, max(N1 / 110.0, 1.0) * np.pi, N1)[None, :]
+    base = 80.0 * (np.sin(x) * np.cos(y)) ** 8
+    REF = base + rng.normal(0, 1.0, (N0, N1))
+    SCI = ratio * (0.6 * base + 0.2 * np.roll(base, 1, 0) + 0.2 * np.roll(base, -1, 1)) + sky + rng.normal(0, 1.0, (N0, N1))
+    keep = base > 0.5
+    return REF, SCI, np.where(keep, REF, 0.0), np.where(keep, SCI, 0.0)
+
+
+def _tied_residual(LH, rhs, sol, ij00):
+    """Residual of the tied system P^T A P x_t = P^T b (TweakLS, BSplineSFFT.py:2201-2272) at the restored solution x = P x_t."""
+    r = LH @ sol - rhs
+    tied = r[ij00].sum()
+    keep = np.ones(r.shape[0], dtype=bool)
+    keep[ij00] = False
+    return max(float(np.max(np.abs(r[keep]))), abs(float(tied)))
+
+
+def test_config3_bspline_6144(dev):
+    from sfft_amd.plan import clear_plan_cache
+    from sfft_amd.BSplineSFFT import GeneralSFFTSubtract_PureCupy as BGSSPC
+    clear_plan_cache()
+    N = 6144
+    cfg, _, _ = _config3(N, N, dev)
+    plan = cfg[1]["plan"]
+    REF, SCI, mREF, mSCI = _blob_pair(N, N, 3, sky=0.0)   # sky-subtracted frames: a sky step at the mask edge is not in the model
+    R, S = _to(dev, REF), _to(dev, SCI)
+    w, L, Fab, Fij = 8, 17, 289, 25
+    ij00 = np.arange(w * L + w, Fij * Fab, Fab)
+    PN = float(N) * float(N)
+    # (1) the B-spline factors are a partition of unity: equal centre coefficients are the identity kernel
+    sol = np.zeros(plan.NEQ)
+    sol[ij00] = PN
+    sol[plan.Fijab] = 2.5
+    D = plan.apply(R, S, _to(dev, sol)).cpu().numpy()
+    assert rms(D - (SCI - REF - 2.5)) <= 1e-10 * rms(SCI)
+    # (2) the same for a shift kernel
+    a, b = 5, -8
+    sol = np.zeros(plan.NEQ)
+    sol[ij00] = PN
+    sol[ij00 - (w * L + w) + (a + w) * L + (b + w)] = PN
+    D = plan.apply(R, S, _to(dev, sol)).cpu().numpy()
+    assert rms(D - (SCI - np.roll(REF, (a, b), (0, 1)))) <= 1e-10 * rms(SCI)
+    del D
+    # (3) end to end on a masked pair that differs from the full pair (the apply pass's transforms run on the second stream)
+    solution, diff, _ = BGSSPC.GSS(R, S, _to(dev, mREF), _to(dev, mSCI), cfg, VERBOSE_LEVEL=0)
+    assert plan.query("LAST_SOLVER") == 1
+    LH, rhs = plan.get_system()
+    assert float((LH - LH.T).abs().max() / LH.abs().max()) <= 1e-13
+    sol_h = solution.cpu().numpy()
+    assert np.all(sol_h[ij00] == sol_h[ij00[0]])                     # tied scaling
+    res = _tied_residual(LH.cpu().numpy(), rhs.cpu().numpy(), sol_h, ij00)
+    assert res <= 1e-6 * float(rhs.abs().max())
+    del LH
+    d = diff.cpu().numpy()
+    assert np.isfinite(d).all() and rms(d) < 2.0
+    assert abs(sol_h[ij00[0]] / PN - 1.25) < 0.05
+    # apply is deterministic and linear in the solution at this size too
+    D1 = plan.apply(R, S, solution).cpu().numpy()
+    assert np.array_equal(D1, d)
+    clear_plan_cache()
+
+
+def test_config3_bspline_strip_matches_oracle(dev):
+    """6144 x 96 strip with config 3's basis: the same 7231-unknown system as the full frame (outer-blocked Cholesky, 325 Omega
+    passes, tied scaling), small enough for the oracle: LHMAT / RHb <= 1e-11, apply-only DIFF <= 1e-10 RMS(J), end to end <= 1e-6."""
+    from oracle import bspline_oracle as BO
+    from sfft_amd.plan import clear_plan_cache
+    from sfft_amd.BSplineSFFT import GeneralSFFTSubtract as BGSS, ElementalSFFTSubtract as BESS
+    clear_plan_cache()
+    N0, N1 = 6144, 96
+    cfg, kx, ky = _config3(N0, N1, dev)
+    plan = cfg[1]["plan"]
+    REF, SCI, mREF, mSCI = _blob_pair(N0, N1, 4)
+    basis = BO.make_basis(N0, N1, "B-Spline", 2, kx, ky, "Polynomial", 2)
+    p = BO.SSC(N0, N1, 8, basis, True)
+    assert p["NEQ"] == 7231
+    ncpu = min(32, os.cpu_count() or 1)
+    LH_o, rhs_o = BO.establish_system(mREF, mSCI, p, basis, workers=ncpu)
+    sol, D, _ = BGSS.GSS(REF, SCI, mREF, mSCI, cfg, VERBOSE_LEVEL=0)
+    assert plan.query("LAST_SOLVER") == 1
+    LH, rhs = plan.get_system()
+    assert np.max(np.abs(LH.cpu().numpy() - LH_o)) <= 1e-11 * np.max(np.abs(LH_o))
+    assert np.max(np.abs(rhs.cpu().numpy() - rhs_o)) <= 1e-11 * np.max(np.abs(rhs_o))
+    del LH
+    sol_o = BO.solve_system(LH_o, rhs_o, p)
+    D_o = BO.subtract(REF, SCI, sol_o, p, basis, workers=ncpu)
+    Da = BESS.ESS(REF, SCI, cfg, SFFTSolution=sol_o, Subtract=True, VERBOSE_LEVEL=0)[1]
+    assert rms(Da - D_o) <= 1e-10 * rms(SCI)
+    assert rel_rms_err(D, D_o) <= 1e-6
+    ij00 = np.arange(8 * 17 + 8, 25 * 289, 289)
+    assert np.all(sol[ij00] == sol[ij00[0]])
+    clear_plan_cache()
+
+
+# ------------------------------------------------------------------------------------------------
+# (d3) BASELINE config 2 at FULL size against the oracle: 4096 x 4096, KerHW 8, orders 2/2.  The oracle (pinned by the
+# reference-made fixtures, including two at this kernel geometry) builds the 1740 x 1740 system and the difference image
+# on the host cores in a few minutes; every Omega / Gamma / Theta lag patch, the Phi / Delta closed forms and the
+# mixed-domain apply are compared element by element at the size the benchmark runs.
+# ------------------------------------------------------------------------------------------------
+def test_config2_full_size_matches_oracle(dev, big):
+    from oracle import sfft_oracle as O
+    plan, pair, g = big
+    N = plan.N0
+    ncpu = min(64, os.cpu_count() or 1)
+    p = O.SSC(N, N, 8, 2, 2, True)
+    LH_o, rhs_o = O.establish_system(pair["mREF"], pair["mSCI"], p, workers=ncpu)
+    sol, diff = plan.subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"])
+    LH, rhs = plan.get_system()
+    LH, rhs = LH.cpu().numpy(), rhs.cpu().numpy()
+    assert np.max(np.abs(LH - LH_o)) <= 1e-11 * np.max(np.abs(LH_o))
+    assert np.max(np.abs(rhs - rhs_o)) <= 1e-11 * np.max(np.abs(rhs_o))
+    nk = p["Fijab"]      # block by block: the kernel block is far smaller than the background block
+    for blk, blk_o in ((LH[:nk, :nk], LH_o[:nk, :nk]), (LH[:nk, nk:], LH_o[:nk, nk:]), (LH[nk:, :nk], LH_o[nk:, :nk]),
+                       (LH[nk:, nk:], LH_o[nk:, nk:]), (rhs[:nk], rhs_o[:nk]), (rhs[nk:], rhs_o[nk:])):
+        assert np.max(np.abs(blk - blk_o)) <= 1e-11 * np.max(np.abs(blk_o))
+    # apply-only with the oracle's own solution, then end to end
+    sol_o = O.solve_system(LH_o, rhs_o, p)
+    D_o = O.ESS(pair["REF"], pair["SCI"], p, sol_o, True, ncpu)[1]
+    Da = plan.apply(g["REF"], g["SCI"], _to(dev, sol_o)).cpu().numpy()
+    assert rms(Da - D_o) <= 1e-10 * rms(pair["SCI"])
+    assert rel_rms_err(diff.cpu().numpy(), D_o) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
 # (e) B-spline form (sfft_amd.BSplineSFFT): golden vectors from the reference's dev-version Numpy backend
 # ------------------------------------------------------------------------------------------------
 from _golden import bspline_golden_names, load_bspline_golden
@@ -612,13 +754,20 @@ def test_kernel_regularisation_matches_oracle(dev, mode):
     else:
         D_o = BO.subtract(pair["REF"], pair["SCI"], sol_o, BO.SSC(N0, N1, w, basis, mode != "ENTANGLED"), basis, workers=8)
     assert rel_rms_err(D, D_o) <= 1e-6
-    # switching the penalty off on the same (cached) plan restores the plain system
+    # the penalty belongs to the config, not to the (shared, cached) plan: a second config of the same geometry without it
+    # solves the plain system, and the first config still solves the penalised one afterwards (the reference derives REGMAT
+    # from each config's own parameter dictionary at ESS time)
+    from sfft_amd.BSplineSFFT import ElementalSFFTSubtract as BESS
     kw.update(REGULARIZE_KERNEL=False)
     cfg2 = BSSC.SSC(NX=N0, NY=N1, KerHW=w, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index, **kw)
     assert cfg2[1]["plan"] is plan
-    plan.solve(_to(dev, pair["mREF"]), _to(dev, pair["mSCI"]))
+    sol2 = BESS.ESS(pair["mREF"], pair["mSCI"], cfg2, VERBOSE_LEVEL=0)[0]
     LH2, _ = plan.get_system()
     assert np.max(np.abs(LH2.cpu().numpy()[:nk, :nk] - (LH_o - LAM * REG)[:nk, :nk])) <= 1e-11 * np.max(np.abs(LH_o[:nk, :nk]))
+    sol1 = BESS.ESS(pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)[0]
+    LH1, _ = plan.get_system()
+    assert np.max(np.abs(LH1.cpu().numpy()[:nk, :nk] - LH_o[:nk, :nk])) <= 1e-11 * np.max(np.abs(LH_o[:nk, :nk]))
+    assert np.array_equal(sol1, sol.cpu().numpy() if hasattr(sol, "cpu") else sol) and not np.array_equal(sol1, sol2)
 
 
 def test_varying_scaling_large_shape_properties(dev):

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sfft_amd.sharding import shard_pair_ids, pack_record, gather_records
+from sfft_amd.sharding import shard_pair_ids, pack_record, gather_records, run_shard, STATUS_OK, STATUS_SINGULAR
 
 
 def test_round_robin_sharding_covers_all_pairs():
@@ -74,3 +74,41 @@ def test_single_process_gather_without_process_group():
     assert table.shape == (3, 7) and table[2, 3] == 2.0
     with pytest.raises(RuntimeError, match="missing pairs"):
         gather_records(recs[:2], 3, 4, torch.device("cpu"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# config-4 batch mode (bench.py --pairs M): uneven shards, worker threads pulling from the shard's queue, real status codes
+# ---------------------------------------------------------------------------------------------------
+def _batch_worker(rank, world, port, n_pairs, bad_pair, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen = []
+
+        def work(wi, pid):
+            seen.append((wi, pid))
+            if pid == bad_pair:
+                raise np.linalg.LinAlgError("Singular matrix")
+            return torch.from_numpy(_solve_pair(pid))
+        recs = run_shard(shard_pair_ids(n_pairs, rank, world), 2, work, 10, torch.device("cpu"))
+        assert sorted(p for _, p in seen) == shard_pair_ids(n_pairs, rank, world)
+        table = gather_records(recs, n_pairs, 10, torch.device("cpu"))
+        np.save(os.path.join(out_dir, "batch_%d.npy" % rank), table.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_batch_with_uneven_shards_and_a_failed_pair(tmp_path):
+    n_pairs, world, bad = 7, 2, 4            # shards of 4 and 3 pairs; pair 4 fails and must not stop its shard
+    port = _free_port()
+    mp.spawn(_batch_worker, args=(world, port, n_pairs, bad, str(tmp_path)), nprocs=world, join=True)
+    t0 = np.load(tmp_path / "batch_0.npy")
+    assert np.array_equal(t0, np.load(tmp_path / "batch_1.npy"))
+    assert t0.shape == (n_pairs, 13) and list(t0[:, 0]) == list(range(n_pairs))
+    for pid in range(n_pairs):
+        if pid == bad:
+            assert t0[pid, 1] == STATUS_SINGULAR and not t0[pid, 3:].any()
+        else:
+            assert t0[pid, 1] == STATUS_OK and np.array_equal(t0[pid, 3:], _solve_pair(pid))
+        assert t0[pid, 2] > 0.0              # measured milliseconds of that pair
