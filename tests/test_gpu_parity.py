@@ -296,6 +296,18 @@ def test_error_behaviour(dev):
     # exactly singular system (all-zero masked pair): Cholesky fails, LU meets a zero pivot -> LinAlgError like numpy
     with pytest.raises(np.linalg.LinAlgError):
         ElementalSFFTSubtract.ESS(b, b, cfg, VERBOSE_LEVEL=0)
+    # ... and a failed pair must not poison the handle: the same config / plan then solves a good pair, through
+    # GSS (deferred status check) and through ESS, to the same result as a fresh plan
+    from sfft_amd.plan import Plan
+    from sfft_amd.utils.synthetic import make_pair
+    good = make_pair(64, 64, seed=3, mask=False)
+    with pytest.raises(np.linalg.LinAlgError):
+        GeneralSFFTSubtract.GSS(b, b, b, b, cfg, VERBOSE_LEVEL=0)
+    sol, diff, _ = GeneralSFFTSubtract.GSS(good["REF"], good["SCI"], good["mREF"], good["mSCI"], cfg, VERBOSE_LEVEL=0)
+    fresh = Plan(64, 64, 2, 1, 1, True, device=dev.index)
+    sol_f, diff_f = fresh.subtract(t(good["REF"]), t(good["SCI"]), t(good["mREF"]), t(good["mSCI"]))
+    assert np.array_equal(sol, sol_f.cpu().numpy()) and np.array_equal(diff, diff_f.cpu().numpy())
+    assert cfg[1]["plan"].query("LAST_SOLVER") == 1 and np.isfinite(diff).all()
     # unsupported size is reported, not mis-computed
     with pytest.raises(Exception, match="not supported by this build"):
         SingleSFFTConfigure.SSC(10007, 64, 2, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)   # prime > 4096
