@@ -166,6 +166,11 @@ struct sfft_plan {
     double* d_winv = nullptr;           // [nblk][CB][CB] inverses of the diagonal blocks of the Cholesky factor
     unsigned int* d_bflags = nullptr;   // [nblk] "x_b published" flags of the back substitution, stamped with the solve's epoch
     unsigned int* d_epoch = nullptr;    // solve counter behind the flag stamps (device resident: the launch chain has constant arguments)
+    unsigned int* d_tflags = nullptr;   // [nbc][nbc + 1] "tile factored" flags of chol_dataflow, [nbc * (nbc + 1)] = its task counter
+    double* d_w16 = nullptr;            // [nbc][4][16][16] inverses of the 16 x 16 diagonal sub-blocks of the factor (chol_dataflow's MFMA triangular solves)
+    unsigned long long* d_trace = nullptr;   // env SFFT_DF_TRACE=1: [nbc][16] wall-clock stamps of the critical path of chol_dataflow (development aid)
+    int dataflow = 1;                   // env SFFT_CHOL_DF=0: launch-per-step factorisation (A/B testing)
+    int df_groups = 64;                 // env SFFT_CHOL_DF_WG: persistent workgroups of chol_dataflow
     hipGraphExec_t chol_exec = nullptr; // the factorisation + back substitution chain, captured once (env SFFT_NO_GRAPH=1: plain launches)
     int use_graph = 1;
     int* h_status = nullptr;            // pinned: status word of the most recent attempt
@@ -812,7 +817,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->fa.tie_first = KerHW * p->L + KerHW; p->fa.tie_stride = p->Fab; p->fa.tie_cnt = (p->mode == 2) ? p->Fij : 0;
     }
     PLAN_TRY(dev_alloc(p, &p->d_spec, (size_t)(p->Fij + 1 + p->nsca) * N0 * p->Nhp));
-    p->ld = (p->NEQfs + 1 + 3) & ~3;
+    p->ld = (p->NEQfs + 1 + 15) & ~15;          // rows are whole 128-byte lines (chol_dataflow hands tiles between workgroups)
     PLAN_TRY(dev_alloc(p, &p->d_A, (size_t)(p->NEQfs + 1) * p->ld));
     PLAN_TRY(dev_alloc(p, &p->d_dbuf, (size_t)3 * CB * CB));      // two hand-over blocks of the two-kernel path + the raw block of chol_step
     PLAN_TRY(dev_alloc(p, &p->d_xv, (size_t)p->NEQfs));
@@ -828,6 +833,12 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         *p->h_status = 0;
         PLAN_TRY(dev_alloc(p, &p->d_epoch, (size_t)1));
         PLAN_HIP(hipMemset(p->d_epoch, 0, sizeof(unsigned int)));
+        PLAN_TRY(dev_alloc(p, &p->d_tflags, (size_t)nblk_b * (nblk_b + 1) + 1));
+        PLAN_HIP(hipMemset(p->d_tflags, 0, ((size_t)nblk_b * (nblk_b + 1) + 1) * sizeof(unsigned int)));
+        PLAN_TRY(dev_alloc(p, &p->d_w16, (size_t)nblk_b * 1024));
+        if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
+        if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
+        if (const char* ev = getenv("SFFT_CHOL_DF_WG")) p->df_groups = std::max(1, atoi(ev));
         if (const char* ev = getenv("SFFT_FUSED_STEP")) p->fused_step = atoi(ev);
         if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
         int ncu = 0;
@@ -983,7 +994,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_cyp, p->d_rowmomI, p->d_gamR};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_cyp, p->d_rowmomI, p->d_gamR};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1344,10 +1355,19 @@ static int run_fill(sfft_plan* p, hipStream_t s, bool lower_only)
 static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s)
 {
     const int n = p->NEQfs;
-    hipLaunchKernelGGL(chol_begin, dim3(1), dim3(1), 0, s, p->d_epoch);
+    const int nbc = (n + CB - 1) / CB;
+    unsigned int* d_queue = p->d_tflags + (size_t)nbc * (nbc + 1);
+    hipLaunchKernelGGL(chol_begin, dim3(1), dim3(1), 0, s, p->d_epoch, d_queue);
+    const bool dataflow = p->dataflow && n < p->chol_outer_min;
+    if (dataflow) {
+        // the whole factorisation as one launch of persistent workgroups (see chol_dataflow)
+        const int ntask = 2 + (nbc - 1) * (nbc + 2) / 2;
+        hipLaunchKernelGGL(chol_dataflow, dim3(std::min(p->df_groups, ntask)), dim3(256), 0, s, p->d_A, p->ld, n, p->d_tflags, d_queue,
+                           p->d_epoch, p->d_status, p->d_rd, p->d_w16, p->d_trace);
+    } else
     hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
     int step = 0;
-    int kb = 0;                 // first column not yet factored
+    int kb = dataflow ? n : 0;  // first column not yet factored
     if (p->fused_step && n >= p->chol_outer_min) {
         // outer blocks of 256 columns (see chol_syrk): the inner steps stay inside the block, one rank-256 update per block
         const int OB = 4 * CB;
@@ -1497,6 +1517,18 @@ static int solve_check(sfft_plan* p, double* d_solution, hipStream_t s, bool* re
 {
     if (redone) *redone = false;
     p->last_solver = p->attempt_lu ? 2 : 1;
+    if (p->d_trace && !p->attempt_lu) {      // development aid (SFFT_DF_TRACE=1): critical-path stamps of chol_dataflow, in 10 ns ticks
+        const int nbc = (p->NEQfs + CB - 1) / CB;
+        std::vector<unsigned long long> h((size_t)nbc * 16);
+        if (hipMemcpy(h.data(), p->d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            const unsigned long long t0 = h[8];
+            for (int j = 0; j < nbc; ++j) {
+                fprintf(stderr, "df_trace j=%d", j);
+                for (int k = 0; k < 9; ++k) fprintf(stderr, " %lld", h[(size_t)j * 16 + k] ? (long long)(h[(size_t)j * 16 + k] - t0) : -1LL);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     if (*p->h_status == 0) return SFFT_OK;
     if (p->attempt_lu) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
     int rc;

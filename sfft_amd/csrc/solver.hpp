@@ -38,10 +38,11 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 }
 
 // first node of a solve: a new stamp for this solve's flag hand-offs (never 0 in its upper 24 bits)
-__global__ void chol_begin(unsigned int* epoch_ctr)
+__global__ void chol_begin(unsigned int* epoch_ctr, unsigned int* queue)
 {
     unsigned int v = (*epoch_ctr + 1u) & 0xFFFFFFu;
     *epoch_ctr = v ? v : 1u;
+    *queue = 0u;                            // task counter of chol_dataflow
 }
 
 // One panel step.  Every workgroup factors the 64x64 diagonal block (right-looking; thread (i, cg) owns elements
@@ -469,6 +470,355 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
         const int cc = cg + 4 * q;
         if (i < ni) A[(size_t)(i0 + i) * ld + k + cc] = p[q];
     }
+}
+
+// ---- the whole factorisation as ONE launch: dataflow over 64 x 64 tiles ------------------------------------------------
+// Left-looking tile Cholesky (with the border row riding along) executed by a fixed number of persistent workgroups that
+// pull tasks from a device-side queue (an atomic counter) in a topological order; a task waits for the tiles it consumes
+// through one epoch-stamped flag per tile (release by the producer after its stores, acquire by the consumer's lane 0,
+// agent scope) -- no host round trips, no launch boundaries, and the panel of step j + 1 overlaps the updates of step j.
+//
+//   PT(j):  owns the sub-diagonal tile X = (j, j-1) and the diagonal tile D = (j, j).  It accumulates
+//           X -= L(j,k) L(j-1,k)^T and D -= L(j,k) L(j,k)^T for k < j-1 while those tiles arrive, then -- the critical path --
+//           waits for the factor of D(j-1), solves X L(j-1,j-1)^T = X, applies D -= X X^T from its own registers, factors D
+//           and publishes both.  One hand-off per block step instead of two (trsm -> update -> factor stay in one workgroup).
+//   TR(i,j): every other tile (rows i >= j+2 and the border row): C = A(i,j) - sum_{k<j} L(i,k) L(j,k)^T, then X L(j,j)^T = C.
+//
+// Task order: PT(0); then for j = 1 .. nbc-1: PT(j), TR(j+1 .. nbc-1, j-1), TR(border, j-1); last TR(border, nbc-1).  Every
+// task only waits for tasks earlier in the order, and a task is only ever taken by a workgroup that is already running, so
+// the kernel cannot deadlock however few of its workgroups are resident (other streams' kernels may hold the other CUs);
+// all spins are bounded and report through `status` (-> pivoted-LU fallback) rather than hang.
+// Tile rows are whole 128-byte lines (ld is a multiple of 16 doubles, tiles start at multiples of 64 columns), so a tile's
+// final values never share a line with data another workgroup is still rewriting.
+#define DF_EPOCH_TAG 0x7Eu
+struct DfGeom { int n, nbc, ld; };
+__device__ __forceinline__ int df_flag_id(const DfGeom& g, int i, int j) { return j * (g.nbc + 1) + i; }    // i = nbc: the border row
+
+// Hand-off protocol (placement independent; the per-XCD L2s are not coherent and a CU's L1 is never refreshed by other CUs):
+//   producer: payload with write-through (sc1) 16-byte stores, every storing wave drains its stores (s_waitcnt vmcnt(0)),
+//             __syncthreads(), then ONE lane stores the flag (relaxed, agent scope) -- no release fence needed;
+//   consumer: ONE lane polls the flag with relaxed agent-scope loads (+ s_sleep), ONE agent-scope acquire after the match
+//             (drops this CU's stale L1 lines), __syncthreads(), then plain loads by every wave.
+typedef unsigned int df_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void df_poll(const unsigned int* flags, int id, unsigned int epoch, int* __restrict__ status)
+{
+    long long spins = 0;
+    while (__hip_atomic_load(flags + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1LL << 26)) { atomicOr(status, 4); break; }      // bounded: a protocol error reports (-> LU fallback), never hangs
+    }
+}
+__device__ __forceinline__ void df_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+// all threads call: drain this wave's payload stores, meet, then lane 0 stamps the flag
+__device__ __forceinline__ void df_publish(unsigned int* flags, int id, unsigned int epoch, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + id, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// write-through store of the LDS tile T (rows < nr) to the tile of A at (r0, c0): 16 bytes per lane, whole rows of 512 bytes
+// (columns beyond the system's last one land in the row padding -- never past the row -- or in the unused upper triangle)
+__device__ __forceinline__ void df_store_tile(__amdgpu_buffer_rsrc_t rsrc, int ld, int r0, int nr, int c0, const double (*T)[CB + 1], int tid)
+{
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = tid + 256 * it, r = e >> 5, c = 2 * (e & 31);
+        const double v0 = T[r][c], v1 = T[r][c + 1];
+        df_u4 pk;
+        pk.x = (unsigned int)__double2loint(v0); pk.y = (unsigned int)__double2hiint(v0);
+        pk.z = (unsigned int)__double2loint(v1); pk.w = (unsigned int)__double2hiint(v1);
+        if (r < nr && c0 + c < ld) __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (int)((((size_t)(r0 + r)) * ld + c0 + c) * sizeof(double)), 0, /*aux: sc1*/ 16);
+    }
+}
+
+// load the 64 x 64 tile with first row r0 (nr valid rows, the rest read as zero) and first column c0 into LDS [64][65]
+__device__ __forceinline__ void df_load_tile(const double* __restrict__ A, int ld, int r0, int nr, int c0, double (*dst)[CB + 1], int tid)
+{
+    double v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, i = e >> 6, t = e & 63;
+        v[it] = A[(size_t)(r0 + min(i, nr - 1)) * ld + c0 + t];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, i = e >> 6, t = e & 63;
+        dst[i][t] = (i < nr) ? v[it] : 0.0;
+    }
+}
+
+
+// Inverses of the four 16 x 16 diagonal sub-blocks of the factor held in L.Dl (with L.rdiag), by ONE wave: lane 16 b + c owns
+// column c of W_bb = L_bb^-1 and runs the forward substitution down that column (16 steps, all lanes in lockstep).  Result in
+// W16t[b][c][i] = W_bb[i][c].  These are what lets every triangular solve against this block run on the matrix cores.
+#define W16_LD 17
+__device__ __forceinline__ void chol_inv16(const PanelLds& L, double (*W16t)[16][W16_LD], int lane)
+{
+    const int b = lane >> 4, c = lane & 15;
+    double w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double s0 = (i == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < i; ++t) {
+            const double lv = L.Dl[16 * b + i][16 * b + t];
+            if (t & 1) s1 = fma(-lv, w[t], s1); else s0 = fma(-lv, w[t], s0);
+        }
+        w[i] = (i >= c) ? (s0 + s1) * L.rdiag[16 * b + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) W16t[b][c][i] = w[i];
+}
+
+// X L^T = C for the 64 x 64 tile C held in T (in place), L in Dl (identity beyond its last row), W16t as above.  Each wave owns
+// 16 rows of T and needs no workgroup barrier: for the four 16-column blocks in turn, Y_b = C_b - sum_{b' < b} X_b' L_bb'^T and
+// X_b = Y_b W_bb^T, all as v_mfma_f64_16x16x4_f64 (40 per wave).  The 16 x 16 inverses are only used block-diagonally; the
+// coupling between blocks is by substitution.
+__device__ __forceinline__ void df_trsm_mfma(double (*T)[CB + 1], const double (*Dl)[CB + 1], const double (*W16t)[16][W16_LD], int wv, int ln, int lk)
+{
+    const int R0 = 16 * wv;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        d4s acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = T[R0 + lk + 4 * q][16 * b + ln];
+#pragma unroll
+        for (int bp = 0; bp < b; ++bp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[R0 + ln][16 * bp + 4 * ks + lk], Dl[16 * b + ln][16 * bp + 4 * ks + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[R0 + lk + 4 * q][16 * b + ln] = acc[q];           // Y_b
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        d4s x = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(T[R0 + ln][16 * b + 4 * ks + lk], W16t[b][4 * ks + lk][ln], x, 0, 0, 0);     // B[k][j] = W_bb[j][k]
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[R0 + lk + 4 * q][16 * b + ln] = x[q];             // X_b
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int ld, int n, unsigned int* flags, unsigned int* queue,
+                                                     const unsigned int* __restrict__ epoch_ctr, int* __restrict__ status,
+                                                     double* __restrict__ rd, double* __restrict__ w16, unsigned long long* __restrict__ trace)
+{
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD];
+    __shared__ int s_task;
+#define DF_TRACE(slot) do { if (trace && tid == 0) trace[(size_t)bj * 16 + (slot)] = wall_clock64(); } while (0)
+    double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // operand tile / the accumulated tile T
+    double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // operand tile / start of the PanelLds
+    PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
+    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
+    const unsigned int epoch = (*epoch_ctr << 8) | DF_EPOCH_TAG;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
+    const int ti = tid >> 2, cg = tid & 3;
+    DfGeom g;
+    g.n = n; g.ld = ld; g.nbc = (n + CB - 1) / CB;
+    const int nbc = g.nbc;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((size_t)(n + 1) * ld * sizeof(double)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)w16, 0, (int)((size_t)nbc * 1024 * sizeof(double)), 0x00020000);
+    for (;;) {
+        __syncthreads();                    // s_task (and the LDS tiles) of the previous task are no longer read
+        if (tid == 0) s_task = (int)atomicAdd(queue, 1u);
+        __syncthreads();
+        int t = s_task;
+        // ---- decode: group 0 = {PT(0)}, group j (1 <= j < nbc) = {PT(j), TR(j+1..nbc-1, j-1), TR(border, j-1)}, last = {TR(border, nbc-1)}
+        int kind = -1, bi = 0, bj = 0;      // kind 0: PT(bj); kind 1: TR(bi, bj)
+        if (t == 0) { kind = 0; bj = 0; }
+        else {
+            t -= 1;
+            int j = 1;
+            for (; j < nbc; ++j) {
+                const int cnt = nbc - j + 1;
+                if (t < cnt) break;
+                t -= cnt;
+            }
+            if (j < nbc) {
+                if (t == 0) { kind = 0; bj = j; }
+                else { kind = 1; bj = j - 1; bi = j + t; }       // t = 1 .. nbc-j: rows j+1 .. nbc-1, then nbc (= border)
+            } else if (t == 0) { kind = 1; bj = nbc - 1; bi = nbc; }
+        }
+        if (kind < 0) return;               // queue exhausted
+
+        if (kind == 1) {
+            // ================= TR(bi, bj): C = A(bi,bj) - sum_k L(bi,k) L(bj,k)^T;  X L(bj,bj)^T = C =================
+            const int c0 = bj * CB, nbj = min(CB, n - c0);
+            const int r0 = (bi == nbc) ? n : bi * CB;
+            const int ni = (bi == nbc) ? 1 : min(CB, n - r0);
+            d4s c[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * wv + lk + 4 * q, jc = 16 * jt + ln;
+                    const double v = A[(size_t)(r0 + min(i, ni - 1)) * ld + c0 + min(jc, nbj - 1)];
+                    c[jt][q] = (i < ni && jc < nbj) ? v : 0.0;
+                }
+            for (int k = 0; k < bj; ++k) {
+                if (tid == 0) { df_poll(flags, df_flag_id(g, bi, k), epoch, status); df_poll(flags, df_flag_id(g, bj, k), epoch, status); df_acquire(); }
+                __syncthreads();            // (also: the previous iteration's MFMAs have read Li / Lj)
+                df_load_tile(A, ld, r0, ni, k * CB, Li, tid);
+                df_load_tile(A, ld, c0, nbj, k * CB, Lj, tid);
+                __syncthreads();
+#pragma unroll 4
+                for (int ks = 0; ks < CB / 4; ++ks) {
+                    const double av = -Li[16 * wv + ln][4 * ks + lk];
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) c[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Lj[16 * jt + ln][4 * ks + lk], c[jt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            double (*T)[CB + 1] = Li;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) T[16 * wv + lk + 4 * q][16 * jt + ln] = c[jt][q];
+            if (tid == 0) { df_poll(flags, df_flag_id(g, bj, bj), epoch, status); df_acquire(); }
+            __syncthreads();
+            {   // the factor of the diagonal block (identity beyond nbj) and the inverses of its 16 x 16 diagonal sub-blocks
+                double dv[16], wvv[4];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int e = tid + 256 * it, i = e >> 6, q = e & 63;
+                    dv[it] = A[(size_t)(c0 + min(i, nbj - 1)) * ld + c0 + min(q, nbj - 1)];
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) wvv[it] = w16[(size_t)bj * 1024 + tid + 256 * it];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int e = tid + 256 * it, i = e >> 6, q = e & 63;
+                    L.Dl[i][q] = (i < nbj && q <= i) ? dv[it] : ((i == q) ? 1.0 : 0.0);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { const int e = tid + 256 * it; W16t[e >> 8][(e >> 4) & 15][e & 15] = wvv[it]; }
+            }
+            __syncthreads();
+            df_trsm_mfma(T, L.Dl, W16t, wv, ln, lk);
+            __syncthreads();
+            df_store_tile(rsrc, ld, r0, ni, c0, T, tid);
+            df_publish(flags, df_flag_id(g, bi, bj), epoch, tid);
+            continue;
+        }
+
+        // ================= PT(bj): X = (bj, bj-1), D = (bj, bj) =================
+        const int j = bj;
+        const int d0 = j * CB, nbd = min(CB, n - d0);           // rows of both tiles, columns of D
+        const int x0 = (j - 1) * CB;                             // columns of X (a full block when j >= 1)
+        d4s cx[4], cd[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * wv + lk + 4 * q, jc = 16 * jt + ln;
+                const int ir = d0 + min(i, nbd - 1);
+                const double vd = A[(size_t)ir * ld + d0 + min(jc, nbd - 1)];
+                const double vx = A[(size_t)ir * ld + (j > 0 ? x0 + jc : d0 + min(jc, nbd - 1))];      // (j = 0 has no X tile: any valid address)
+                cd[jt][q] = (i < nbd && jc <= i) ? vd : 0.0;     // lower triangle of the diagonal tile
+                cx[jt][q] = (j > 0 && i < nbd) ? vx : 0.0;
+            }
+        for (int k = 0; k + 1 < j; ++k) {
+            if (tid == 0) { df_poll(flags, df_flag_id(g, j, k), epoch, status); df_poll(flags, df_flag_id(g, j - 1, k), epoch, status); df_acquire(); }
+            __syncthreads();
+            df_load_tile(A, ld, d0, nbd, k * CB, Li, tid);       // L(j, k)
+            df_load_tile(A, ld, x0, CB, k * CB, Lj, tid);        // L(j-1, k)
+            __syncthreads();
+#pragma unroll 2
+            for (int ks = 0; ks < CB / 4; ++ks) {
+                const double av = -Li[16 * wv + ln][4 * ks + lk];
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    cx[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Lj[16 * jt + ln][4 * ks + lk], cx[jt], 0, 0, 0);
+                    cd[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[16 * jt + ln][4 * ks + lk], cd[jt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        DF_TRACE(0);
+        double (*T)[CB + 1] = Li;
+        if (j > 0) {
+            // ---- critical path: X L(j-1,j-1)^T = X as soon as the factor of D(j-1) is out ----
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) T[16 * wv + lk + 4 * q][16 * jt + ln] = cx[jt][q];
+            if (tid == 0) { df_poll(flags, df_flag_id(g, j - 1, j - 1), epoch, status); DF_TRACE(1); df_acquire(); }
+            __syncthreads();
+            DF_TRACE(2);
+            {
+                double dv[16], wvv[4];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int e = tid + 256 * it, i = e >> 6, q = e & 63;
+                    dv[it] = A[(size_t)(x0 + i) * ld + x0 + q];
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) wvv[it] = w16[(size_t)(j - 1) * 1024 + tid + 256 * it];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int e = tid + 256 * it, i = e >> 6, q = e & 63;
+                    L.Dl[i][q] = (q <= i) ? dv[it] : 0.0;
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { const int e = tid + 256 * it; W16t[e >> 8][(e >> 4) & 15][e & 15] = wvv[it]; }
+            }
+            __syncthreads();
+            DF_TRACE(3);
+            df_trsm_mfma(T, L.Dl, W16t, wv, ln, lk);                         // X: published, and the operand tile of D -= X X^T (rows >= nbd stay zero)
+            DF_TRACE(4);
+            __syncthreads();
+            df_store_tile(rsrc, ld, d0, nbd, x0, T, tid);
+            df_publish(flags, df_flag_id(g, j, j - 1), epoch, tid);
+            DF_TRACE(5);
+#pragma unroll 4
+            for (int ks = 0; ks < CB / 4; ++ks) {
+                const double av = -T[16 * wv + ln][4 * ks + lk];
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) cd[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[16 * jt + ln][4 * ks + lk], cd[jt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // ---- factor D ----
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[16 * wv + lk + 4 * q][16 * jt + ln] = cd[jt][q];
+        __syncthreads();
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cc = cg + 4 * q;
+            a[q] = (ti < nbd && cc <= ti) ? T[ti][cc] : ((ti == cc) ? 1.0 : 0.0);           // identity padding beyond nbd
+        }
+        __syncthreads();                    // T has been read; the PanelLds region may be overwritten
+        DF_TRACE(6);
+        chol_factor_diag(a, L, tid, nbd, true, status);
+        if (wv == 0) {
+            chol_inv16(L, W16t, lane);
+            // publish: lane 16 b + c holds W16t[b][c][0..15] = 128 contiguous bytes of w16[j][b][c][*]
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const double v0 = W16t[lane >> 4][lane & 15][2 * h], v1 = W16t[lane >> 4][lane & 15][2 * h + 1];
+                df_u4 pk;
+                pk.x = (unsigned int)__double2loint(v0); pk.y = (unsigned int)__double2hiint(v0);
+                pk.z = (unsigned int)__double2loint(v1); pk.w = (unsigned int)__double2hiint(v1);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_w, (int)(((size_t)j * 1024 + (size_t)lane * 16 + 2 * h) * sizeof(double)), 0, /*aux: sc1*/ 16);
+            }
+        }
+        DF_TRACE(7);
+        df_store_tile(rsrc, ld, d0, nbd, d0, L.Dl, tid);                     // (Dl is zero above the diagonal)
+        if (tid < nbd) __hip_atomic_store(&rd[d0 + tid], L.rdiag[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        df_publish(flags, df_flag_id(g, j, j), epoch, tid);
+        DF_TRACE(8);
+    }
+#undef DF_TRACE
 }
 
 // ---- outer blocking for large systems ----------------------------------------------------------------------------
