@@ -30,9 +30,29 @@ def build(force=False):
     return LIB
 
 
+def physical_cores():
+    """Physical cores this process may run on (one hardware thread per core: the restatement is barrier-heavy and memory-bound,
+    SMT siblings only add contention)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except Exception:
+        allowed = set(range(os.cpu_count() or 1))
+    seen = set()
+    try:
+        for cpu in allowed:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        return max(1, len(seen))
+    except Exception:
+        return max(1, len(allowed))
+
+
 def lib():
     global _lib
     if _lib is None:
+        # read by libgomp when the library's OpenMP runtime starts: spread the team over the cores, one thread per core
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        os.environ.setdefault("OMP_PLACES", "cores")
         L = ctypes.CDLL(build())
         i, d = ctypes.c_int, ctypes.c_void_p
         L.sfftcpu_solve.argtypes = [i, i, i, i, i, i, d, d, d, d, d, i, d]
@@ -121,29 +141,27 @@ def measure(N0, N1, w, DK, DB, quick=True):
     from sfft_amd.utils.synthetic import make_pair
     pair = make_pair(N0, N1, seed=1234, mask=True, sky=0.0, bkg_scale=0.05)      # the GPU run's pair 0
     args = (pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], w, DK, DB, True)
-    ncores = os.cpu_count() or 1
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    ncores = physical_cores()
 
-    def run(nthreads, warm, n):
-        ts, last = [], None
+    def run(nthreads, warm, n, budget_s):
+        ts, last, t_begin = [], None, time.perf_counter()
         for k in range(warm + n):
             t0 = time.perf_counter()
             sol, diff, st = gss(*args, nthreads=nthreads)
             dt = time.perf_counter() - t0
-            if k >= warm:
+            if k >= warm or (time.perf_counter() - t_begin) > budget_s:
                 ts.append(dt)
                 last = st
+            if (time.perf_counter() - t_begin) > budget_s and ts:        # bounded: never more than the budget + one run
+                break
         return float(np.median(ts)), ts, last, diff
 
     if quick:
-        t_all, ts_all, st_all, diff = run(ncores, 1, 3)
-        t_8, ts_8, st_8, _ = run(8, 0, 1)
+        t_all, ts_all, st_all, diff = run(ncores, 1, 3, 40.0)
+        t_8, ts_8, st_8, _ = run(8, 0, 1, 40.0)
     else:
-        t_all, ts_all, st_all, diff = run(ncores, 3, 10)
-        t_8, ts_8, st_8, _ = run(8, 3, 10)
+        t_all, ts_all, st_all, diff = run(ncores, 3, 10, 300.0)
+        t_8, ts_8, st_8, _ = run(8, 3, 10, 600.0)
     assert np.isfinite(diff).all()
     return {"value": 1.0 / t_all, "unit": "image-pairs/s", "mpix_per_s": N0 * N1 / 1e6 / t_all, "cores": ncores, "kind": "port",
             "restatement": "C++/OpenMP restatement of the reference's Numpy path (oracle/csrc/sfft_cpu.cpp: same 17 functions, c2c fp64 "
@@ -154,7 +172,7 @@ def measure(N0, N1, w, DK, DB, quick=True):
             "threads_8": {"value": 1.0 / t_8, "seconds_per_pair": t_8, "runs": ts_8, "cores": 8,
                           "stage_s": dict(zip(STAGES, [float(v) for v in st_8]))},
             "sample": "one full GSS (solve on the masked pair + apply) of the %dx%d pair with seed 1234 (pair 0 of the GPU batch), KerHW %d, "
-                      "orders %d/%d, no size scaling: %s at %d threads (all cores), %s at 8 threads (the reference's default)"
+                      "orders %d/%d, no size scaling: %s at %d threads (all physical cores, one thread per core), %s at 8 threads (the reference's default)"
                       % (N0, N1, w, DK, DB,
                          "1 warm-up + median of %d" % len(ts_all) if quick else "3 warm-ups + median of %d" % len(ts_all), ncores,
                          "%d run(s)" % len(ts_8) if quick else "3 warm-ups + median of %d" % len(ts_8))}

@@ -143,6 +143,16 @@ struct Fft1d {
     }
 };
 
+// per-thread scratch that lives as long as the thread (OpenMP pool threads persist): a fresh std::vector per parallel region is a
+// 0.5 MB mmap / munmap per thread per transform, which serialises on the process's address-space lock at high thread counts
+struct Scratch {
+    cd* p = nullptr;
+    size_t n = 0;
+    ~Scratch() { std::free(p); }
+    cd* get(size_t need) { if (need > n) { std::free(p); p = (cd*)std::malloc(sizeof(cd) * need); n = need; } return p; }
+};
+thread_local Scratch tl_scratch;
+
 struct Fft2d {
     int N0, N1;
     Fft1d f0, f1;
@@ -154,13 +164,16 @@ struct Fft2d {
         const int CB = 8;   // columns gathered per block for the axis-0 pass
 #pragma omp parallel num_threads(nthreads)
         {
-            std::vector<cd> bx(std::max(N0, N1)), by(std::max(N0, N1));
-            std::vector<cd> blk((size_t)CB * N0);
+            const size_t M = (size_t)std::max(N0, N1);
+            cd* base = tl_scratch.get(2 * M + (size_t)CB * N0);
+            cd* bx = base;
+            cd* by = base + M;
+            cd* blk = base + 2 * M;
 #pragma omp for schedule(static)
             for (int r = 0; r < N0; ++r) {
                 cd* row = a + (size_t)r * N1;
-                std::memcpy(bx.data(), row, sizeof(cd) * N1);
-                const cd* res = f1.run(bx.data(), by.data(), sign);
+                std::memcpy(bx, row, sizeof(cd) * N1);
+                const cd* res = f1.run(bx, by, sign);
                 std::memcpy(row, res, sizeof(cd) * N1);
             }
 #pragma omp for schedule(static)
@@ -169,8 +182,8 @@ struct Fft2d {
                 for (int r = 0; r < N0; ++r)
                     for (int c = 0; c < nc; ++c) blk[(size_t)c * N0 + r] = a[(size_t)r * N1 + c0 + c];
                 for (int c = 0; c < nc; ++c) {
-                    std::memcpy(bx.data(), &blk[(size_t)c * N0], sizeof(cd) * N0);
-                    const cd* res = f0.run(bx.data(), by.data(), sign);
+                    std::memcpy(bx, &blk[(size_t)c * N0], sizeof(cd) * N0);
+                    const cd* res = f0.run(bx, by, sign);
                     for (int r = 0; r < N0; ++r) blk[(size_t)c * N0 + r] = res[r] * scale;
                 }
                 for (int r = 0; r < N0; ++r)
@@ -205,8 +218,7 @@ int lu_solve(double* A, double* b, int n, int nthreads)
                 std::swap(b[k], b[p]);
             }
             const double inv = 1.0 / A[(size_t)k * n + k];
-#pragma omp parallel for num_threads(nthreads) schedule(static) if (n - k > 256)
-            for (int i = k + 1; i < n; ++i) {
+            for (int i = k + 1; i < n; ++i) {          // (the panel is 48 columns wide: one thread; the parallel work is the trailing update)
                 const double l = A[(size_t)i * n + k] * inv;
                 A[(size_t)i * n + k] = l;
                 double* ri = A + (size_t)i * n;
