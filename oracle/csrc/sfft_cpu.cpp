@@ -48,12 +48,17 @@ template <typename T> struct Buf {
     ~Buf() { std::free(p); }
     Buf(const Buf&) = delete;
     Buf& operator=(const Buf&) = delete;
-    void resize(size_t n_) { std::free(p); n = n_; p = (T*)std::malloc(sizeof(T) * (n_ ? n_ : 1)); }
+    void resize(size_t n_) { if (n_ <= n && p) return; std::free(p); n = n_; p = (T*)std::malloc(sizeof(T) * (n_ ? n_ : 1)); }      // grow only
     T* data() { return p; }
     const T* data() const { return p; }
     T& operator[](size_t i) { return p[i]; }
     const T& operator[](size_t i) const { return p[i]; }
 };
+
+// The big buffers live as long as the process and only ever grow: a 13 GB working set that is unmapped after every call is
+// 3.3 million page faults per call, taken under the process's address-space lock -- at 128 threads that lock, not the arithmetic,
+// sets the time.  (Calls are not re-entrant: one GSS at a time per process, which is how the tests and the bench use it.)
+static Buf<cd> g_planes, g_work, g_Wla, g_Wmb, g_FD;
 
 double now_s()
 {
@@ -161,7 +166,7 @@ struct Fft2d {
     // in-place 2-D transform of a row-major [N0][N1] complex plane, times `scale`
     void run(cd* a, int sign, double scale, int nthreads) const
     {
-        const int CB = 8;   // columns gathered per block for the axis-0 pass
+        const int CB = 16;  // columns gathered per block for the axis-0 pass (256 contiguous bytes per row)
 #pragma omp parallel num_threads(nthreads)
         {
             const size_t M = (size_t)std::max(N0, N1);
@@ -345,13 +350,14 @@ int sfftcpu_solve(int N0, int N1, int w, int DK, int DB, int cpr, const double* 
     const size_t P = (size_t)N0 * N1;
     const int Fij = p.Fij, Fpq = p.Fpq, Fab = p.Fab, Fijab = p.Fijab, NEQ = p.NEQ;
     double t0 = now_s(), st[7] = {0, 0, 0, 0, 0, 0, 0};
-    Buf<cd> planes;
+    Buf<cd>& planes = g_planes;
     preliminary(p, fft, I, J, planes, nthreads);
     const cd* FJ = planes.data();
     const cd* FI = planes.data() + P;
     const cd* FT = planes.data() + (size_t)(1 + Fij) * P;
     st[0] = now_s() - t0;
-    Buf<cd> work(P);
+    Buf<cd>& work = g_work;
+    work.resize(P);
     std::vector<double> LH((size_t)NEQ * NEQ), RHb(NEQ);
     const int* ab = p.REF_ab.data();
 
@@ -469,7 +475,7 @@ int sfftcpu_apply(int N0, int N1, int w, int DK, int DB, int cpr, const double* 
     const size_t P = (size_t)N0 * N1;
     const int Fij = p.Fij, Fpq = p.Fpq, Fab = p.Fab, Fijab = p.Fijab, L0 = p.L0, L1 = p.L1;
     double t0 = now_s(), st[4] = {0, 0, 0, 0};
-    Buf<cd> planes;
+    Buf<cd>& planes = g_planes;
     preliminary(p, fft, I, J, planes, nthreads);
     const cd* FJ = planes.data();
     const cd* FI = planes.data() + P;
@@ -478,7 +484,10 @@ int sfftcpu_apply(int N0, int N1, int w, int DK, int DB, int cpr, const double* 
 
     // Kab_Wla[a + w0] = Wl ** a, Kab_Wmb[b + w1] = Wm ** b as FULL-SIZE planes (SFFTSubtract.py:778-792), Wl = exp(-2 pi i row / N0)
     t0 = now_s();
-    Buf<cd> Wla((size_t)L0 * P), Wmb((size_t)L1 * P);
+    Buf<cd>& Wla = g_Wla;
+    Buf<cd>& Wmb = g_Wmb;
+    Wla.resize((size_t)L0 * P);
+    Wmb.resize((size_t)L1 * P);
     for (int a = -p.w0; a <= p.w0; ++a) {
         cd* pl = Wla.data() + (size_t)(a + p.w0) * P;
 #pragma omp parallel for num_threads(nthreads) schedule(static)
@@ -502,7 +511,8 @@ int sfftcpu_apply(int N0, int N1, int w, int DK, int DB, int cpr, const double* 
 
     // Construct_FDIFF (SFFTConfigure.py:1316-1359): per pixel, over ab then ij
     t0 = now_s();
-    Buf<cd> FD(P);
+    Buf<cd>& FD = g_FD;
+    FD.resize(P);
     const int* ab = p.REF_ab.data();
 #pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int ROW = 0; ROW < N0; ++ROW)

@@ -292,6 +292,342 @@ __global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cpl
     }
 }
 
+// The same passes on the OTHER fp64 matrix instruction.  A loop of independent v_mfma_f64_16x16x4_f64 sustains 47 TFLOP/s on MI355X,
+// one of v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction) 71 - 74.5 (scripts/micro/mfma_f64_peak.hip,
+// profiles/r02_mfma_f64_peak.txt).  Its layout (scripts/micro/mfma_f64_4x4_layout.hip): A_blk[i][k] in lane 16 k + 4 blk + i,
+// B_blk[k][j] in lane 16 k + 4 blk + j, D_blk[i][j] in lane 16 i + 4 blk + j.  With k = image row of the step and the four blocks =
+// the four 4-column groups of a 16-column tile, B is the Hadamard product in exactly the lane layout the loads already produce
+// (lane = 16 row + column), A is the twiddle of lag 4 g + i (the same in all four blocks: gathered from the one twiddle per lane
+// the loads bring, by ds_swizzle within the 16-lane row), and the lane (i, column) of D holds lag 4 g + i: four instructions (lag groups) per real product where the
+// 16 x 16 x 4 form has one, at a third of the cycles each.
+template <int NT>
+__global__ void __launch_bounds__(64, 3) greek_g1_mfma4(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
+                                                                       cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
+                                                                       int rows_per_chunk, const cplx* __restrict__ W0tab, int HM,
+                                                                       const cplx* __restrict__ Xp, int ncb, int S, int npass)
+{
+    const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
+    const int total = ncb * S * npass;
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int tile = logical / npass;
+    const int chunk = tile / ncb;
+    const int m0 = (tile - chunk * ncb) * 16 * NT;
+    const G1Pass pr = passes[pass0 + (logical - tile * npass)];
+    const int h = pr.h, PH = 2 * h + 1;
+    const int lb = chunk * rows_per_chunk;
+    const int le = min(N0, lb + rows_per_chunk);
+    const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
+    const bool colfac = pr.b_plane < 0;
+    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz;
+    const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz;
+    const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
+    const int tcol = min(1 + n, HM - 1);   // the lane LOADS the twiddle of lag n + 1 (lags beyond the table: unused rows of D); the A operands of
+                                           // the four lag groups are gathered from the lanes of its 16-lane row (see compute)
+    size_t co[NT];
+    bool act[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = m0 + 16 * t + n;
+        act[t] = m < Nh;
+        co[t] = lay.col(act[t] ? m : Nh - 1);
+    }
+    constexpr int NS = 4;                                  // accumulator sets per column tile (S1 .. S4), four lag groups each
+    d4v Sx[NT][NS];
+    double g0x[NT], g0y[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Sx[t][q] = (d4v){0.0, 0.0, 0.0, 0.0};
+        g0x[t] = g0y[t] = 0.0;
+    }
+    // Software pipeline, written out as two register sets that alternate (the compiler sinks a plain "load next, use
+    // current" formulation back to load-then-wait within one step, which left every step exposed to the L2 latency): the
+    // loads of step s + 1 are issued, a scheduling barrier pins them there, then the MFMAs of step s run.  Addresses are
+    // 32-bit byte offsets from wave-uniform plane bases (scalar base + vector offset loads), advanced by one add and one
+    // clamp per step; rows past the chunk are masked by vf, so the clamp only has to keep the reads inside the plane.
+    struct LoadSet { cplx tw, a[NT], b[NT]; };
+    const char* __restrict__ Ab = reinterpret_cast<const char*>(A);
+    const char* __restrict__ Bb = reinterpret_cast<const char*>(B);
+    const char* __restrict__ Xb = reinterpret_cast<const char*>(xp);
+    const char* __restrict__ Wb = reinterpret_cast<const char*>(W0tab) + (size_t)tcol * sizeof(cplx);
+    unsigned cob[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cob[t] = (unsigned)(co[t] * sizeof(cplx));
+    const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
+    const unsigned rlast = (unsigned)(N0 - 1);
+    const unsigned r0 = min((unsigned)(lb + kq), rlast);
+    unsigned rowb = r0 * rsb, twb = r0 * hmb, xb = r0 * (unsigned)sizeof(cplx);
+    const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb, xb_max = rlast * (unsigned)sizeof(cplx);
+    // DG: two diagonal Omega passes side by side (plane A with itself, plane B with itself).  Their products |A|^2, |B|^2 are real,
+    // so each needs only two of the four sums: one wave does both with the loads and MFMAs of one ordinary pass -- and walks the
+    // rows at the pace of the ordinary passes, which the L2 sharing of a tile depends on (single diagonal passes at half the
+    // MFMAs ran ahead of the others and doubled the kernel's HBM traffic)
+    auto run = [&](auto CF, auto DGt) {
+        constexpr bool cf = decltype(CF)::value;
+        constexpr bool DG = decltype(DGt)::value;
+        auto issue = [&](LoadSet& L) {
+            L.tw = *reinterpret_cast<const cplx*>(Wb + twb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                L.a[t] = *reinterpret_cast<const cplx*>(Ab + (cob[t] + rowb));
+                L.b[t] = cf ? *reinterpret_cast<const cplx*>(Xb + xb) : *reinterpret_cast<const cplx*>(Bb + (cob[t] + rowb));
+            }
+            rowb = min(rowb + 4u * rsb, rowb_max);
+            twb = min(twb + 4u * hmb, twb_max);
+            if (cf) xb = min(xb + 4u * (unsigned)sizeof(cplx), xb_max);
+        };
+        auto compute = [&](const LoadSet& L, double vf) {
+            // A operand of lag group g: lane (row, n) needs the twiddle of lag 4 g + (n & 3), which lane (row, 4 g + (n & 3)) of the same
+            // 16-lane row loaded: ds_swizzle in bit-mask mode, source lane = (lane & 0x13) | (4 g) within each half wave
+            const double wx0 = L.tw.x * vf, wy0 = L.tw.y * vf;
+            double wx[4], wy[4];
+#define SFFT_SWZ(v, G) __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x13 | ((4 * (G)) << 5)), \
+                                        __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x13 | ((4 * (G)) << 5)))
+            wx[0] = SFFT_SWZ(wx0, 0); wx[1] = SFFT_SWZ(wx0, 1); wx[2] = SFFT_SWZ(wx0, 2); wx[3] = SFFT_SWZ(wx0, 3);
+            wy[0] = SFFT_SWZ(wy0, 0); wy[1] = SFFT_SWZ(wy0, 1); wy[2] = SFFT_SWZ(wy0, 2); wy[3] = SFFT_SWZ(wy0, 3);
+#undef SFFT_SWZ
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                // DG: H.x = |a|^2, H.y = |b|^2 (two real products; g0x / g0y are their lag-0 sums)
+                const cplx H = DG ? make_double2(fma(L.a[t].x, L.a[t].x, L.a[t].y * L.a[t].y), fma(L.b[t].x, L.b[t].x, L.b[t].y * L.b[t].y))
+                                  : cmulc(L.a[t], L.b[t]);
+                g0x[t] = fma(H.x, vf, g0x[t]);
+                g0y[t] = fma(H.y, vf, g0y[t]);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    Sx[t][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.x, Sx[t][0][gq], 0, 0, 0);      // S1            (DG: S1 of |A|^2)
+                    Sx[t][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], H.y, Sx[t][1][gq], 0, 0, 0);      // S2            (DG: S3 of |B|^2)
+                    Sx[t][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], H.x, Sx[t][2][gq], 0, 0, 0);      // S3            (DG: S3 of |A|^2)
+                    Sx[t][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.y, Sx[t][3][gq], 0, 0, 0);      // S4            (DG: S1 of |B|^2)
+                }
+            }
+        };
+        LoadSet L0, L1;
+        issue(L0);
+        for (int l = lb; l < le; l += 8) {
+            issue(L1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(L0, (l + kq < le) ? 1.0 : 0.0);
+            issue(L0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(L1, (l + 4 + kq < le) ? 1.0 : 0.0);      // (a step past the chunk runs on zero weights)
+        }
+    };
+    const bool diag = !colfac && pr.dual;
+    if (colfac) run(std::true_type{}, std::false_type{});
+    else if (diag) run(std::false_type{}, std::true_type{});
+    else run(std::false_type{}, std::false_type{});
+    cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        double sx = g0x[t], sy = g0y[t];
+        sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
+        sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
+        const int m = m0 + 16 * t + n;
+        if (!act[t]) continue;
+        if (diag) {     // two real, even sequences: G(+-r) = S1 +- i S3 for |A|^2 (Sx[0], Sx[2]) and for |B|^2 (Sx[3], Sx[1])
+            cplx* g2 = Gp + pr.gp_off2 + (size_t)chunk * PH * Nhp;
+            if (kq == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * q + kq + 1;               // D lane 16 i + ... of lag group q holds lag index 4 q + i
+                if (r <= h) {
+                    g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[t][0][q], Sx[t][2][q]);
+                    g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[t][0][q], -Sx[t][2][q]);
+                    g2[(size_t)(h + r) * Nhp + m] = make_double2(Sx[t][3][q], Sx[t][1][q]);
+                    g2[(size_t)(h - r) * Nhp + m] = make_double2(Sx[t][3][q], -Sx[t][1][q]);
+                }
+            }
+            continue;
+        }
+        if (kq == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * q + kq + 1;               // lag group q, row i = lane >> 4 of its 4 x 4 result blocks
+            if (r <= h) {
+                const double s1 = Sx[t][0][q], s2 = Sx[t][1][q], s3 = Sx[t][2][q], s4 = Sx[t][3][q];
+                g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
+                g[(size_t)(h - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
+            }
+        }
+    }
+}
+
+// ---- pass GROUPS: what bounds the kernels above is not the matrix pipe but the L1 / texture-addresser path -- every pass of a tile
+// re-reads its two planes through the CU's L1 (42 plane reads per tile for 6 distinct planes at Fij = 6; the 64-byte pieces of the
+// panel layout cost a full line each).  Here a wave takes up to three passes that share planes and loads each plane once per step:
+//   a triangle (x,y), (y,z), (x,z): 3 planes for 3 passes;  an edge with the two diagonals of its planes, (x,y) + dual(|x|^2, |y|^2):
+//   2 planes for the work of 2 passes.  The slots of a group have FIXED operand pairs (v0,v1), (v1,v2), (v0,v2) -- the host orders the
+//   planes of a group to fit -- so that nothing in the loop is indexed at run time.  At Fij = 6 the 15 + 3 launched passes become 4 triangles + 3 edge groups: 7 waves per tile
+//   and 18 plane loads per step instead of 36 (+ 7 twiddle loads instead of 9).
+// One 16-column tile per wave (48 accumulator registers per slot set); the 4 x 4 x 4 matrix instruction as in greek_g1_mfma4.
+// Measured at 4096^2, KerHW 8 (profiles/r02_*): 0.455 ms for the 7 groups against 0.435 - 0.45 for greek_g1_mfma and 0.458 for
+// greek_g1_mfma4 -- the launch does not move.  Experiments on this kernel: without the matrix instructions (loads, Hadamard products
+// and twiddles only) it takes 0.306 ms = 1.25 GB of HBM traffic at 4.1 TB/s; re-reading the same rows every step (no new memory
+// traffic) 0.409 ms against the 0.31 ms its 4 x 4 x 4 instructions need at the 74 TFLOP/s the instruction sustains alone; three
+// waves per SIMD (168 registers, 36 bytes of scratch) 0.53 ms; twiddles by recurrence instead of load + swizzle 0.453 ms; bursts
+// of 2 or 3 steps 0.453 / 0.458 ms.  The memory side and the compute side each need most of the launch and overlap poorly at two
+// waves per SIMD; the memory floor (0.8 GB of planes read once, no partial sums written) would be 0.19 ms.
+#ifndef DF_BURST
+#define DF_BURST 1     // steps whose loads are issued together (measured: 1, 2, 3 all 0.455 ms at 4096^2)
+#endif
+struct G1Group {
+    int plane[3];     // planes v0, v1, v2 loaded per step (an unused v2 repeats v0)
+    int mask;         // bit s set: slot s is in use.  Slot 0 = (v0, v1), slot 1 = (v1, v2), slot 2 = (v0, v2): fixed operand pairs
+    int pass[3];      // slot -> G1Pass record (gp_off, gp_off2, dual; only slot 0 may be a dual pass)
+};
+
+#ifndef G4G_WAVES
+#define G4G_WAVES 2
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
+                                                        const G1Group* __restrict__ groups, int ngroup,
+                                                        cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
+                                                        int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S)
+{
+    const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
+    const int total = ncb * S * ngroup;
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);      // the groups of a tile run back to back on one XCD
+    if (logical >= total) return;
+    const int tile = logical / ngroup;
+    const int chunk = tile / ncb;
+    const int m0 = (tile - chunk * ncb) * 16;
+    const G1Group gr = groups[logical - tile * ngroup];
+    const bool use0 = (gr.mask & 1) != 0, use1 = (gr.mask & 2) != 0, use2 = (gr.mask & 4) != 0;
+    const int k0 = use0 ? gr.pass[0] : (use1 ? gr.pass[1] : gr.pass[2]), k1 = use1 ? gr.pass[1] : k0, k2 = use2 ? gr.pass[2] : k0;
+    const long long go0 = passes[k0].gp_off, go1 = passes[k1].gp_off, go2 = passes[k2].gp_off;
+    const long long gd0 = passes[k0].gp_off2;
+    const bool d0 = use0 && passes[k0].dual != 0;
+    const int h = passes[k0].h, PH = 2 * h + 1;
+    const int lb = chunk * rows_per_chunk;
+    const int le = min(N0, lb + rows_per_chunk);
+    const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
+    const int m = m0 + n;
+    const bool act = m < Nh;
+    const unsigned cob = (unsigned)(lay.col(act ? m : Nh - 1) * sizeof(cplx));
+    const char* __restrict__ P0 = reinterpret_cast<const char*>(spec + (size_t)gr.plane[0] * plane_sz);
+    const char* __restrict__ P1 = reinterpret_cast<const char*>(spec + (size_t)gr.plane[1] * plane_sz);
+    const char* __restrict__ P2 = reinterpret_cast<const char*>(spec + (size_t)gr.plane[2] * plane_sz);
+    const int tcol = min(1 + n, HM - 1);
+    const char* __restrict__ Wb = reinterpret_cast<const char*>(W0tab) + (size_t)tcol * sizeof(cplx);
+    const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
+    const unsigned rlast = (unsigned)(N0 - 1);
+    const unsigned r0 = min((unsigned)(lb + kq), rlast);
+    unsigned rowb = r0 * rsb, twb = r0 * hmb;
+    const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb;
+    const bool three = gr.plane[2] != gr.plane[0];          // (wave uniform) a third plane is in use
+    d4v Sx[3][4];
+    double g0x[3], g0y[3];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Sx[sl][q] = (d4v){0.0, 0.0, 0.0, 0.0};
+        g0x[sl] = g0y[sl] = 0.0;
+    }
+    struct LoadSet { cplx tw, v[3]; };
+    // (two instantiations of the loop, with and without the third plane: a run-time `three ? load : v0` makes the compiler select
+    //  between ADDRESSES, which puts the whole load set in scratch)
+    auto run = [&](auto MODE) {
+    constexpr int mode = decltype(MODE)::value;      // 0: two planes, slot 0 only; 1: three planes; 2: two planes, slot 0 = the dual pass and slot 2 = the edge of the SAME two planes
+    constexpr bool three_c = mode == 1;
+    auto issue = [&](LoadSet& L) {
+        L.tw = *reinterpret_cast<const cplx*>(Wb + twb);
+        L.v[0] = *reinterpret_cast<const cplx*>(P0 + (cob + rowb));
+        L.v[1] = *reinterpret_cast<const cplx*>(P1 + (cob + rowb));
+        if (three_c) L.v[2] = *reinterpret_cast<const cplx*>(P2 + (cob + rowb)); else L.v[2] = make_double2(0.0, 0.0);
+        rowb = min(rowb + 4u * rsb, rowb_max);
+        twb = min(twb + 4u * hmb, twb_max);
+    };
+    auto compute = [&](const LoadSet& L, double vf) {
+        double wx[4], wy[4];
+        const double wx0 = L.tw.x * vf, wy0 = L.tw.y * vf;
+#define SFFT_SWZ(v, G) __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x13 | ((4 * (G)) << 5)), \
+                                        __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x13 | ((4 * (G)) << 5)))
+        wx[0] = SFFT_SWZ(wx0, 0); wx[1] = SFFT_SWZ(wx0, 1); wx[2] = SFFT_SWZ(wx0, 2); wx[3] = SFFT_SWZ(wx0, 3);
+        wy[0] = SFFT_SWZ(wy0, 0); wy[1] = SFFT_SWZ(wy0, 1); wy[2] = SFFT_SWZ(wy0, 2); wy[3] = SFFT_SWZ(wy0, 3);
+#undef SFFT_SWZ
+        auto slot = [&](auto SL, bool dual) {
+            constexpr int sl = decltype(SL)::value;
+            const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode == 2) ? 1 : 2];
+            // dual: H.x = |a|^2, H.y = |b|^2 (two real products side by side)
+            const cplx H = dual ? make_double2(fma(va.x, va.x, va.y * va.y), fma(vb.x, vb.x, vb.y * vb.y)) : cmulc(va, vb);
+            g0x[sl] = fma(H.x, vf, g0x[sl]);
+            g0y[sl] = fma(H.y, vf, g0y[sl]);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                Sx[sl][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.x, Sx[sl][0][gq], 0, 0, 0);      // S1   (dual: S1 of |A|^2)
+                Sx[sl][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], H.y, Sx[sl][1][gq], 0, 0, 0);      // S2   (dual: S3 of |B|^2)
+                Sx[sl][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], H.x, Sx[sl][2][gq], 0, 0, 0);      // S3   (dual: S3 of |A|^2)
+                Sx[sl][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.y, Sx[sl][3][gq], 0, 0, 0);      // S4   (dual: S1 of |B|^2)
+            }
+        };
+        if (use0) slot(std::integral_constant<int, 0>{}, d0);
+        if (three_c) {
+            if (use1) slot(std::integral_constant<int, 1>{}, false);
+            if (use2) slot(std::integral_constant<int, 2>{}, false);
+        }
+        if (mode == 2) slot(std::integral_constant<int, 2>{}, false);
+    };
+    // Bursts: the loads of DF_BURST steps (4 DF_BURST rows: 256 DF_BURST contiguous bytes per panel and plane) are issued together, two bursts
+    // alternating -- a DRAM page then serves one long request run per stream instead of one 256-byte piece per microsecond.
+    LoadSet LA[DF_BURST], LB[DF_BURST];
+#pragma unroll
+    for (int u = 0; u < DF_BURST; ++u) issue(LA[u]);
+    for (int l = lb; l < le; l += 8 * DF_BURST) {
+#pragma unroll
+        for (int u = 0; u < DF_BURST; ++u) issue(LB[u]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < DF_BURST; ++u) compute(LA[u], (l + 4 * u + kq < le) ? 1.0 : 0.0);
+#pragma unroll
+        for (int u = 0; u < DF_BURST; ++u) issue(LA[u]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < DF_BURST; ++u) compute(LB[u], (l + 4 * (DF_BURST + u) + kq < le) ? 1.0 : 0.0);      // (steps past the chunk run on zero weights)
+    }
+    };
+    if (three) run(std::integral_constant<int, 1>{}); else if (use2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 0>{});
+    if (!act) return;
+    auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual) {
+        constexpr int sl = decltype(SL)::value;
+        double sx = g0x[sl], sy = g0y[sl];
+        sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
+        sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
+        cplx* g = Gp + gp_off + (size_t)chunk * PH * Nhp;
+        if (dual) {     // two real, even sequences: G(+-r) = S1 +- i S3 for |A|^2 (Sx[0], Sx[2]) and for |B|^2 (Sx[3], Sx[1])
+            cplx* g2 = Gp + gp_off2 + (size_t)chunk * PH * Nhp;
+            if (kq == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * q + kq + 1;
+                if (r <= h) {
+                    g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][0][q], Sx[sl][2][q]);
+                    g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][0][q], -Sx[sl][2][q]);
+                    g2[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][3][q], Sx[sl][1][q]);
+                    g2[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][3][q], -Sx[sl][1][q]);
+                }
+            }
+            return;
+        }
+        if (kq == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * q + kq + 1;
+            if (r <= h) {
+                const double s1 = Sx[sl][0][q], s2 = Sx[sl][1][q], s3 = Sx[sl][2][q], s4 = Sx[sl][3][q];
+                g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
+                g[(size_t)(h - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
+            }
+        }
+    };
+    if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0);
+    if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false);
+    if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false);
+}
+
 // W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)
 __global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
 {

@@ -14,6 +14,7 @@
 // columns kept (the inputs are real, so the other half is the conjugate mirror) and Nhp >= Nh the padded
 // row stride.  All arithmetic is IEEE fp64.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -190,7 +191,10 @@ struct sfft_plan {
                                         // but 488 -> 463 pairs/s pipelined: the vector launch overlaps better with the other pairs' kernels)
     int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
-    int g1_mfma = 1;                    // Omega passes on the matrix cores (greek_g1_mfma); env SFFT_G1_MFMA=0: vector kernel (A/B testing)
+    int g1_mfma = 3;                    // Omega passes on the matrix cores: 3 = greek_g1_mfma4g (pass groups that share plane loads, v_mfma_f64_4x4x4_4b_f64),
+                                        // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 1: greek_g1_mfma (16x16x4), 0: vector kernel (A/B testing)
+    G1Group* d_groups = nullptr;        // pass groups of the Omega launch
+    int n_groups = 0;
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     int timing = 0;
@@ -790,6 +794,73 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         (void)PHo; (void)PHg;
         PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
         PLAN_HIP(hipMemcpy(p->d_passes, p->passes.data(), p->passes.size() * sizeof(G1Pass), hipMemcpyHostToDevice));
+        if (p->g1_mfma >= 3 && hO >= 9 && hO <= 16) {
+            // Pass groups of the Omega launch (greek_g1_mfma4g): an edge (x, y) with the dual-diagonal pass of the same two planes;
+            // then triangles (x,y), (y,z), (x,z) among the remaining ordinary passes, greedily; then pairs of passes that share a
+            // plane; then single passes.
+            const int nl = p->n_omg_launch;
+            std::vector<char> used((size_t)nl, 0);
+            std::vector<G1Group> groups;
+            // slots have fixed operand pairs: 0 = (v0, v1), 1 = (v1, v2), 2 = (v0, v2); passes are oriented a_plane <= b_plane
+            auto find_edge = [&](int x, int y) {      // the unused ordinary pass (x, y), x < y
+                for (int k = 0; k < nl; ++k) {
+                    const G1Pass& q = p->passes[k];
+                    if (!used[k] && !q.dual && q.a_plane == x && q.b_plane == y) return k;
+                }
+                return -1;
+            };
+            auto blank = [&](int v0, int v1, int v2) {
+                G1Group g; g.plane[0] = v0; g.plane[1] = v1; g.plane[2] = v2; g.mask = 0;
+                g.pass[0] = g.pass[1] = g.pass[2] = 0;
+                return g;
+            };
+            auto put = [&](G1Group& g, int sl, int k) { g.mask |= 1 << sl; g.pass[sl] = k; used[k] = 1; };
+            for (int k = 0; k < nl; ++k) if (p->passes[k].dual && !used[k]) {          // the two diagonals of (x, y) [slot 0] + the edge (x, y) [slot 2]
+                const int x = p->passes[k].a_plane, y = p->passes[k].b_plane;
+                G1Group g = blank(x, y, x);          // (third plane = first: "two planes"; slot 2 then reads (v0, v1) as well)
+                put(g, 0, k);
+                const int e = find_edge(std::min(x, y), std::max(x, y));
+                if (e >= 0 && x < y) put(g, 2, e);
+                groups.push_back(g);
+            }
+            for (int k = 0; k < nl; ++k) if (!used[k] && p->passes[k].a_plane < p->passes[k].b_plane) {      // triangles x < y < z
+                const int u = p->passes[k].a_plane, v = p->passes[k].b_plane;
+                for (int w3 = 0; w3 < p->Fij && !used[k]; ++w3) {
+                    if (w3 == u || w3 == v) continue;
+                    int t[3] = {u, v, w3};
+                    std::sort(t, t + 3);
+                    used[k] = 1;                        // (so that find_edge skips it)
+                    int e[3] = {find_edge(t[0], t[1]), find_edge(t[1], t[2]), find_edge(t[0], t[2])};
+                    used[k] = 0;
+                    for (int q = 0; q < 3; ++q) { const int ea = q == 1 ? t[1] : t[0], eb = q == 0 ? t[1] : t[2]; if (ea == u && eb == v) e[q] = k; }
+                    if (e[0] >= 0 && e[1] >= 0 && e[2] >= 0) {
+                        G1Group g = blank(t[0], t[1], t[2]);
+                        put(g, 0, e[0]); put(g, 1, e[1]); put(g, 2, e[2]);
+                        groups.push_back(g);
+                    }
+                }
+            }
+            for (int k = 0; k < nl; ++k) if (!used[k]) {                               // what is left: two passes that share a plane, single passes
+                const int x = p->passes[k].a_plane, y = p->passes[k].b_plane;
+                bool done = false;
+                for (int k2 = k + 1; k2 < nl && !done && x < y; ++k2) if (!used[k2] && !p->passes[k2].dual && p->passes[k2].a_plane < p->passes[k2].b_plane) {
+                    const int u = p->passes[k2].a_plane, v = p->passes[k2].b_plane;
+                    int t[3], nt = 0;
+                    for (int w3 : {x, y, u, v}) { bool in = false; for (int q = 0; q < nt; ++q) in = in || t[q] == w3; if (!in && nt < 3) t[nt++] = w3; else if (!in) nt = 4; }
+                    if (nt != 3) continue;
+                    std::sort(t, t + 3);
+                    auto slot_for = [&](int a2, int b2) { return (a2 == t[0] && b2 == t[1]) ? 0 : (a2 == t[1] && b2 == t[2]) ? 1 : 2; };
+                    G1Group g = blank(t[0], t[1], t[2]);
+                    put(g, slot_for(x, y), k); put(g, slot_for(u, v), k2);
+                    groups.push_back(g);
+                    done = true;
+                }
+                if (!done) { G1Group g = blank(x, y, x); put(g, 0, k); groups.push_back(g); }
+            }
+            p->n_groups = (int)groups.size();
+            PLAN_TRY(dev_alloc(p, &p->d_groups, groups.size()));
+            PLAN_HIP(hipMemcpy(p->d_groups, groups.data(), groups.size() * sizeof(G1Group), hipMemcpyHostToDevice));
+        }
         PLAN_TRY(dev_alloc(p, &p->d_jobs, p->jobs.size()));
         PLAN_HIP(hipMemcpy(p->d_jobs, p->jobs.data(), p->jobs.size() * sizeof(PatchJob), hipMemcpyHostToDevice));
         PLAN_TRY(dev_alloc(p, &p->d_gp, (size_t)goff));
@@ -994,7 +1065,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_cyp, p->d_rowmomI, p->d_gamR};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_cyp, p->d_rowmomI, p->d_gamR};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1327,8 +1398,17 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
     if (h >= 9 && h <= 16 && p->g1_mfma) {
         const int ncb = (p->Nh + 31) / 32;
         const int total = ncb * p->S * npass;
-        hipLaunchKernelGGL((greek_g1_mfma<2, false>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
-                           p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+        if (p->g1_mfma >= 3 && p->d_groups && pass0 == 0 && npass == p->n_omg_launch) {
+            const int ncb16 = (p->Nh + 15) / 16;
+            const int totg = ncb16 * p->S * p->n_groups;
+            hipLaunchKernelGGL(greek_g1_mfma4g, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                               p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S);
+        } else if (p->g1_mfma == 1)        // (SFFT_G1_MFMA=1: the 16 x 16 x 4 instruction, for A/B runs)
+            hipLaunchKernelGGL((greek_g1_mfma<2, false>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
+                               p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+        else
+            hipLaunchKernelGGL((greek_g1_mfma4<2>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
+                               p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
         LAUNCH_CHECK();
         return SFFT_OK;
     }
@@ -1524,7 +1604,7 @@ static int solve_check(sfft_plan* p, double* d_solution, hipStream_t s, bool* re
             const unsigned long long t0 = h[8];
             for (int j = 0; j < nbc; ++j) {
                 fprintf(stderr, "df_trace j=%d", j);
-                for (int k = 0; k < 9; ++k) fprintf(stderr, " %lld", h[(size_t)j * 16 + k] ? (long long)(h[(size_t)j * 16 + k] - t0) : -1LL);
+                for (int k = 0; k < 10; ++k) fprintf(stderr, " %lld", h[(size_t)j * 16 + k] ? (long long)(h[(size_t)j * 16 + k] - t0) : -1LL);
                 fprintf(stderr, "\n");
             }
         }

@@ -59,7 +59,9 @@ struct PanelLds {
 
 // Factor the CB x CB diagonal block held as a[q] = D[i][cg + 4 q] by thread (i = tid >> 2, cg = tid & 3) (identity padding
 // beyond nb); on return L.Dl holds the lower-triangular factor and L.rdiag the reciprocal diagonal.  All 256 threads call.
-__device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, int tid, int nb, bool report, int* __restrict__ status)
+// Vd (optional, [CB][4]): row 4 jq + k receives row k of the INVERSE of the 4 x 4 pivot block of step jq (used by chol_inv16_mfma).
+__device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, int tid, int nb, bool report, int* __restrict__ status,
+                                                 double (*Vd)[4] = nullptr)
 {
     const int i = tid >> 2, cg = tid & 3;
     double (&Rw)[CB][4] = L.Rw;
@@ -99,6 +101,18 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
         Fw[i][cg] = lf;
         if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
+        if (Vd && (tid >> 4) == 4) {         // sixteen lanes of wave 1 (off the stores above): element (k, c) of the inverse of the pivot block
+            // [[1/rs0], [t10, 1/rs1], [t20, t21, 1/rs2], [t30, t31, t32, 1/rs3]]
+            const int k = (tid >> 2) & 3, c = tid & 3;
+            const double v10 = -t10 * rs0 * rs1, v21 = -t21 * rs1 * rs2, v32 = -t32 * rs2 * rs3;
+            const double v20 = -fma(t21, v10, t20 * rs0) * rs2, v31 = -fma(t32, v21, t31 * rs1) * rs3;
+            const double v30 = -fma(t32, v20, fma(t31, v10, t30 * rs0)) * rs3;
+            const double r0v = (c == 0) ? rs0 : 0.0;
+            const double r1v = (c == 0) ? v10 : (c == 1) ? rs1 : 0.0;
+            const double r2v = (c == 0) ? v20 : (c == 1) ? v21 : (c == 2) ? rs2 : 0.0;
+            const double r3v = (c == 0) ? v30 : (c == 1) ? v31 : (c == 2) ? v32 : rs3;
+            Vd[j0 + k][c] = (k == 0) ? r0v : (k == 1) ? r1v : (k == 2) ? r2v : r3v;
+        }
         __syncthreads();
         if (jq < 15) {
             const double f0 = Fw[i][0], f1 = Fw[i][1], f2 = Fw[i][2], f3 = Fw[i][3];
@@ -573,6 +587,51 @@ __device__ __forceinline__ void chol_inv16(const PanelLds& L, double (*W16t)[16]
     for (int i = 0; i < 16; ++i) W16t[b][c][i] = w[i];
 }
 
+// The same four inverses on the matrix cores, one 16 x 16 block per wave (b = wave index): with D = blockdiag of the block's
+// 4 x 4 diagonal sub-blocks (inverses in Vd, from chol_factor_diag) L_bb = D (I + N), N = D^-1 (L_bb - D) strictly block-lower,
+// hence nilpotent: N^4 = 0 and L_bb^-1 = (I - N + N^2 - N^3) D^-1.  Four 16^3 products = 16 v_mfma_f64_16x16x4_f64 and three
+// trips through the wave's LDS scratch Ws[3][16][17]; the result lands in W16t[b][c][i] = W_bb[i][c].
+__device__ __forceinline__ void chol_inv16_mfma(const double (*Dl)[CB + 1], const double (*Vd)[4], double (*Ws)[16][W16_LD],
+                                                double (*W16t)[16][W16_LD], int b, int ln, int lk)
+{
+    const int R = 16 * b;
+    d4s nA = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double av = ((ln >> 2) == ks) ? Vd[R + ln][lk] : 0.0;                          // D^-1 [i = ln][k = 4 ks + lk]
+        const double bv = (ks > (ln >> 2)) ? Dl[R + 4 * ks + lk][R + ln] : 0.0;              // (L_bb - D)[k][j = ln]
+        nA = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, nA, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ws[0][lk + 4 * q][ln] = nA[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    d4s n2 = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) n2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[0][ln][4 * ks + lk], Ws[0][4 * ks + lk][ln], n2, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ws[1][lk + 4 * q][ln] = n2[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    d4s n3 = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) n3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[0][ln][4 * ks + lk], Ws[1][4 * ks + lk][ln], n3, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ws[2][lk + 4 * q][ln] = ((lk + 4 * q == ln) ? 1.0 : 0.0) - nA[q] + n2[q] - n3[q];      // I - N + N^2 - N^3
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    d4s wacc = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double bv = (ks == (ln >> 2)) ? Vd[R + 4 * ks + lk][ln & 3] : 0.0;             // D^-1 [k][j = ln]
+        wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[2][ln][4 * ks + lk], bv, wacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) W16t[b][ln][lk + 4 * q] = wacc[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // X L^T = C for the 64 x 64 tile C held in T (in place), L in Dl (identity beyond its last row), W16t as above.  Each wave owns
 // 16 rows of T and needs no workgroup barrier: for the four 16-column blocks in turn, Y_b = C_b - sum_{b' < b} X_b' L_bb'^T and
 // X_b = Y_b W_bb^T, all as v_mfma_f64_16x16x4_f64 (40 per wave).  The 16 x 16 inverses are only used block-diagonally; the
@@ -610,13 +669,14 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
                                                      const unsigned int* __restrict__ epoch_ctr, int* __restrict__ status,
                                                      double* __restrict__ rd, double* __restrict__ w16, unsigned long long* __restrict__ trace)
 {
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
     __shared__ int s_task;
 #define DF_TRACE(slot) do { if (trace && tid == 0) trace[(size_t)bj * 16 + (slot)] = wall_clock64(); } while (0)
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // operand tile / the accumulated tile T
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // operand tile / start of the PanelLds
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
     double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
+    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD);
     const unsigned int epoch = (*epoch_ctr << 8) | DF_EPOCH_TAG;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int ti = tid >> 2, cg = tid & 3;
@@ -799,17 +859,18 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
         }
         __syncthreads();                    // T has been read; the PanelLds region may be overwritten
         DF_TRACE(6);
-        chol_factor_diag(a, L, tid, nbd, true, status);
-        if (wv == 0) {
-            chol_inv16(L, W16t, lane);
-            // publish: lane 16 b + c holds W16t[b][c][0..15] = 128 contiguous bytes of w16[j][b][c][*]
+        chol_factor_diag(a, L, tid, nbd, true, status, Vd);
+        DF_TRACE(9);
+        {   // inverses of the 16 x 16 diagonal sub-blocks, one per wave, published with the factor: lane = 4 c + h stores
+            // W16t[wv][c][4 h .. 4 h + 3] = 32 contiguous bytes of w16[j][wv][c][*]
+            chol_inv16_mfma(L.Dl, Vd, reinterpret_cast<double (*)[16][W16_LD]>(&T[0][0]) + 3 * wv, W16t, wv, ln, lk);
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                const double v0 = W16t[lane >> 4][lane & 15][2 * h], v1 = W16t[lane >> 4][lane & 15][2 * h + 1];
+            for (int h = 0; h < 2; ++h) {
+                const double v0 = W16t[wv][lane >> 2][4 * (lane & 3) + 2 * h], v1 = W16t[wv][lane >> 2][4 * (lane & 3) + 2 * h + 1];
                 df_u4 pk;
                 pk.x = (unsigned int)__double2loint(v0); pk.y = (unsigned int)__double2hiint(v0);
                 pk.z = (unsigned int)__double2loint(v1); pk.w = (unsigned int)__double2hiint(v1);
-                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_w, (int)(((size_t)j * 1024 + (size_t)lane * 16 + 2 * h) * sizeof(double)), 0, /*aux: sc1*/ 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_w, (int)(((size_t)j * 1024 + (size_t)wv * 256 + (size_t)lane * 4 + 2 * h) * sizeof(double)), 0, /*aux: sc1*/ 16);
             }
         }
         DF_TRACE(7);
