@@ -161,3 +161,106 @@ def test_lambda_zero_is_no_regularisation_and_large_lambda_smooths():
     lam = 1e3 * np.abs(L0).max() / np.abs(REG).max()
     s2 = sv.ESS(I, J, p, basis, scab, REGMAT=REG, LAMBDA_REGULARIZE=lam)[0]
     assert s2 @ REG @ s2 < 1e-3 * (s0 @ REG @ s0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Two transcriptions must agree: oracle/bspline_sv_literal.py follows the reference's CUDA kernels and host loops line by
+# line (per-element loops, the same index tables and cIdx loops); oracle/bspline_sv_oracle.py is the vectorised restatement
+# the GPU tests use.  Agreement to 1e-13 narrows -- does not close -- the "parity unpinned" label of these modes.
+# ---------------------------------------------------------------------------------------------------
+from oracle import bspline_sv_literal as lit
+
+LIT_CASES = [
+    dict(N0=16, N1=12, w=1),                                                                                     # poly kernel 2, poly scaling 1
+    dict(N0=18, N1=14, w=1, ker=('B-Spline', 1, (9.5,), ()), sca=('Polynomial', 1, (), ()), bkg=('Polynomial', 0, (), ())),
+    dict(N0=14, N1=16, w=2, ker=('B-Spline', 2, (), ()), sca=('B-Spline', 1, (), ()), bkg=('B-Spline', 1, (), ())),
+]
+
+
+def _lit_args(I, J, basis, scab, p):
+    return (I, J, p['N0'], p['N1'], p['w0'], p['w1'], basis['kbx'], basis['kby'], [tuple(x) for x in basis['ker_pairs']],
+            scab['sbx'], scab['sby'], [tuple(x) for x in scab['sca_pairs']], basis['tbx'], basis['tby'],
+            [tuple(x) for x in basis['bkg_pairs']])
+
+
+@pytest.mark.parametrize("kw", LIT_CASES)
+def test_literal_transcription_agrees_with_the_vectorised_oracle(kw):
+    I, J, basis, scab, p = _case(**kw)
+    L_v, b_v = sv.establish_system(I, J, p, basis, scab)
+    L_l, b_l = lit.establish_system(*_lit_args(I, J, basis, scab, p))
+    nk = p['Fijab']
+    for blk_v, blk_l in ((L_v[:nk, :nk], L_l[:nk, :nk]), (L_v[:nk, nk:], L_l[:nk, nk:]), (L_v[nk:, :nk], L_l[nk:, :nk]),
+                         (L_v[nk:, nk:], L_l[nk:, nk:]), (b_v[:nk], b_l[:nk]), (b_v[nk:], b_l[nk:])):
+        assert np.abs(blk_v - blk_l).max() <= 1e-13 * np.abs(blk_l).max()
+    # regularisation: Laplacian -> iREGMAT -> REGMAT, unweighted and weighted
+    XY = np.array([[3.0, 2.5], [8.0, 9.0], [12.5, 4.0], [5.5, 10.5]])
+    kerspec = dict(KerSpType=basis['KerSpType'], DK=kw.get('ker', ('Polynomial', 2))[1],
+                   KerIntKnotX=list(kw.get('ker', ('', 0, (), ()))[2]), KerIntKnotY=list(kw.get('ker', ('', 0, (), ()))[3]))
+    for W in (None, np.array([1.0, 2.0, 0.5, 3.0])):
+        SST, CSST, DSST = sv.spatial_gram(p, kerspec, scab, XY, W)
+        REG_v = sv.regularization_matrix(p, sv.laplacian_ireg(p['w0'], p['w1'], True), SST, CSST, DSST)
+        REG_l, iREG_l = lit.regularization_matrix(p['N0'], p['N1'], p['w0'], p['w1'], p['Fij'], p['Fpq'], SST, CSST, DSST, True)
+        assert np.array_equal(iREG_l, sv.laplacian_ireg(p['w0'], p['w1'], True))
+        assert np.abs(REG_v - REG_l).max() <= 1e-13 * np.abs(REG_l).max()
+    # tweak + solve + restore, then the difference image, both from the literal system
+    lam = 10.0 / p['SCALE'] ** 2 * 1e-6
+    sol_v = sv.solve_system(L_l + lam * REG_l, b_l, p)
+    sol_l = lit.tweak_solve_restore(L_l + lam * REG_l, b_l, p['Fij'], p['Fpq'], p['w0'], p['w1'], 'SEPARATE-VARYING',
+                                    basis['KerSpType'], ScaFij=p['ScaFij'])
+    assert np.abs(sol_v - sol_l).max() <= 1e-9 * np.abs(sol_l).max()
+    ij00 = np.arange(p['w0'] * p['L1'] + p['w1'], p['Fijab'], p['Fab'])
+    assert np.all(sol_l[ij00[p['ScaFij']:]] == 0.0)
+    D_v = sv.subtract(I, J, sol_l, p, basis, scab)
+    D_l = lit.construct_diff(*((I, J, sol_l) + _lit_args(I, J, basis, scab, p)[2:]))
+    assert np.sqrt(np.mean((D_v - D_l) ** 2)) <= 1e-12 * np.sqrt(np.mean(J ** 2))
+
+
+def test_literal_spatial_grams_and_constant_scaling_tweak_agree():
+    """spatial Gram matrices (:3583-3635) and the B-spline TweakLS of SEPARATE-CONSTANT scaling (the sum rule, :2201-2272)."""
+    rng = np.random.default_rng(1)
+    SP, ScaSP = rng.normal(size=(6, 5)), rng.normal(size=(3, 5))
+    for W in (None, np.array([1.0, 2.0, 3.0, 4.0, 5.0])):
+        SST, CSST, DSST = lit.spatial_grams(SP, ScaSP, 6, W)
+        Wm = np.eye(5) / 5 if W is None else np.diag(W) / W.sum()
+        Sp = np.concatenate((ScaSP, np.zeros((3, 5))), axis=0)
+        assert np.allclose(SST, SP @ Wm @ SP.T, rtol=1e-14, atol=0) and np.allclose(CSST, SP @ Wm @ Sp.T, rtol=1e-14, atol=1e-300)
+        assert np.allclose(DSST, Sp @ Wm @ Sp.T, rtol=1e-14, atol=1e-300)
+    N0, N1, w = 20, 16, 1
+    pair = make_pair(N0, N1, seed=9, density=60.0)
+    basis = bo.make_basis(N0, N1, 'B-Spline', 1, (10.5,), (), 'Polynomial', 1, (), ())
+    pc = bo.SSC(N0, N1, w, basis, ConstPhotRatio=True)
+    LH, rhs = bo.establish_system(pair['REF'], pair['SCI'], pc, basis)
+    sol_o = bo.solve_system(LH, rhs, pc)                                   # pinned by reference-made goldens
+    sol_l = lit.tweak_solve_restore(LH, rhs, pc['Fij'], pc['Fpq'], w, w, 'SEPARATE-CONSTANT', 'B-Spline')
+    assert np.abs(sol_o - sol_l).max() <= 1e-9 * np.abs(sol_o).max()
+    ij00 = np.arange(w * 3 + w, pc['Fijab'], pc['Fab'])
+    assert np.all(sol_l[ij00] == sol_l[ij00[0]])
+
+
+def test_gridconvolve_oracle_uses_convolve2d_as_defined():
+    """oracle/gridconv_oracle.py loops over segments like the reference (BSplineSFFT.py:4985-5003) and calls scipy's convolve2d; here
+    that call is checked against the definition of a 'same', zero-filled convolution written out as four loops."""
+    from scipy.signal import convolve2d
+    from oracle import gridconv_oracle as gc
+    rng = np.random.default_rng(4)
+    img, ker = rng.normal(size=(13, 11)), rng.normal(size=(5, 3))
+    assert np.abs(convolve2d(img, ker, mode='same', boundary='fill', fillvalue=0.0) - lit.convolve2d_same_fill0(img, ker)).max() <= 1e-13
+    # ... and the segment loop against a per-pixel evaluation with the pixel's own segment kernel
+    N0, N1, TiHW = 17, 14, 2
+    AllocatedL, _ = gc.tile_labels(N0, N1, TiHW)
+    Nseg = AllocatedL.max() + 1
+    KerStack = rng.uniform(0.5, 1.5, size=(Nseg, 3, 3))
+    img = rng.normal(size=(N0, N1))
+    out = gc.gsvc(img, AllocatedL, KerStack, normalize_kernel=True)
+    ref = np.zeros((N0, N1))
+    for x in range(N0):
+        for y in range(N1):
+            K = KerStack[AllocatedL[x, y]] / KerStack[AllocatedL[x, y]].sum()
+            acc = 0.0
+            for u in range(3):
+                for v in range(3):
+                    xx, yy = x + 1 - u, y + 1 - v
+                    if 0 <= xx < N0 and 0 <= yy < N1:
+                        acc += K[u, v] * img[xx, yy]
+            ref[x, y] = acc
+    assert np.abs(out - ref).max() <= 1e-13
