@@ -56,7 +56,7 @@ CONFIGS = {
 }
 
 
-def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply):
+def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False):
     """Algorithmic HBM bytes per stage for ONE pair (solve + apply), as built, and the
     canonical reference-algorithm figure B_alg of SURVEY.md 8(d).  n_colfac = distinct column factors of the kernel basis
     (DK + 1 for a polynomial, Fj for a B-spline tensor basis): one row transform each."""
@@ -78,6 +78,10 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply):
         # (the Fij diagonal passes have a real product: half the lag work)
         "greek_g1_flops": N0 * Nh * ((n_omg - Fij) * (6 + 2 * 4 * (2 * w)) + Fij * (3 + 4 * (2 * w))),
     }
+    if theta_fused:      # the Fij Theta passes (half width w) ride in the Omega launch: + the FJ plane, + their flops; the short-pass stage
+        out["greek_g1"] += spec                                  # keeps only the Gamma block (one read of the masked image)
+        out["greek_g1b"] = r * P
+        out["greek_g1_flops"] += N0 * Nh * Fij * (6 + 2 * 4 * w)
     if mixed_apply:
         # polynomial kernel: row pass into stage planes, mixed-domain column convolution (reads them, writes one plane),
         # inverse row pass with the DIFF epilogue -- no column transforms
@@ -350,7 +354,8 @@ def main():
         ms_step = elapsed * 1e3 / args.steps
         iso_stage = {k: v / n_iso for k, v in iso_acc.items()}
         mixed = (not bspline) and w <= 12
-        ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed)
+        theta_fused = bool(plans[0].query("THETA_FUSED"))
+        ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused)
         headline = (args.config == 2 and (N0, N1, w) == (4096, 4096, 8))
 
         pmc = {}
@@ -360,8 +365,9 @@ def main():
             pass
         fast = (N0 == 4096 and N1 == 4096)
         KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if fast else "cols_fwd_weighted / strided_dft",
-                     "fwd_rows": "rows_r2c_4096" if fast else "rows_r2c", "greek_g1": "greek_g1_mfma<2, false> (Omega passes)",
-                     "greek_g1b": "greek_g1<8, 2> (Theta passes) + row_moments / gamma_rows / gamma_patches (Gamma block)",
+                     "fwd_rows": "rows_r2c_4096" if fast else "rows_r2c",
+                     "greek_g1": "greek_g1_mfma4g (Omega passes in groups%s)" % (" + the Theta passes" if theta_fused else ""),
+                     "greek_g1b": ("" if theta_fused else "greek_g1<8, 2> (Theta passes) + ") + "row_moments / gamma_rows / gamma_patches (Gamma block)",
                      "construct": "vconv_mixed2<2, 8, 4>" if mixed and w <= 8 else ("vconv_mixed" if mixed else "construct_fd")}
 
         def roof(stages, dom="fwd_cols"):
@@ -377,9 +383,10 @@ def main():
             return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_flops"],
                     "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
-                    "sustained_peak_measured": 47.4,     # profiles/r01_mfma_f64_peak.txt: a loop of independent MFMAs, TFLOP/s
-                    "note": "v_mfma_f64_16x16x4_f64 (the fp64 matrix and vector peaks are equal on MI355X); a loop of nothing but independent "
-                            "MFMAs sustains 47.4 TFLOP/s on this device (scripts/micro/mfma_f64_peak.hip); HBM side: "
+                    "sustained_peak_measured": 74.5,     # profiles/r02_mfma_f64_peak.txt: a loop of independent v_mfma_f64_4x4x4_4b_f64, TFLOP/s
+                    "note": "v_mfma_f64_4x4x4_4b_f64; a loop of nothing but independent MFMAs sustains 74.5 TFLOP/s with this instruction and "
+                            "47.4 with v_mfma_f64_16x16x4_f64 on this device (scripts/micro/mfma_f64_peak.hip); the launch is not bound by the "
+                            "matrix pipe alone: memory side 0.31 ms, compute side 0.41 ms measured separately (greek.hpp); HBM side: "
                             "%.0f GB/s of algorithmic bytes" % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
         per_pair_keys = [k for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse") if k in ab]
         if batch_mode:

@@ -47,6 +47,7 @@ enum {
     SFFT_Q_NUM_GREEK_PAIRS,         /* spectral products actually transformed per solve */
     SFFT_Q_SCAFIJ,                  /* scaling terms of a plan made by sfft_plan_create_varscale (0 otherwise) */
     SFFT_Q_SOLVE_GRAPH,             /* 1 once the factorisation chain of this plan has been captured and replays as a hipGraph */
+    SFFT_Q_THETA_FUSED,             /* 1: the Theta passes ride in the Omega launch of this plan (stage GREEK_G1 then carries them) */
     SFFT_Q_COUNT
 };
 

@@ -477,6 +477,8 @@ struct G1Group {
     int plane[3];     // planes v0, v1, v2 loaded per step (an unused v2 repeats v0)
     int mask;         // bit s set: slot s is in use.  Slot 0 = (v0, v1), slot 1 = (v1, v2), slot 2 = (v0, v2): fixed operand pairs
     int pass[3];      // slot -> G1Pass record (gp_off, gp_off2, dual; only slot 0 may be a dual pass)
+    int tpass[2];     // >= 0: Theta passes (v0, J) and (v1, J) of half width ht <= 8 ride along; J is then plane[2] and slot 2 reads (v0, v1)
+    int ht;
 };
 
 #ifndef G4G_WAVES
@@ -518,9 +520,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     const unsigned r0 = min((unsigned)(lb + kq), rlast);
     unsigned rowb = r0 * rsb, twb = r0 * hmb;
     const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb;
+    const bool theta = gr.tpass[0] >= 0;                    // (wave uniform) edge + dual group with the Theta passes of its two planes
     const bool three = gr.plane[2] != gr.plane[0];          // (wave uniform) a third plane is in use
+    const long long gt0 = theta ? passes[gr.tpass[0]].gp_off : 0, gt1 = theta ? passes[gr.tpass[1]].gp_off : 0;
+    const int ht = gr.ht, PHt = 2 * ht + 1;
     d4v Sx[3][4];
     double g0x[3], g0y[3];
+    double St[2][4][2], t0x[2] = {0.0, 0.0}, t0y[2] = {0.0, 0.0};       // Theta slots: four sums x two lag groups (lags 1 .. 8)
+#pragma unroll
+    for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) St[ts][q][0] = St[ts][q][1] = 0.0;
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
 #pragma unroll
@@ -531,8 +541,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     // (two instantiations of the loop, with and without the third plane: a run-time `three ? load : v0` makes the compiler select
     //  between ADDRESSES, which puts the whole load set in scratch)
     auto run = [&](auto MODE) {
-    constexpr int mode = decltype(MODE)::value;      // 0: two planes, slot 0 only; 1: three planes; 2: two planes, slot 0 = the dual pass and slot 2 = the edge of the SAME two planes
-    constexpr bool three_c = mode == 1;
+    constexpr int mode = decltype(MODE)::value;      // 0: two planes, slot 0 only; 1: three planes; 2: two planes, slot 0 = the dual pass and slot 2 = the edge of the SAME two planes;
+                                                     // 3: as 2, plus the Theta passes (v0, J), (v1, J) with J as the third plane
+    constexpr bool three_c = mode == 1 || mode == 3;
     auto issue = [&](LoadSet& L) {
         L.tw = *reinterpret_cast<const cplx*>(Wb + twb);
         L.v[0] = *reinterpret_cast<const cplx*>(P0 + (cob + rowb));
@@ -551,7 +562,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
 #undef SFFT_SWZ
         auto slot = [&](auto SL, bool dual) {
             constexpr int sl = decltype(SL)::value;
-            const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode == 2) ? 1 : 2];
+            const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode >= 2) ? 1 : 2];
             // dual: H.x = |a|^2, H.y = |b|^2 (two real products side by side)
             const cplx H = dual ? make_double2(fma(va.x, va.x, va.y * va.y), fma(vb.x, vb.x, vb.y * vb.y)) : cmulc(va, vb);
             g0x[sl] = fma(H.x, vf, g0x[sl]);
@@ -565,11 +576,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
             }
         };
         if (use0) slot(std::integral_constant<int, 0>{}, d0);
-        if (three_c) {
+        if (mode == 1) {
             if (use1) slot(std::integral_constant<int, 1>{}, false);
             if (use2) slot(std::integral_constant<int, 2>{}, false);
         }
-        if (mode == 2) slot(std::integral_constant<int, 2>{}, false);
+        if (mode >= 2) slot(std::integral_constant<int, 2>{}, false);
+        if (mode == 3) {
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts) {
+                const cplx H = cmulc(L.v[ts], L.v[2]);           // FI_x conj(FJ)
+                t0x[ts] = fma(H.x, vf, t0x[ts]);
+                t0y[ts] = fma(H.y, vf, t0y[ts]);
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    St[ts][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.x, St[ts][0][gq], 0, 0, 0);
+                    St[ts][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], H.y, St[ts][1][gq], 0, 0, 0);
+                    St[ts][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], H.x, St[ts][2][gq], 0, 0, 0);
+                    St[ts][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.y, St[ts][3][gq], 0, 0, 0);
+                }
+            }
+        }
     };
     // Bursts: the loads of DF_BURST steps (4 DF_BURST rows: 256 DF_BURST contiguous bytes per panel and plane) are issued together, two bursts
     // alternating -- a DRAM page then serves one long request run per stream instead of one 256-byte piece per microsecond.
@@ -589,7 +615,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         for (int u = 0; u < DF_BURST; ++u) compute(LB[u], (l + 4 * (DF_BURST + u) + kq < le) ? 1.0 : 0.0);      // (steps past the chunk run on zero weights)
     }
     };
-    if (three) run(std::integral_constant<int, 1>{}); else if (use2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 0>{});
+    if (theta) run(std::integral_constant<int, 3>{});
+    else if (three) run(std::integral_constant<int, 1>{});
+    else if (use2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 0>{});
     if (!act) return;
     auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual) {
         constexpr int sl = decltype(SL)::value;
@@ -626,6 +655,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0);
     if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false);
     if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false);
+    if (theta) {
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+            double sx = t0x[ts], sy = t0y[ts];
+            sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
+            sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
+            cplx* g = Gp + (ts == 0 ? gt0 : gt1) + (size_t)chunk * PHt * Nhp;
+            if (kq == 0) g[(size_t)ht * Nhp + m] = make_double2(sx, sy);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 4 * q + kq + 1;
+                if (r <= ht) {
+                    const double s1 = St[ts][0][q], s2 = St[ts][1][q], s3 = St[ts][2][q], s4 = St[ts][3][q];
+                    g[(size_t)(ht + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
+                    g[(size_t)(ht - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
+                }
+            }
+        }
+    }
 }
 
 // W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)

@@ -195,6 +195,7 @@ struct sfft_plan {
                                         // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 1: greek_g1_mfma (16x16x4), 0: vector kernel (A/B testing)
     G1Group* d_groups = nullptr;        // pass groups of the Omega launch
     int n_groups = 0;
+    int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     int timing = 0;
@@ -812,6 +813,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             auto blank = [&](int v0, int v1, int v2) {
                 G1Group g; g.plane[0] = v0; g.plane[1] = v1; g.plane[2] = v2; g.mask = 0;
                 g.pass[0] = g.pass[1] = g.pass[2] = 0;
+                g.tpass[0] = g.tpass[1] = -1; g.ht = 0;
                 return g;
             };
             auto put = [&](G1Group& g, int sl, int k) { g.mask |= 1 << sl; g.pass[sl] = k; used[k] = 1; };
@@ -856,6 +858,28 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                     done = true;
                 }
                 if (!done) { G1Group g = blank(x, y, x); put(g, 0, k); groups.push_back(g); }
+            }
+            // The Theta passes (x, J), half width w <= 8, ride in the edge groups (x, y) + dual(x, y): the group then loads J as its third
+            // plane, and the separate vector launch (which re-reads all Fij + 1 planes) disappears -- when every kernel plane has such a
+            // group (Fij even) and the short-pass launch holds nothing but the Theta passes
+            {
+                bool ok = p->gamma_analytic && p->n_dense_w == p->n_the && hG <= 8 && !(getenv("SFFT_THETA_FUSED") && atoi(getenv("SFFT_THETA_FUSED")) == 0);
+                std::vector<int> owner((size_t)p->Fij, -1);
+                if (ok) for (size_t gi = 0; gi < groups.size(); ++gi) {
+                    const G1Group& g = groups[gi];
+                    if ((g.mask & 1) && p->passes[g.pass[0]].dual && (g.mask & 4) && g.plane[2] == g.plane[0] && g.plane[0] < p->Fij && g.plane[1] < p->Fij) {
+                        owner[g.plane[0]] = (int)gi; owner[g.plane[1]] = (int)gi;
+                    }
+                }
+                for (int a = 0; a < p->Fij && ok; ++a) ok = owner[a] >= 0;
+                if (ok) {
+                    for (int a = 0; a < p->Fij; ++a) {
+                        G1Group& g = groups[owner[a]];
+                        g.tpass[g.plane[0] == a ? 0 : 1] = the_pass[a];
+                        g.plane[2] = JP; g.ht = hG;
+                    }
+                    p->theta_in_groups = 1;
+                }
             }
             p->n_groups = (int)groups.size();
             PLAN_TRY(dev_alloc(p, &p->d_groups, groups.size()));
@@ -1104,6 +1128,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_dense_w); break;
         case SFFT_Q_SCAFIJ: *v = p->nsca; break;
         case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
+        case SFFT_Q_THETA_FUSED: *v = (p->theta_in_groups && p->g1_mfma >= 3) ? 1 : 0; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
     return SFFT_OK;
@@ -1648,7 +1673,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
-        if (!theta_with_omega && (rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
+        if (!theta_with_omega && !(p->theta_in_groups && p->g1_mfma >= 3) && (rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
         if (p->gamma_analytic) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
 #define ROWMOM_I(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
