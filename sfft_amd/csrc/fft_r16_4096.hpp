@@ -36,7 +36,14 @@ __device__ __forceinline__ void fft4096_core(cplx (&u)[16], int j, cplx* lds, co
 
 // rows, real -> half complex (N1 = 4096), two image rows per transform, spatial factors fused.  Planes [first, first +
 // count) of a launch group share their source image: the workgroup reads its two rows once and produces every plane.
-struct RowGroups { int ngroups; int first[SFFT_MAX_PLANES]; int count[SFFT_MAX_PLANES]; };
+#define ROWMOM_FUSED_MAX 8                           // most moments per row the row pass computes itself (polynomial bases: DK + DB + 1 <= 7)
+struct RowGroups {
+    int ngroups; int first[SFFT_MAX_PLANES]; int count[SFFT_MAX_PLANES];
+    // row moments of a group's source image, sum_n src[l][n] * cy(n)^q for q < mom_nq (cy = (n + 1) / N1), written to mom_out[l][SFFT_MAX_BQ]:
+    // what row_moments computes in a pass of its own over the same image (Delta and the real-space Gamma block), here from the
+    // rows the workgroup has just loaded.  mom_nq = 0: none.
+    double* mom_out[SFFT_MAX_PLANES]; int mom_nq[SFFT_MAX_PLANES];
+};
 
 // Workgroup b takes row pair (b % 8) * pairs_per_xcd + b / 8: consecutive row pairs run on one XCD, so that with a panel
 // layout the pieces of a 128-byte line written by neighbouring row pairs merge in that XCD's L2.
@@ -64,6 +71,36 @@ __global__ void __launch_bounds__(256, 2) rows_r2c_4096(RowsArgs a, RowGroups gr
         const int n = j + 256 * r;
         x0[r] = r0p[n];
         x1[r] = r1p[n] * h1;
+    }
+    const int mnq = grp.mom_nq[blockIdx.y];
+    if (mnq > 0) {                          // (workgroup uniform)
+        double a0[ROWMOM_FUSED_MAX], a1[ROWMOM_FUSED_MAX];
+#pragma unroll
+        for (int q = 0; q < ROWMOM_FUSED_MAX; ++q) a0[q] = a1[q] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double c = (double)(j + 256 * r + 1) * (1.0 / 4096.0);
+            double pw = 1.0;
+#pragma unroll
+            for (int q = 0; q < ROWMOM_FUSED_MAX; ++q) { a0[q] = fma(x0[r], pw, a0[q]); a1[q] = fma(x1[r], pw, a1[q]); pw *= c; }
+        }
+        double* red = reinterpret_cast<double*>(lds);         // [4 waves][2 rows][SFFT_MAX_BQ]
+#pragma unroll
+        for (int q = 0; q < ROWMOM_FUSED_MAX; ++q) {
+            if (q < mnq) {
+                double u0 = a0[q], u1 = a1[q];
+                for (int off = 32; off > 0; off >>= 1) { u0 += __shfl_down(u0, off); u1 += __shfl_down(u1, off); }
+                if ((j & 63) == 0) { red[((j >> 6) * 2 + 0) * SFFT_MAX_BQ + q] = u0; red[((j >> 6) * 2 + 1) * SFFT_MAX_BQ + q] = u1; }
+            }
+        }
+        __syncthreads();
+        if (j < 2 * mnq) {
+            const int row = j / mnq, q = j - row * mnq;
+            const double v = red[(0 * 2 + row) * SFFT_MAX_BQ + q] + red[(1 * 2 + row) * SFFT_MAX_BQ + q]
+                           + red[(2 * 2 + row) * SFFT_MAX_BQ + q] + red[(3 * 2 + row) * SFFT_MAX_BQ + q];
+            if (row == 0 || has1) grp.mom_out[blockIdx.y][(size_t)(l0 + row) * SFFT_MAX_BQ + q] = v;
+        }
+        __syncthreads();                    // the transform below reuses this LDS
     }
     const double hs = 0.5 * scale;
     for (int pp = 0; pp < pcount; ++pp) {

@@ -195,6 +195,7 @@ struct sfft_plan {
                                         // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 1: greek_g1_mfma (16x16x4), 0: vector kernel (A/B testing)
     G1Group* d_groups = nullptr;        // pass groups of the Omega launch
     int n_groups = 0;
+    int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
@@ -898,6 +899,9 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             std::vector<double> cyp((size_t)nd * N1);
             for (int d = 0; d < nd; ++d) for (int x1 = 0; x1 < N1; ++x1)
                 cyp[(size_t)d * N1 + x1] = p->gam_tab ? BS.kby[(size_t)(d / NQB) * N1 + x1] * ipow_host((x1 + 1.0) / N1, d % NQB) : ipow_host((x1 + 1.0) / N1, d);
+            // the 4096^2 fast path with a polynomial kernel basis: the moments come out of the row pass of the forward transforms
+            p->rowmom_fused = (!p->gam_tab && !p->no_fast_fft && !p->no_staged && N0 == 4096 && N1 == 4096 && nd <= ROWMOM_FUSED_MAX && p->nby <= ROWMOM_FUSED_MAX &&
+                               !(getenv("SFFT_ROWMOM_FUSED") && atoi(getenv("SFFT_ROWMOM_FUSED")) == 0)) ? 1 : 0;
             PLAN_TRY(dev_alloc(p, &p->d_cyp, cyp.size()));
             PLAN_HIP(hipMemcpy(p->d_cyp, cyp.data(), cyp.size() * sizeof(double), hipMemcpyHostToDevice));
             PLAN_TRY(dev_alloc(p, &p->d_rowmomI, (size_t)N0 * GAMMA_ND));
@@ -1229,6 +1233,7 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
         RowsArgs rw = ra;                       // unweighted planes (J, plain FFTs) get the table of ones: branch-free kernel
         for (int k = 0; k < nplanes; ++k) { if (!rw.wx[k]) rw.wx[k] = p->d_ones; if (!rw.wy[k]) rw.wy[k] = p->d_ones; }
         RowGroups grp; grp.ngroups = 0;
+        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { grp.mom_out[u] = nullptr; grp.mom_nq[u] = 0; }
         for (int k = 0; k < nplanes; ++k) {
             if (k > 0 && ra.src[k] == ra.src[k - 1]) ++grp.count[grp.ngroups - 1];
             else { grp.first[grp.ngroups] = k; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
@@ -1317,11 +1322,18 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
         RowsArgs ra;
         for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = p->d_ones; ra.wy[u] = p->d_ones; }
         RowGroups grp; grp.ngroups = 0;
+        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { grp.mom_out[u] = nullptr; grp.mom_nq[u] = 0; }
         for (int u = 0; u < n; ++u) {
             ra.src[u] = stages[k0 + u].src; ra.wy[u] = stages[k0 + u].wy;
             if (u > 0 && ra.src[u] == ra.src[u - 1]) ++grp.count[grp.ngroups - 1];
             else { grp.first[grp.ngroups] = u; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
         }
+        if (p->rowmom_fused && d_J && k0 == 0)        // solve pass: the moments of the masked pair from the rows this launch reads anyway
+            for (int gI = 0; gI < grp.ngroups; ++gI) {
+                const double* src = ra.src[grp.first[gI]];
+                if (src == d_J) { grp.mom_out[gI] = p->d_rowmom; grp.mom_nq[gI] = p->nby; }
+                else if (src == d_I) { grp.mom_out[gI] = p->d_rowmomI; grp.mom_nq[gI] = p->gam_nmu; }
+            }
         hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp,
                            p->d_stage + (size_t)k0 * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
@@ -1655,7 +1667,8 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
         if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS))) return rc;
 #define ROWMOM_J(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby)
-        if (p->nby == 1) ROWMOM_J(1); else if (p->nby == 2) ROWMOM_J(2); else if (p->nby == 3) ROWMOM_J(3); else if (p->nby == 4) ROWMOM_J(4);
+        if (p->rowmom_fused) { /* written by rows_r2c_4096 */ }
+        else if (p->nby == 1) ROWMOM_J(1); else if (p->nby == 2) ROWMOM_J(2); else if (p->nby == 3) ROWMOM_J(3); else if (p->nby == 4) ROWMOM_J(4);
 #undef ROWMOM_J
         else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
@@ -1677,6 +1690,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         if (p->gamma_analytic) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
 #define ROWMOM_I(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
+            if (!p->rowmom_fused)
             switch (nd) {           // exactly nd table values per column (a larger template bound re-reads clamped copies)
                 case 1: ROWMOM_I(1); break; case 2: ROWMOM_I(2); break; case 3: ROWMOM_I(3); break; case 4: ROWMOM_I(4); break;
                 case 5: ROWMOM_I(5); break; case 6: ROWMOM_I(6); break; case 7: ROWMOM_I(7); break; default: ROWMOM_I(SFFT_MAX_BQ); break;
