@@ -470,6 +470,9 @@ __global__ void __launch_bounds__(64, 3) greek_g1_mfma4(const cplx* __restrict__
 // waves per SIMD (168 registers, 36 bytes of scratch) 0.53 ms; twiddles by recurrence instead of load + swizzle 0.453 ms; bursts
 // of 2 or 3 steps 0.453 / 0.458 ms.  The memory side and the compute side each need most of the launch and overlap poorly at two
 // waves per SIMD; the memory floor (0.8 GB of planes read once, no partial sums written) would be 0.19 ms.
+// HBM fetch of the launch with the Theta passes aboard: 1.55 GB for 0.94 GB of planes (PMC, profiles/r02_b_*): sibling groups start
+// whenever a slot frees up and drift apart by more rows than the 4 MB L2 holds.  Putting the groups of a tile into ONE workgroup (7 or
+// 4 waves, dispatched together) was measured and dropped: 0.65 / 0.57 ms against 0.51 (the 8-slot CU leaves a slot idle).
 #ifndef DF_BURST
 #define DF_BURST 1     // steps whose loads are issued together (measured: 1, 2, 3 all 0.455 ms at 4096^2)
 #endif
