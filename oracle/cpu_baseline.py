@@ -163,16 +163,21 @@ def measure(N0, N1, w, DK, DB, quick=True):
         t_all, ts_all, st_all, diff = run(ncores, 3, 10, 300.0)
         t_8, ts_8, st_8, _ = run(8, 3, 10, 600.0)
     assert np.isfinite(diff).all()
-    return {"value": 1.0 / t_all, "unit": "image-pairs/s", "mpix_per_s": N0 * N1 / 1e6 / t_all, "cores": ncores, "kind": "port",
+    # headline = the faster of the two thread counts (the restatement's strided column passes and full-size table sweeps stop
+    # scaling well before 128 threads on a two-socket host; both measurements are reported)
+    best_t, best_n = (t_all, ncores) if t_all <= t_8 else (t_8, 8)
+    fmt = lambda ts, full: ("3 warm-ups + median of %d" % len(ts)) if full else ("%d run(s)" % len(ts))
+    return {"value": 1.0 / best_t, "unit": "image-pairs/s", "mpix_per_s": N0 * N1 / 1e6 / best_t, "cores": best_n, "kind": "port",
             "restatement": "C++/OpenMP restatement of the reference's Numpy path (oracle/csrc/sfft_cpu.cpp: same 17 functions, c2c fp64 "
-                           "transforms of the same planes, full-size twiddle planes, per-pixel Construct_FDIFF, LU solve); own "
-                           "mixed-radix Stockham FFT; g++ %s" % " ".join(CXXFLAGS[:3]),
-            "cpu_model": _cpu_model(),
-            "seconds_per_pair": t_all, "runs": ts_all, "stage_s": dict(zip(STAGES, [float(v) for v in st_all])),
+                           "transforms of the same planes, full-size twiddle planes, per-pixel Construct_FDIFF, LU solve), pinned by the "
+                           "reference-made fixtures (tests/test_cpu_restatement.py); own mixed-radix Stockham FFT; g++ %s" % " ".join(CXXFLAGS[:3]),
+            "cpu_model": _cpu_model(), "physical_cores": ncores, "seconds_per_pair": best_t,
+            "all_cores": {"value": 1.0 / t_all, "seconds_per_pair": t_all, "runs": ts_all, "cores": ncores,
+                          "stage_s": dict(zip(STAGES, [float(v) for v in st_all]))},
             "threads_8": {"value": 1.0 / t_8, "seconds_per_pair": t_8, "runs": ts_8, "cores": 8,
                           "stage_s": dict(zip(STAGES, [float(v) for v in st_8]))},
             "sample": "one full GSS (solve on the masked pair + apply) of the %dx%d pair with seed 1234 (pair 0 of the GPU batch), KerHW %d, "
-                      "orders %d/%d, no size scaling: %s at %d threads (all physical cores, one thread per core), %s at 8 threads (the reference's default)"
-                      % (N0, N1, w, DK, DB,
-                         "1 warm-up + median of %d" % len(ts_all) if quick else "3 warm-ups + median of %d" % len(ts_all), ncores,
-                         "%d run(s)" % len(ts_8) if quick else "3 warm-ups + median of %d" % len(ts_8))}
+                      "orders %d/%d, no size scaling: %s at %d threads (all physical cores, one thread per core) and %s at 8 threads (the "
+                      "reference's default NUM_CPU_THREADS_4SUBTRACT); `value` is the faster of the two (%d threads)"
+                      % (N0, N1, w, DK, DB, ("1 warm-up + " + fmt(ts_all, False)) if quick else fmt(ts_all, True), ncores,
+                         fmt(ts_8, not quick), best_n)}
