@@ -154,7 +154,7 @@ struct sfft_plan {
     cplx* d_stage = nullptr;            // fast path: row-pass output, one plane per distinct (image, column factor) (lazy)
     int n_stage_alloc = 0;
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
-    hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr; int no_overlap = 0;
+    hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr, ev_mom = nullptr, ev_gam = nullptr; int no_overlap = 0;
     const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
     cplx* d_gp = nullptr;
     double* d_patches = nullptr; size_t n_patches = 0;
@@ -555,6 +555,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         }
         PLAN_HIP(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
         PLAN_HIP(hipEventCreateWithFlags(&p->ev_pre, hipEventDisableTiming));
+        PLAN_HIP(hipEventCreateWithFlags(&p->ev_mom, hipEventDisableTiming));
+        PLAN_HIP(hipEventCreateWithFlags(&p->ev_gam, hipEventDisableTiming));
     }
     {
         std::vector<double> ones((size_t)std::max(N0, N1), 1.0);
@@ -1101,6 +1103,8 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
     if (p->ev_in) hipEventDestroy(p->ev_in);
     if (p->ev_pre) hipEventDestroy(p->ev_pre);
+    if (p->ev_mom) hipEventDestroy(p->ev_mom);
+    if (p->ev_gam) hipEventDestroy(p->ev_gam);
     delete p;
     return SFFT_OK;
 }
@@ -1674,6 +1678,20 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
     }
+    // The real-space Gamma block (two small kernels on the row moments) does not depend on the spectra: when the moments came out of
+    // the row pass it runs on the plan's second stream, beside the Omega launch, and joins before the system is filled
+    const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !getenv("SFFT_NO_GAMMA_ASIDE");
+    if (gamma_aside) {
+        const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
+        HIPCHK(hipEventRecord(p->ev_mom, s));
+        HIPCHK(hipStreamWaitEvent(p->s2, p->ev_mom, 0));
+        hipLaunchKernelGGL(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, p->s2, d_I, p->d_rowmomI, p->d_tby,
+                           p->gam_tab ? p->d_kby : (const double*)nullptr, nd, p->gam_db, p->w, p->N0, p->N1, p->d_gamR);
+        hipLaunchKernelGGL(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, p->s2, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, NQB,
+                           p->N0, p->d_patches + p->fa.gam_off, p->scale * p->scale);
+        LAUNCH_CHECK();
+        HIPCHK(hipEventRecord(p->ev_gam, p->s2));
+    }
     bool theta_with_omega = false;
     {
         StageTimer t(p, SFFT_ST_GREEK_G1, s);
@@ -1687,7 +1705,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
         if (!theta_with_omega && !(p->theta_in_groups && p->g1_mfma >= 3) && (rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
-        if (p->gamma_analytic) {     // Gamma block: row moments of I, then the patches (no spectra involved)
+        if (p->gamma_analytic && !gamma_aside) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
 #define ROWMOM_I(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
             if (!p->rowmom_fused)
@@ -1716,6 +1734,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
                            p->n_omg, p->d_patches, p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
         LAUNCH_CHECK();
     }
+    if (gamma_aside) HIPCHK(hipStreamWaitEvent(s, p->ev_gam, 0));
     p->have_system = true;
     if (p->overlap_I) {      // sfft_subtract: start the full pair's forward transforms now, beside the dense solve
         const double* dI = p->overlap_I;
