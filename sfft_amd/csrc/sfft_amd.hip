@@ -1484,7 +1484,7 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
         // the whole factorisation as one launch of persistent workgroups (see chol_dataflow)
         const int ntask = 2 + (nbc - 1) * (nbc + 2) / 2;
         hipLaunchKernelGGL(chol_dataflow, dim3(std::min(p->df_groups, ntask)), dim3(256), 0, s, p->d_A, p->ld, n, p->d_tflags, d_queue,
-                           p->d_epoch, p->d_status, p->d_rd, p->d_w16, p->d_trace);
+                           p->d_epoch, p->d_status, p->d_rd, p->d_w16, p->d_winv, p->d_trace);
     } else
     hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
     int step = 0;
@@ -1544,7 +1544,8 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
     HIPCHK(hipMemsetAsync(d_solution, 0, (size_t)p->NEQ * sizeof(double), s));
     const int nblk = (n + CB - 1) / CB;
     if (p->back_variant == 1) {
-        hipLaunchKernelGGL(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
+        if (!dataflow)      // (chol_dataflow leaves the inverses of the diagonal blocks behind itself)
+            hipLaunchKernelGGL(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
         hipLaunchKernelGGL(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->d_epoch, p->d_status);
     } else
     for (int b = nblk - 1; b >= 0; --b) {

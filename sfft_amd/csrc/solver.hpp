@@ -632,6 +632,44 @@ __device__ __forceinline__ void chol_inv16_mfma(const double (*Dl)[CB + 1], cons
     __builtin_amdgcn_wave_barrier();
 }
 
+// W = L^-1 (64 x 64, lower triangular) from L (Dl) and the inverses of its four 16 x 16 diagonal sub-blocks (W16t), by block forward
+// substitution on the matrix cores: column-block c is owned by wave c (c < 3), W_rc = -W_rr sum_{m = c}^{r-1} L_rm W_mc for r = c+1 .. 3.
+// Result in Wf[64][65] (zero above the diagonal).  What chol_inv_diag computes in a launch of its own (64 barrier-separated steps);
+// here it runs in the factoring workgroup AFTER the factor has been published, i.e. off the critical path of the factorisation.
+// Sm: per-wave scratch [4][16][17].  All 256 threads call (barriers inside).
+__device__ __forceinline__ void chol_inv64_mfma(const double (*Dl)[CB + 1], const double (*W16t)[16][W16_LD], double (*Wf)[CB + 1],
+                                                double (*Sm)[16][W16_LD], int tid, int wv, int ln, int lk)
+{
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        Wf[r][c] = ((r >> 4) == (c >> 4)) ? W16t[r >> 4][c & 15][r & 15] : 0.0;
+    }
+    __syncthreads();
+    if (wv < 3) {
+        const int c = wv;
+        for (int r = c + 1; r < 4; ++r) {
+            d4s acc = (d4s){0.0, 0.0, 0.0, 0.0};
+            for (int m = c; m < r; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dl[16 * r + ln][16 * m + 4 * ks + lk], Wf[16 * m + 4 * ks + lk][16 * c + ln], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Sm[wv][lk + 4 * q][ln] = acc[q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            d4s x = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(W16t[r][4 * ks + lk][ln], Sm[wv][4 * ks + lk][ln], x, 0, 0, 0);      // A[i][k] = W_rr[i][k]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Wf[16 * r + lk + 4 * q][16 * c + ln] = -x[q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+}
+
 // X L^T = C for the 64 x 64 tile C held in T (in place), L in Dl (identity beyond its last row), W16t as above.  Each wave owns
 // 16 rows of T and needs no workgroup barrier: for the four 16-column blocks in turn, Y_b = C_b - sum_{b' < b} X_b' L_bb'^T and
 // X_b = Y_b W_bb^T, all as v_mfma_f64_16x16x4_f64 (40 per wave).  The 16 x 16 inverses are only used block-diagonally; the
@@ -667,9 +705,9 @@ __device__ __forceinline__ void df_trsm_mfma(double (*T)[CB + 1], const double (
 
 __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int ld, int n, unsigned int* flags, unsigned int* queue,
                                                      const unsigned int* __restrict__ epoch_ctr, int* __restrict__ status,
-                                                     double* __restrict__ rd, double* __restrict__ w16, unsigned long long* __restrict__ trace)
+                                                     double* __restrict__ rd, double* __restrict__ w16, double* __restrict__ winv, unsigned long long* __restrict__ trace)
 {
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB + 4 * 16 * W16_LD];
     __shared__ int s_task;
 #define DF_TRACE(slot) do { if (trace && tid == 0) trace[(size_t)bj * 16 + (slot)] = wall_clock64(); } while (0)
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // operand tile / the accumulated tile T
@@ -677,6 +715,7 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
     double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
     double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD);
+    double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB);
     const unsigned int epoch = (*epoch_ctr << 8) | DF_EPOCH_TAG;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int ti = tid >> 2, cg = tid & 3;
@@ -878,6 +917,16 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
         if (tid < nbd) __hip_atomic_store(&rd[d0 + tid], L.rdiag[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         df_publish(flags, df_flag_id(g, j, j), epoch, tid);
         DF_TRACE(8);
+        // off the critical path (the factor is out): the full inverse of the diagonal block for the back substitution
+        chol_inv64_mfma(L.Dl, W16t, T, Sm64, tid, wv, ln, lk);
+        {
+            double* Wg = winv + (size_t)j * CB * CB;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int e = tid + 256 * it;
+                Wg[e] = T[e >> 6][e & 63];
+            }
+        }
     }
 #undef DF_TRACE
 }
