@@ -1085,3 +1085,70 @@ def test_lu_redo_after_a_failed_cholesky_attempt_inside_subtract(dev):
         else:
             assert np.isfinite(diff.cpu().numpy()).all()
     plan.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# (h) host-side sharing rules (round-1 advisor findings): configs of one geometry share a cached plan
+# ------------------------------------------------------------------------------------------------
+def test_two_host_threads_sharing_one_cached_plan_get_single_thread_results(dev):
+    """Two threads run GSS through configs that share ONE cached plan (same geometry): the per-plan lock serialises them and each
+    gets exactly the result of a run on its own."""
+    import threading
+    from sfft_amd.sfftcore import SingleSFFTConfigure, GeneralSFFTSubtract
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1, w = 192, 160, 3
+    pairs = [make_pair(N0, N1, seed=40 + k, mask=True, sky=0.0, bkg_scale=0.05) for k in range(2)]
+    cfgs = [SingleSFFTConfigure.SSC(N0, N1, w, 2, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index) for _ in range(2)]
+    assert cfgs[0][1]["plan"] is cfgs[1][1]["plan"]
+    ref = [GeneralSFFTSubtract.GSS(p["REF"], p["SCI"], p["mREF"], p["mSCI"], cfgs[0], VERBOSE_LEVEL=0) for p in pairs]
+    out = [[None] * 6 for _ in range(2)]
+
+    def work(k):
+        torch.cuda.set_device(dev)
+        for it in range(6):
+            out[k][it] = GeneralSFFTSubtract.GSS(pairs[k]["REF"], pairs[k]["SCI"], pairs[k]["mREF"], pairs[k]["mSCI"], cfgs[k], VERBOSE_LEVEL=0)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        for it in range(6):
+            assert np.array_equal(out[k][it][0], ref[k][0]) and np.array_equal(out[k][it][1], ref[k][1])
+
+
+def test_clearing_the_plan_cache_keeps_live_configs_usable(dev):
+    from sfft_amd.plan import clear_plan_cache
+    from sfft_amd.sfftcore import SingleSFFTConfigure, ElementalSFFTSubtract
+    from sfft_amd.utils.synthetic import make_pair
+    pair = make_pair(64, 48, seed=2, mask=False)
+    cfg = SingleSFFTConfigure.SSC(64, 48, 2, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+    s0 = ElementalSFFTSubtract.ESS(pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)[0]
+    clear_plan_cache()
+    s1 = ElementalSFFTSubtract.ESS(pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)[0]       # the config still holds its plan
+    assert np.array_equal(s0, s1)
+    cfg2 = SingleSFFTConfigure.SSC(64, 48, 2, 1, 1, True, VERBOSE_LEVEL=0, CUDA_DEVICE_4SUBTRACT=dev.index)
+    assert cfg2[1]["plan"] is not cfg[1]["plan"]
+    assert np.array_equal(ElementalSFFTSubtract.ESS(pair["mREF"], pair["mSCI"], cfg2, VERBOSE_LEVEL=0)[0], s0)
+
+
+def test_entry_points_leave_the_current_device_alone(dev):
+    """Every C entry point restores the calling thread's HIP device (one device here: the call must at least not disturb it, and
+    tensors created afterwards land on the device torch considers current)."""
+    from sfft_amd.plan import get_plan
+    from sfft_amd.utils.synthetic import make_pair
+    pair = make_pair(64, 64, seed=1, mask=False)
+    before = torch.cuda.current_device()
+    plan = get_plan(64, 64, 2, 1, 1, True, dev.index)
+    plan.subtract(_to(dev, pair["REF"]), _to(dev, pair["SCI"]), _to(dev, pair["mREF"]), _to(dev, pair["mSCI"]))
+    assert torch.cuda.current_device() == before and torch.zeros(1, device="cuda").device.index == before
+
+
+def test_pccp_accepts_host_tensors_with_nans(dev):
+    """Inputs on the host (or another device) are moved to CUDA_DEVICE_4SUBTRACT before the NaN mask is built (advisor finding)."""
+    from sfft_amd import PureCupy_Customized_Packet
+    g = load_golden("c96x80_w3_k2b2_cpr_nan")
+    m = g["meta"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))          # CPU tensors
+    sol, diff = PureCupy_Customized_Packet.PCCP(t(g["REF"]), t(g["SCI"]), t(g["mREF"]), t(g["mSCI"]), m["ForceConv"], m["KerHW"],
+                                                KerPolyOrder=m["DK"], BGPolyOrder=m["DB"], ConstPhotRatio=bool(m["CPR"]),
+                                                CUDA_DEVICE_4SUBTRACT=str(dev.index), VERBOSE_LEVEL=0)
+    assert diff.is_cuda and rel_rms_err(diff.cpu().numpy(), g["DIFF"]) <= 1e-6
