@@ -473,6 +473,17 @@ __global__ void __launch_bounds__(64, 3) greek_g1_mfma4(const cplx* __restrict__
 // HBM fetch of the launch with the Theta passes aboard: 1.55 GB for 0.94 GB of planes (PMC, profiles/r02_b_*): sibling groups start
 // whenever a slot frees up and drift apart by more rows than the 4 MB L2 holds.  Putting the groups of a tile into ONE workgroup (7 or
 // 4 waves, dispatched together) was measured and dropped: 0.65 / 0.57 ms against 0.51 (the 8-slot CU leaves a slot idle).
+// The stamps of SFFT_G1_TRACE (scripts/g1_trace.py) show the siblings of a tile starting within 0.8 us of each other (median) and
+// ending 25 us apart (of 126 us): they drift by ~100 of their 512 rows.  Pace keeping (every wave publishes its row every 32 rows
+// and naps when more than 48 .. 256 rows ahead of its slowest sibling) does bring the fetch down to the ideal -- 0.96 GB, end spread
+// 7 us -- and costs far more than it saves: 0.64 - 0.80 ms (the waves differ in speed, and a napping wave leaves the matrix pipe
+// idle).  Dropped; the re-reads are the price of letting every wave run at its own pace.
+// Where the compute side's cycles go (scripts/micro/mfma4_pattern.hip, profiles/r02_mfma4_pattern.txt): 48 matrix instructions on 48
+// accumulators with 8 different A and 6 different B operands -- this kernel's pattern -- sustain the same 74 TFLOP/s as one operand
+// pair, but 26 fp64 vector instructions per 48 matrix instructions (three complex products and the operand scaling) bring it down to
+// 61 at two waves per SIMD: vector fp64 work is not hidden beside the matrix pipe, it takes ~6 cycles of it per instruction.  A step
+// here carries ~24 fp64 vector instructions, 16 ds_swizzle, ~10 integer instructions and 4 loads beside its 48 matrix instructions;
+// a wave alone on its SIMD needs 1345 cycles per step (720 of them matrix instructions), and two waves sharing a SIMD twice that.
 #ifndef DF_BURST
 #define DF_BURST 1     // steps whose loads are issued together (measured: 1, 2, 3 all 0.455 ms at 4096^2)
 #endif
@@ -490,8 +501,10 @@ struct G1Group {
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
                                                         const G1Group* __restrict__ groups, int ngroup,
                                                         cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
-                                                        int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S)
+                                                        int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S,
+                                                        unsigned long long* __restrict__ trace)
 {
+    const unsigned long long t_start = trace ? wall_clock64() : 0ULL;      // (SFFT_G1_TRACE: start / end stamp and XCD of every wave)
     const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
     const int total = ncb * S * ngroup;
     const int per = (total + 7) >> 3;
@@ -677,6 +690,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
             }
         }
     }
+    if (trace && lane == 0) { trace[3 * (size_t)blockIdx.x] = t_start; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)logical; }
 }
 
 // W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)

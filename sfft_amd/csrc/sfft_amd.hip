@@ -193,6 +193,7 @@ struct sfft_plan {
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 3;                    // Omega passes on the matrix cores: 3 = greek_g1_mfma4g (pass groups that share plane loads, v_mfma_f64_4x4x4_4b_f64),
                                         // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 1: greek_g1_mfma (16x16x4), 0: vector kernel (A/B testing)
+    unsigned long long* d_g1trace = nullptr;   // env SFFT_G1_TRACE=file: per-wave start / end stamps of the grouped Omega launch (development aid)
     G1Group* d_groups = nullptr;        // pass groups of the Omega launch
     int n_groups = 0;
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
@@ -884,6 +885,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                     p->theta_in_groups = 1;
                 }
             }
+            if (getenv("SFFT_G1_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_g1trace, (size_t)3 * 65536)); PLAN_HIP(hipMemset(p->d_g1trace, 0, (size_t)3 * 65536 * 8)); }
             p->n_groups = (int)groups.size();
             PLAN_TRY(dev_alloc(p, &p->d_groups, groups.size()));
             PLAN_HIP(hipMemcpy(p->d_groups, groups.data(), groups.size() * sizeof(G1Group), hipMemcpyHostToDevice));
@@ -1095,7 +1097,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_cyp, p->d_rowmomI, p->d_gamR};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_cyp, p->d_rowmomI, p->d_gamR};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1443,7 +1445,13 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             const int ncb16 = (p->Nh + 15) / 16;
             const int totg = ncb16 * p->S * p->n_groups;
             hipLaunchKernelGGL(greek_g1_mfma4g, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
-                               p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S);
+                               p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
+            if (p->d_g1trace) {     // development aid (SFFT_G1_TRACE=file): dump the wave stamps of this launch
+                hipStreamSynchronize(s);
+                std::vector<unsigned long long> h((size_t)3 * 8 * ((totg + 7) / 8));
+                if (hipMemcpy(h.data(), p->d_g1trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                    if (FILE* f = fopen(getenv("SFFT_G1_TRACE"), "w")) { for (size_t k = 0; k + 2 < h.size(); k += 3) fprintf(f, "%llu %llu %llu\n", h[k], h[k + 1], h[k + 2]); fclose(f); }
+            }
         } else if (p->g1_mfma == 1)        // (SFFT_G1_MFMA=1: the 16 x 16 x 4 instruction, for A/B runs)
             hipLaunchKernelGGL((greek_g1_mfma<2, false>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
                                p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
