@@ -498,6 +498,10 @@ struct G1Group {
 #ifndef G4G_WAVES
 #define G4G_WAVES 2
 #endif
+// MASK = false: every row chunk is a whole number of 8-row iterations (4096 / 8 chunks: 512 rows), so no step ever runs past its chunk
+// and the per-step row mask (a compare, two selects, two multiplies and the masked lag-0 sums) drops out of the loop -- vector
+// instructions are not free beside the matrix pipe here.
+template <bool MASK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
                                                         const G1Group* __restrict__ groups, int ngroup,
                                                         cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     };
     auto compute = [&](const LoadSet& L, double vf) {
         double wx[4], wy[4];
-        const double wx0 = L.tw.x * vf, wy0 = L.tw.y * vf;
+        const double wx0 = MASK ? L.tw.x * vf : L.tw.x, wy0 = MASK ? L.tw.y * vf : L.tw.y;
 #define SFFT_SWZ(v, G) __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x13 | ((4 * (G)) << 5)), \
                                         __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x13 | ((4 * (G)) << 5)))
         wx[0] = SFFT_SWZ(wx0, 0); wx[1] = SFFT_SWZ(wx0, 1); wx[2] = SFFT_SWZ(wx0, 2); wx[3] = SFFT_SWZ(wx0, 3);
@@ -581,8 +585,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
             const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode >= 2) ? 1 : 2];
             // dual: H.x = |a|^2, H.y = |b|^2 (two real products side by side)
             const cplx H = dual ? make_double2(fma(va.x, va.x, va.y * va.y), fma(vb.x, vb.x, vb.y * vb.y)) : cmulc(va, vb);
-            g0x[sl] = fma(H.x, vf, g0x[sl]);
-            g0y[sl] = fma(H.y, vf, g0y[sl]);
+            g0x[sl] = MASK ? fma(H.x, vf, g0x[sl]) : g0x[sl] + H.x;
+            g0y[sl] = MASK ? fma(H.y, vf, g0y[sl]) : g0y[sl] + H.y;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 Sx[sl][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.x, Sx[sl][0][gq], 0, 0, 0);      // S1   (dual: S1 of |A|^2)
@@ -601,8 +605,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts) {
                 const cplx H = cmulc(L.v[ts], L.v[2]);           // FI_x conj(FJ)
-                t0x[ts] = fma(H.x, vf, t0x[ts]);
-                t0y[ts] = fma(H.y, vf, t0y[ts]);
+                t0x[ts] = MASK ? fma(H.x, vf, t0x[ts]) : t0x[ts] + H.x;
+                t0y[ts] = MASK ? fma(H.y, vf, t0y[ts]) : t0y[ts] + H.y;
 #pragma unroll
                 for (int gq = 0; gq < 2; ++gq) {
                     St[ts][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.x, St[ts][0][gq], 0, 0, 0);
@@ -623,12 +627,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         for (int u = 0; u < DF_BURST; ++u) issue(LB[u]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < DF_BURST; ++u) compute(LA[u], (l + 4 * u + kq < le) ? 1.0 : 0.0);
+        for (int u = 0; u < DF_BURST; ++u) compute(LA[u], (!MASK || l + 4 * u + kq < le) ? 1.0 : 0.0);
 #pragma unroll
         for (int u = 0; u < DF_BURST; ++u) issue(LA[u]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < DF_BURST; ++u) compute(LB[u], (l + 4 * (DF_BURST + u) + kq < le) ? 1.0 : 0.0);      // (steps past the chunk run on zero weights)
+        for (int u = 0; u < DF_BURST; ++u) compute(LB[u], (!MASK || l + 4 * (DF_BURST + u) + kq < le) ? 1.0 : 0.0);      // (steps past the chunk run on zero weights)
     }
     };
     if (theta) run(std::integral_constant<int, 3>{});

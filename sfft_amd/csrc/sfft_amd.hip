@@ -1444,8 +1444,13 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
         if (p->g1_mfma >= 3 && p->d_groups && pass0 == 0 && npass == p->n_omg_launch) {
             const int ncb16 = (p->Nh + 15) / 16;
             const int totg = ncb16 * p->S * p->n_groups;
-            hipLaunchKernelGGL(greek_g1_mfma4g, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
-                               p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
+            const bool whole = (p->rows_per_chunk % (8 * DF_BURST)) == 0 && (p->N0 % p->rows_per_chunk) == 0;      // no step runs past its chunk
+            if (whole)
+                hipLaunchKernelGGL(greek_g1_mfma4g<false>, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
+            else
+                hipLaunchKernelGGL(greek_g1_mfma4g<true>, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
             if (p->d_g1trace) {     // development aid (SFFT_G1_TRACE=file): dump the wave stamps of this launch
                 hipStreamSynchronize(s);
                 std::vector<unsigned long long> h((size_t)3 * 8 * ((totg + 7) / 8));
