@@ -56,7 +56,7 @@ CONFIGS = {
 }
 
 
-def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False):
+def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False, omg_counts=None):
     """Algorithmic HBM bytes per stage for ONE pair (solve + apply), as built, and the
     canonical reference-algorithm figure B_alg of SURVEY.md 8(d).  n_colfac = distinct column factors of the kernel basis
     (DK + 1 for a polynomial, Fj for a B-spline tensor basis): one row transform each."""
@@ -64,7 +64,7 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False)
     Nh = N1 // 2 + 1
     c, r = 16, 8
     spec = c * N0 * Nh                                  # one half-spectrum plane
-    n_omg = Fij * (Fij + 1) // 2
+    n_off, n_diag = omg_counts if omg_counts else (Fij * (Fij - 1) // 2, Fij)     # Omega products that are transformed
     out = {
         # forward transforms of the solve pass as built: one row transform per distinct column factor (+ J) into stage planes;
         # the column pass reads every stage plane (from HBM once, its other readers hit L2) and writes Fij + 1 planes
@@ -76,7 +76,7 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False)
         "greek_g1b": (Fij + 1) * spec + r * P,          # Theta passes: Fij planes + FJ; Gamma block: one read of the masked image
         # fp64 flops of the Omega passes: per pass and spectrum element one complex product (6) + 4 real FMAs per lag
         # (the Fij diagonal passes have a real product: half the lag work)
-        "greek_g1_flops": N0 * Nh * ((n_omg - Fij) * (6 + 2 * 4 * (2 * w)) + Fij * (3 + 4 * (2 * w))),
+        "greek_g1_flops": N0 * Nh * (n_off * (6 + 2 * 4 * (2 * w)) + n_diag * (3 + 4 * (2 * w))),
     }
     if theta_fused:      # the Fij Theta passes (half width w) ride in the Omega launch: + the FJ plane, + their flops; the short-pass stage
         out["greek_g1"] += spec                                  # keeps only the Gamma block (one read of the masked image)
@@ -355,7 +355,8 @@ def main():
         iso_stage = {k: v / n_iso for k, v in iso_acc.items()}
         mixed = (not bspline) and w <= 12
         theta_fused = bool(plans[0].query("THETA_FUSED"))
-        ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused)
+        ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused,
+                       (plans[0].query("OMG_OFFDIAG"), plans[0].query("OMG_DIAG")))
         headline = (args.config == 2 and (N0, N1, w) == (4096, 4096, 8))
 
         pmc = {}

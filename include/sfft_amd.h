@@ -48,6 +48,8 @@ enum {
     SFFT_Q_SCAFIJ,                  /* scaling terms of a plan made by sfft_plan_create_varscale (0 otherwise) */
     SFFT_Q_SOLVE_GRAPH,             /* 1 once the factorisation chain of this plan has been captured and replays as a hipGraph */
     SFFT_Q_THETA_FUSED,             /* 1: the Theta passes ride in the Omega launch of this plan (stage GREEK_G1 then carries them) */
+    SFFT_Q_OMG_OFFDIAG,             /* Omega products I_a x conj(I_b), a < b, that are transformed (all Fij (Fij - 1) / 2 unless SFFT_OMG_REDUCE=1) */
+    SFFT_Q_OMG_DIAG,                /* the same for a = b */
     SFFT_Q_COUNT
 };
 

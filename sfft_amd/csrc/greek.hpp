@@ -697,6 +697,189 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     if (trace && lane == 0) { trace[3 * (size_t)blockIdx.x] = t_start; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)logical; }
 }
 
+// ---- redundant Omega passes (polynomial kernel bases) ---------------------------------------------------------------------
+// Omega[(ij),(i'j')](rho) = sum_x I(x) cx^i cy^j * I(x + rho) cx(x0 + r)^i' cy(x1 + e)^j'  (circular).  Where the shift does not wrap,
+// cx(x0 + r) = cx + r / N0 and cy(x1 + e) = cy + e / N1 exactly, so over the INTERIOR pixels of a lag (no wrap in either axis)
+//   Omega_int[(ij),(i'j')] = sum_{u <= i', v <= j'} C(i',u) C(j',v) (r/N0)^(i'-u) (e/N1)^(j'-v) M_(i+u, j+v),
+//   M_ab(rho) = sum_{x interior} I(x) I(x + rho) cx^a cy^b:
+// every pass of a "moment class" (i + i', j + j') carries the same top moment.  One pass per class is transformed (15 of the 21 at
+// orders 2 / 2, 28 of 55 at order 3); the others follow from the moments, lag by lag (omega_derive), once the contribution of the
+// pixels whose shift DOES wrap -- |r| rows and |e| columns at the image border, for every lag -- has been taken out of the kept
+// patches and put into the derived ones.  Those border sums are exact real-space sums (omega_strips): region A = the rows that wrap
+// (all columns), region B = the columns that wrap in the rows that do not; in each the weights factor into a part that is constant
+// along the long axis and a part summed along it ((DK+1)^2 running sums per row or column).  The border columns come from a small
+// transposed copy (edge_cols) so that region B reads contiguously too.  Checked against the reference-made fixtures like every
+// other patch (the 96 x 80, KerHW 8 fixtures have a third of their pixels in the border regions).
+#define OMGR_MAXPAIR 55
+#define OMGR_MAXCLS 28
+struct OmgReduce {
+    int npl, npair, ncls, nskip, h;          // planes, pairs (a <= b, patch order), moment classes, derived pairs, lag half width
+    unsigned char pi[10], pj[10];            // exponents of plane k
+    unsigned char pa[OMGR_MAXPAIR], pb[OMGR_MAXPAIR];      // pair k = (plane pa, plane pb)
+    unsigned char cls_pair[OMGR_MAXCLS];     // the transformed pair of each class, classes in order of total degree
+    unsigned char skip_pair[OMGR_MAXPAIR];   // derived pairs
+};
+
+// Ec[c][x0]: the HE leftmost (c < HE) and HE rightmost columns of the image, one contiguous row per column
+__global__ void __launch_bounds__(256) edge_cols(const double* __restrict__ I, double* __restrict__ Ec, int N0, int N1, int HE)
+{
+    const int x0 = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (x0 >= N0) return;
+    const int x1 = c < HE ? c : N1 - 2 * HE + c;
+    Ec[(size_t)c * N0 + x0] = I[(size_t)x0 * N1 + x1];
+}
+
+template <int DK> struct PolyPl {
+    static constexpr int NE = DK + 1, NPL = (DK + 1) * (DK + 2) / 2, NPAIR = NPL * (NPL + 1) / 2;
+    __host__ __device__ static constexpr int pi(int k) { int c = 0; for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { if (c == k) return i; ++c; } return 0; }
+    __host__ __device__ static constexpr int pj(int k) { int c = 0; for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { if (c == k) return j; ++c; } return 0; }
+};
+
+// part[(lag * 2h + q) * NPAIR + k]: the sum over ONE border line of the lag of I_a(x) I_b(x + rho), pair k = (a <= b) in patch order.
+// Line q < h: row q of region A (exists when q < |r|); line q >= h: column q - h of region B (when q - h < |e|).  One workgroup per
+// (lag, line): 4096 products, (DK+1)^2 running sums, one block reduction.
+template <int DK>
+__global__ void __launch_bounds__(256) omega_strips(const double* __restrict__ I, const double* __restrict__ Ec, int N0, int N1, int h,
+                                                    double* __restrict__ part)
+{
+    typedef PolyPl<DK> PP;
+    constexpr int NE = PP::NE, NPL = PP::NPL, NPAIR = PP::NPAIR;
+    const int PH = 2 * h + 1;
+    const int r = (int)blockIdx.x / PH - h, e = (int)blockIdx.x % PH - h;
+    const int q = blockIdx.y, tid = threadIdx.x;
+    const bool rowline = q < h;
+    const int ql = rowline ? q : q - h;
+    if (ql >= (rowline ? abs(r) : abs(e))) return;
+    const double i0 = 1.0 / (double)N0, i1 = 1.0 / (double)N1;
+    double t[NE][NE];
+#pragma unroll
+    for (int a = 0; a < NE; ++a)
+#pragma unroll
+        for (int b = 0; b < NE; ++b) t[a][b] = 0.0;
+    double wa[NE], wb[NE];                  // powers of the line's own coordinate (unshifted / shifted)
+    wa[0] = wb[0] = 1.0;
+    if (rowline) {
+        // region A: a row whose shift wraps, every column
+        const int x0 = (r > 0 ? N0 - r : 0) + ql;
+        int x0p = x0 + r; if (x0p >= N0) x0p -= N0; if (x0p < 0) x0p += N0;
+        const double* __restrict__ ra = I + (size_t)x0 * N1;
+        const double* __restrict__ rb = I + (size_t)x0p * N1;
+#pragma unroll 4
+        for (int x1 = tid; x1 < N1; x1 += 256) {
+            int x1p = x1 + e; if (x1p >= N1) x1p -= N1; if (x1p < 0) x1p += N1;
+            const double prod = ra[x1] * rb[x1p];
+            const double v = (double)(x1 + 1) * i1, vs = (double)(x1p + 1) * i1;
+            double qa = prod;
+#pragma unroll
+            for (int a = 0; a < NE; ++a) {
+                double qb = qa;
+#pragma unroll
+                for (int b = 0; b < NE; ++b) { t[a][b] += qb; qb *= vs; }
+                qa *= v;
+            }
+        }
+        const double u = (double)(x0 + 1) * i0, us = (double)(x0p + 1) * i0;
+#pragma unroll
+        for (int a = 1; a < NE; ++a) { wa[a] = wa[a - 1] * u; wb[a] = wb[a - 1] * us; }
+    } else {
+        // region B: a column whose shift wraps, in the rows that do not
+        const int x1 = (e > 0 ? N1 - e : 0) + ql;
+        int x1p = x1 + e; if (x1p >= N1) x1p -= N1; if (x1p < 0) x1p += N1;
+        const int ca = x1 < h ? x1 : x1 - (N1 - 2 * h), cbp = x1p < h ? x1p : x1p - (N1 - 2 * h);
+        const double* __restrict__ ea = Ec + (size_t)ca * N0;
+        const double* __restrict__ eb = Ec + (size_t)cbp * N0 + r;
+        const int xlo = r >= 0 ? 0 : -r, xhi = r >= 0 ? N0 - r : N0;
+#pragma unroll 4
+        for (int x0 = xlo + tid; x0 < xhi; x0 += 256) {
+            const double prod = ea[x0] * eb[x0];
+            const double u = (double)(x0 + 1) * i0, us = (double)(x0 + r + 1) * i0;
+            double qa = prod;
+#pragma unroll
+            for (int a = 0; a < NE; ++a) {
+                double qb = qa;
+#pragma unroll
+                for (int b = 0; b < NE; ++b) { t[a][b] += qb; qb *= us; }
+                qa *= u;
+            }
+        }
+        const double v = (double)(x1 + 1) * i1, vs = (double)(x1p + 1) * i1;
+#pragma unroll
+        for (int a = 1; a < NE; ++a) { wa[a] = wa[a - 1] * v; wb[a] = wb[a - 1] * vs; }
+    }
+    __shared__ double red[4][NE * NE];
+    __shared__ double tt[NE][NE];
+#pragma unroll
+    for (int a = 0; a < NE; ++a)
+#pragma unroll
+        for (int b = 0; b < NE; ++b) {
+            double v = t[a][b];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if ((tid & 63) == 0) red[tid >> 6][a * NE + b] = v;
+        }
+    __syncthreads();
+    if (tid < NE * NE) tt[tid / NE][tid % NE] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+    if (tid < NPAIR) {
+        // pair tid = (a <= b): row lines weight the x powers (i, i') and sum the y powers (j, j'); column lines the other way round
+        int a = 0, k = tid;
+        while (k >= NPL - a) { k -= NPL - a; ++a; }
+        const int b = a + k;
+        int ia = 0, ja = 0, ib = 0, jb = 0, c = 0;
+        for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { if (c == a) { ia = i; ja = j; } if (c == b) { ib = i; jb = j; } ++c; }
+        double wA = 1.0, wB = 1.0;
+        const int ea2 = rowline ? ia : ja, eb2 = rowline ? ib : jb;
+        for (int z = 0; z < ea2; ++z) wA *= wa[1];
+        for (int z = 0; z < eb2; ++z) wB *= wb[1];
+        const double sum = rowline ? tt[ja][jb] : tt[ia][ib];
+        part[((size_t)blockIdx.x * 2 * h + q) * NPAIR + tid] = wA * wB * sum;
+    }
+}
+
+// One workgroup (64 threads) per lag: the border sums of the lag (thread k: pair k over its lines), then the interior moments from the
+// transformed patches and the derived patches.  patches: [npair][PH][PH] at omg_off; alpha = the factor the patches carry over the
+// plain correlation sums (SCALE^3).
+__global__ void __launch_bounds__(64) omega_derive(double* __restrict__ patches, const double* __restrict__ part, OmgReduce R,
+                                                   int N0, int N1, double alpha)
+{
+    const int PH = 2 * R.h + 1, lag = blockIdx.x, tid = threadIdx.x;
+    const int r = lag / PH - R.h, e = lag % PH - R.h;
+    __shared__ double strip[OMGR_MAXPAIR];
+    __shared__ double M[7][7];
+    if (tid < R.npair) {
+        double sacc = 0.0;
+        const int nr = abs(r), ne = abs(e);
+        for (int q = 0; q < nr; ++q) sacc += part[((size_t)lag * 2 * R.h + q) * R.npair + tid];
+        for (int q = 0; q < ne; ++q) sacc += part[((size_t)lag * 2 * R.h + R.h + q) * R.npair + tid];
+        strip[tid] = alpha * sacc;
+    }
+    if (tid < 49) M[tid / 7][tid % 7] = 0.0;
+    __syncthreads();
+    if (tid != 0) return;
+    const double rN = (double)r / (double)N0, eN = (double)e / (double)N1;
+    const double rp[4] = {1.0, rN, rN * rN, rN * rN * rN}, ep[4] = {1.0, eN, eN * eN, eN * eN * eN};
+    const double bin[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+    const size_t PP2 = (size_t)PH * PH;
+    for (int c = 0; c < R.ncls; ++c) {
+        const int k = R.cls_pair[c], a = R.pa[k], b = R.pb[k];
+        const int i = R.pi[a], j = R.pj[a], i2 = R.pi[b], j2 = R.pj[b];
+        double val = patches[(size_t)k * PP2 + lag] - strip[k];
+        for (int u = 0; u <= i2; ++u)
+            for (int v = 0; v <= j2; ++v) {
+                if (u == i2 && v == j2) continue;
+                val -= bin[i2][u] * bin[j2][v] * rp[i2 - u] * ep[j2 - v] * M[i + u][j + v];
+            }
+        M[i + i2][j + j2] = val;
+    }
+    for (int q = 0; q < R.nskip; ++q) {
+        const int k = R.skip_pair[q], a = R.pa[k], b = R.pb[k];
+        const int i = R.pi[a], j = R.pj[a], i2 = R.pi[b], j2 = R.pj[b];
+        double val = strip[k];
+        for (int u = 0; u <= i2; ++u)
+            for (int v = 0; v <= j2; ++v) val += bin[i2][u] * bin[j2][v] * rp[i2 - u] * ep[j2 - v] * M[i + u][j + v];
+        patches[(size_t)k * PP2 + lag] = val;
+    }
+}
+
 // W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)
 __global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
 {
@@ -730,6 +913,7 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
                                                 const cplx* __restrict__ root1, const cplx* __restrict__ Yq, double tscale)
 {
     const PatchJob jb = jobs[job0 + blockIdx.y];
+    if (jb.pass < 0) return;                 // a derived Omega patch (omega_derive)
     const int h = jb.h, PH = 2 * h + 1;
     const int r = blockIdx.x;
     if (r >= PH) return;

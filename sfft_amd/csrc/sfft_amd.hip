@@ -133,6 +133,7 @@ struct sfft_plan {
     std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
     std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
+    int n_omg_off = 0, n_omg_diag = 0;  // Omega products actually transformed (off-diagonal / diagonal): all of them unless omg_reduce
     int n_omg_launch = 0;               // Omega pass records that are launched (the rest are partners of dual diagonal passes)
     // polynomial plans: the Gamma block straight from row moments of I (gamma_patches) instead of column-factor passes
     int gamma_analytic = 0; double* d_cyp = nullptr; double* d_rowmomI = nullptr; double* d_gamR = nullptr; GammaArgs ga;
@@ -196,6 +197,8 @@ struct sfft_plan {
     unsigned long long* d_g1trace = nullptr;   // env SFFT_G1_TRACE=file: per-wave start / end stamps of the grouped Omega launch (development aid)
     G1Group* d_groups = nullptr;        // pass groups of the Omega launch
     int n_groups = 0;
+    int omg_reduce = 0;                 // env SFFT_OMG_REDUCE=1: one Omega pass per moment class is transformed, the others are derived (measured: no net gain, off)
+    OmgReduce omgr; double* d_edge = nullptr; double* d_strip = nullptr; hipEvent_t ev_strip = nullptr;
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
@@ -733,8 +736,40 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         const bool dual_diag = p->g1_mfma && hO >= 9 && hO <= 16 && p->Fij >= 2 && !getenv("SFFT_NO_DUAL_DIAG");
         omg_pass.assign((size_t)p->Fij * (p->Fij + 1) / 2, -1);
         auto okey = [&](int a, int b) { return a * p->Fij - (a * (a - 1)) / 2 + (b - a); };      // (a <= b) -> k, the job / patch order
+        // Polynomial kernel bases: the passes of one "moment class" (i + i', j + j') differ by known combinations of lower moments and
+        // by border sums (greek.hpp, "redundant Omega passes"): one pass per class is transformed -- a diagonal pass if the class has
+        // one, else the edge (2m, 2m + 1) that shares its planes with a dual-diagonal pass, else the first -- the rest are derived.
+        std::vector<char> omg_skip(omg_pass.size(), 0);
+        memset(&p->omgr, 0, sizeof(p->omgr));
+        if (p->DK >= 2 && p->DK <= 3 && p->g1_mfma >= 3 && hO >= 9 && hO <= 16 && N0 >= 8 * hO && N1 >= 8 * hO && p->Fij <= 10 &&
+            getenv("SFFT_OMG_REDUCE") && atoi(getenv("SFFT_OMG_REDUCE")) == 1) {
+            OmgReduce& R = p->omgr;
+            R.npl = p->Fij; R.h = hO; R.npair = (int)omg_pass.size();
+            for (int k = 0; k < p->Fij; ++k) { R.pi[k] = (unsigned char)p->kpair[2 * k]; R.pj[k] = (unsigned char)p->kpair[2 * k + 1]; }
+            for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) { R.pa[okey(a, b)] = (unsigned char)a; R.pb[okey(a, b)] = (unsigned char)b; }
+            for (int deg = 0; deg <= 2 * p->DK; ++deg)
+                for (int ca = deg; ca >= 0; --ca) {
+                    const int cb = deg - ca;
+                    int best = -1, rank = 99;
+                    for (int k = 0; k < R.npair; ++k) {
+                        const int a = R.pa[k], b = R.pb[k];
+                        if (R.pi[a] + R.pi[b] != ca || R.pj[a] + R.pj[b] != cb) continue;
+                        const int rk = (a == b) ? 0 : ((a % 2 == 0 && b == a + 1) ? 1 : 2);
+                        if (rk < rank) { rank = rk; best = k; }
+                    }
+                    if (best < 0) continue;
+                    R.cls_pair[R.ncls++] = (unsigned char)best;
+                    for (int k = 0; k < R.npair; ++k) {
+                        const int a = R.pa[k], b = R.pb[k];
+                        if (k != best && R.pi[a] + R.pi[b] == ca && R.pj[a] + R.pj[b] == cb) { omg_skip[k] = 1; R.skip_pair[R.nskip++] = (unsigned char)k; }
+                    }
+                }
+            p->omg_reduce = R.nskip > 0 ? 1 : 0;
+            if (!p->omg_reduce) std::fill(omg_skip.begin(), omg_skip.end(), 0);
+        }
         std::vector<std::pair<int, int>> partners;     // (leader pass, partner plane)
         for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) {
+            if (omg_skip[okey(a, b)]) continue;          // derived by omega_derive: no pass, no partial buffer
             if (a != b || !dual_diag) { omg_pass[okey(a, b)] = add_pass(a, b, 0, hO); continue; }
             if (a % 2 == 0 && a + 1 < p->Fij) {          // leader of the pair (a, a + 1)
                 const int lead = add_pass(a, a + 1, 0, hO);
@@ -750,6 +785,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             omg_pass[okey(pr.second, pr.second)] = rec;
         }
         p->n_omg = (int)omg_pass.size();
+        for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) if (omg_pass[okey(a, b)] >= 0) ++(a == b ? p->n_omg_diag : p->n_omg_off);
         // passes of half width w through greek_g1: Theta, dense Gamma column factors, then the scaling planes' passes
         const int dense0 = (int)p->passes.size();
         for (int a = 0; a < p->Fij; ++a) the_pass.push_back(add_pass(a, JP, 0, hG));
@@ -897,6 +933,11 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_w0tab, (size_t)N0 * p->hm));
         hipLaunchKernelGGL(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
+        if (p->omg_reduce) {
+            PLAN_TRY(dev_alloc(p, &p->d_edge, (size_t)2 * hO * N0));
+            PLAN_TRY(dev_alloc(p, &p->d_strip, (size_t)PHo * PHo * 2 * hO * p->omgr.npair));      // per-line border sums
+            PLAN_HIP(hipEventCreateWithFlags(&p->ev_strip, hipEventDisableTiming));
+        }
         if (p->gamma_analytic) {
             // moment weights: cy^d (polynomial kernel: d = combined degree) or kby[j] cy^d (tabulated kernel: index j (DB + 1) + d)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1;
@@ -1097,7 +1138,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_cyp, p->d_rowmomI, p->d_gamR};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_edge, p->d_strip, p->d_cyp, p->d_rowmomI, p->d_gamR};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1107,6 +1148,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     if (p->ev_pre) hipEventDestroy(p->ev_pre);
     if (p->ev_mom) hipEventDestroy(p->ev_mom);
     if (p->ev_gam) hipEventDestroy(p->ev_gam);
+    if (p->ev_strip) hipEventDestroy(p->ev_strip);
     delete p;
     return SFFT_OK;
 }
@@ -1139,6 +1181,8 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_SCAFIJ: *v = p->nsca; break;
         case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
         case SFFT_Q_THETA_FUSED: *v = (p->theta_in_groups && p->g1_mfma >= 3) ? 1 : 0; break;
+        case SFFT_Q_OMG_OFFDIAG: *v = p->n_omg_off; break;
+        case SFFT_Q_OMG_DIAG: *v = p->n_omg_diag; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
     return SFFT_OK;
@@ -1706,6 +1750,19 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         LAUNCH_CHECK();
         HIPCHK(hipEventRecord(p->ev_gam, p->s2));
     }
+    // border sums of the derived Omega passes (two small real-space kernels on the masked image): beside the Omega launch when the plan
+    // has its second stream, else in line
+    if (p->omg_reduce) {
+        const bool aside = p->s2 && !p->no_overlap && s != nullptr;
+        hipStream_t ss = aside ? p->s2 : s;
+        const int PHo = 2 * p->omgr.h + 1;
+        if (aside && !gamma_aside) { HIPCHK(hipEventRecord(p->ev_mom, s)); HIPCHK(hipStreamWaitEvent(p->s2, p->ev_mom, 0)); }
+        hipLaunchKernelGGL(edge_cols, dim3((p->N0 + 255) / 256, 2 * p->omgr.h), dim3(256), 0, ss, d_I, p->d_edge, p->N0, p->N1, p->omgr.h);
+        if (p->DK == 2) hipLaunchKernelGGL(omega_strips<2>, dim3(PHo * PHo, 2 * p->omgr.h), dim3(256), 0, ss, d_I, p->d_edge, p->N0, p->N1, p->omgr.h, p->d_strip);
+        else hipLaunchKernelGGL(omega_strips<3>, dim3(PHo * PHo, 2 * p->omgr.h), dim3(256), 0, ss, d_I, p->d_edge, p->N0, p->N1, p->omgr.h, p->d_strip);
+        LAUNCH_CHECK();
+        if (aside) HIPCHK(hipEventRecord(p->ev_strip, p->s2));
+    }
     bool theta_with_omega = false;
     {
         StageTimer t(p, SFFT_ST_GREEK_G1, s);
@@ -1746,6 +1803,12 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
                            p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
         hipLaunchKernelGGL(greek_g2, dim3(2 * p->w + 1, (int)p->jobs.size() - p->n_omg), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs,
                            p->n_omg, p->d_patches, p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
+        if (p->omg_reduce) {
+            if (p->s2 && !p->no_overlap && s != nullptr) HIPCHK(hipStreamWaitEvent(s, p->ev_strip, 0));
+            const int PHo = 2 * p->omgr.h + 1;
+            hipLaunchKernelGGL(omega_derive, dim3(PHo * PHo), dim3(64), 0, s, p->d_patches + p->fa.omg_off, p->d_strip, p->omgr,
+                               p->N0, p->N1, p->scale * p->scale * p->scale);
+        }
         LAUNCH_CHECK();
     }
     if (gamma_aside) HIPCHK(hipStreamWaitEvent(s, p->ev_gam, 0));

@@ -1032,6 +1032,30 @@ def test_generic_fft_variants_agree(dev, shape, w):
     assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
 
 
+@pytest.mark.parametrize("shape,w,DK", [((320, 288), 8, 2), ((4096, 4096), 8, 2), ((512, 384), 5, 3)])
+def test_derived_omega_patches_equal_transformed_ones(dev, shape, w, DK):
+    """SFFT_OMG_REDUCE=1 (off by default: no net gain measured): Omega products I_a conj(I_b) whose polynomial degrees add up to
+    the same total are shifted moments of each other, so one per class is transformed and the others come from the interior
+    moments plus exact border sums (omega_strips / omega_derive).  Same linear system to rounding."""
+    from sfft_amd.plan import Plan
+    from sfft_amd.utils.synthetic import make_pair
+    pair = make_pair(*shape, seed=77 + w, mask=True)
+    os.environ["SFFT_OMG_REDUCE"] = "1"
+    try:
+        probe = Plan(shape[0], shape[1], w, DK, 1, True, device=dev.index)
+    finally:
+        os.environ.pop("SFFT_OMG_REDUCE", None)
+    Fij = (DK + 1) * (DK + 2) // 2
+    n_tr = probe.query("OMG_OFFDIAG") + probe.query("OMG_DIAG")
+    probe.close()
+    assert n_tr == (15 if DK == 2 else 28) and n_tr < Fij * (Fij + 1) // 2     # one product per pair of total degrees (i + i', j + j')
+    full = _subtract_with_env(dev, {}, shape, w, DK, 1, pair)
+    red = _subtract_with_env(dev, {"SFFT_OMG_REDUCE": "1"}, shape, w, DK, 1, pair)
+    assert np.max(np.abs(red[2] - full[2])) <= 1e-11 * np.max(np.abs(full[2]))
+    assert np.array_equal(red[3], full[3])
+    assert rms(red[1] - full[1]) <= 1e-7 * rms(full[1])
+
+
 def test_solver_chain_replays_as_graph_on_a_side_stream(dev):
     """On a capturable stream the ~35 launches of the factorisation and back substitution are captured once per plan and
     replayed with hipGraphLaunch (flag stamps come from a device counter, so the arguments are constant).  Same solution as
