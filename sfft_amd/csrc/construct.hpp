@@ -242,11 +242,14 @@ __global__ void __launch_bounds__(256, (W > 8 ? 2 : 4)) vconv_mixed(const cplx* 
 // both rows (row y feeds window slot q, row y + 1 slot q + 1), which halves the LDS traffic and doubles the arithmetic behind
 // every LDS round trip; the window has L + 1 slots and slides by two.
 template <int DK, int W, int KS>
-__global__ void __launch_bounds__(256, 3) vconv_mixed2(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+__global__ void __launch_bounds__(256, (DK <= 2 ? 2 : 3)) vconv_mixed2(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
                                                        const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
-                                                       cplx* __restrict__ trash)
+                                                       cplx* __restrict__ trash, int Rrt)
 {
-    constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2, NSRC = (KS * L + 1) / 2 * 2, R = KS * L - 2 * W;
+    // Rrt > 0: output rows per stream chosen by the host (a whole number of resident rounds, see apply_finish); else KS * L - 2 W
+    constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2;
+    constexpr bool PIPE = FIJ <= 6;
+    const int R = Rrt > 0 ? Rrt : KS * L - 2 * W, NSRC = (R + 2 * W + 1) / 2 * 2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* ctab = reinterpret_cast<cplx*>(smem_raw);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -267,24 +270,56 @@ __global__ void __launch_bounds__(256, 3) vconv_mixed2(const cplx* __restrict__ 
     for (int q = 0; q <= L; ++q) acc[q] = make_double2(0.0, 0.0);
     int y = x0 - W;
     if (y < 0) y += N0;
+    // the two source rows of a step are fetched one step ahead: a wave shares its SIMD with one or two others at most, which
+    // does not hide a trip to HBM at the top of every step (measured: 1.1 - 1.6 us of a 6 us step)
+    cplx S0[NJ], S1[NJ], T0[NJ], T1[NJ];
+    double f0[NJ], f1[NJ], g0[NJ], g1[NJ];
+    {
+        const int y1 = (y + 1 == N0) ? 0 : y + 1;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            T0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            T1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
+            g0[jj] = kbx[(size_t)jj * N0 + y];
+            g1[jj] = kbx[(size_t)jj * N0 + y1];
+        }
+        y = (y1 + 1 == N0) ? 0 : y1 + 1;
+    }
 #pragma unroll 1
     for (int sI = 0; sI < NSRC; sI += 2) {
         int opq;
         asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
         const cplx* __restrict__ ct = ctab + cl + opq;
         const int y1 = (y + 1 == N0) ? 0 : y + 1;
-        cplx S0[NJ], S1[NJ];
-        double f0[NJ], f1[NJ];
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            S0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
-            S1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
-            f0[jj] = kbx[(size_t)jj * N0 + y];
-            f1[jj] = kbx[(size_t)jj * N0 + y1];
+        for (int jj = 0; jj < NJ; ++jj) { S0[jj] = T0[jj]; S1[jj] = T1[jj]; f0[jj] = g0[jj]; f1[jj] = g1[jj]; }
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {       // (the rows after the last step's are read and dropped: any row index is valid)
+            T0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            T1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
+            g0[jj] = kbx[(size_t)jj * N0 + y];
+            g1[jj] = kbx[(size_t)jj * N0 + y1];
+        }
+        // PIPE (up to six terms): the table entries of tap q + 1 are read from LDS while tap q is computed; the scheduling fences
+        // keep exactly one tap of reads in flight (without them the compiler issues all FIJ * L reads up front and spills)
+        cplx cn[PIPE ? FIJ : 1];
+        if (PIPE) {
+#pragma unroll
+            for (int t = 0; t < FIJ; ++t) cn[t] = ct[(t * L + 0) * 16];
         }
 #pragma unroll
         for (int q = 0; q < L; ++q) {           // tap a = q - W
             __builtin_amdgcn_sched_barrier(0);
+            cplx cc[PIPE ? FIJ : 1];
+            if (PIPE) {
+#pragma unroll
+                for (int t = 0; t < FIJ; ++t) cc[t] = cn[t];
+                if (q + 1 < L) {
+#pragma unroll
+                    for (int t = 0; t < FIJ; ++t) cn[t] = ct[(t * L + q + 1) * 16];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             double ax = acc[q].x, ay = acc[q].y, bx = acc[q + 1].x, by = acc[q + 1].y;
 #pragma unroll
             for (int jj = 0; jj <= DK; ++jj) {
@@ -292,7 +327,8 @@ __global__ void __launch_bounds__(256, 3) vconv_mixed2(const cplx* __restrict__ 
 #pragma unroll
                 for (int ii = 0; ii <= DK - jj; ++ii) {
                     const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;
-                    const cplx c = ct[(t * L + q) * 16];
+                    const cplx c = PIPE ? cc[PIPE ? t : 0] : ct[(t * L + q) * 16];
+                    if (ii == 0) { ex = c.x; ey = c.y; gx = c.x; gy = c.y; continue; }        // cx^0 = 1 (polynomial plans only take this path)
                     ex = fma(f0[ii], c.x, ex); ey = fma(f0[ii], c.y, ey);
                     gx = fma(f1[ii], c.x, gx); gy = fma(f1[ii], c.y, gy);
                 }
@@ -322,6 +358,122 @@ __global__ void __launch_bounds__(256, 3) vconv_mixed2(const cplx* __restrict__ 
         acc[L - 1] = make_double2(0.0, 0.0);
         acc[L] = make_double2(0.0, 0.0);
         y = (y1 + 1 == N0) ? 0 : y1 + 1;
+    }
+}
+
+// vconv_direct: the same sum, one output element per thread with no sliding window, for the last few spectrum columns [m0, Nh).
+// With Nh = N1 / 2 + 1 the 16-column tiles of vconv_mixed2 end in a tile holding the Nyquist column alone; taking that column
+// here leaves the main launch a tile count that divides the chip evenly (128 tiles x 4 = two workgroups per CU at 4096^2).
+template <int DK>
+__global__ void __launch_bounds__(256) vconv_direct(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+                                                    const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay, int W, int m0)
+{
+    constexpr int NJ = DK + 1;
+    const int x = blockIdx.x * 256 + threadIdx.x, m = m0 + blockIdx.y;
+    if (x >= N0 || m >= Nh) return;
+    const int L = 2 * W + 1;
+    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(m), rs = (size_t)lay.rstride;
+    double ax = 0.0, ay = 0.0;
+    for (int q = 0; q < L; ++q) {               // tap a = q - W: source row y = x - a
+        int y = x - (q - W);
+        if (y < 0) y += N0;
+        if (y >= N0) y -= N0;
+        double fx[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) fx[jj] = kbx[(size_t)jj * N0 + y];
+#pragma unroll
+        for (int jj = 0; jj <= DK; ++jj) {
+            const cplx S = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            double ex = 0.0, ey = 0.0;
+#pragma unroll
+            for (int ii = 0; ii <= DK - jj; ++ii) {
+                const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;
+                const cplx c = Ctab[((size_t)t * L + q) * Nhp + m];
+                if (ii == 0) { ex = c.x; ey = c.y; continue; }
+                ex = fma(fx[ii], c.x, ex);
+                ey = fma(fx[ii], c.y, ey);
+            }
+            ax = fma(S.x, ex, fma(-S.y, ey, ax));
+            ay = fma(S.x, ey, fma(S.y, ex, ay));
+        }
+    }
+    D[mo + (size_t)x * rs] = make_double2(ax, ay);
+}
+
+// vconv_mixed3: register-stationary taps.  Three lanes share a spectrum column; lane group g keeps the FIJ x TPG table entries of
+// the taps q = g TPG .. g TPG + TPG - 1 (TPG = ceil(L / 3)) in registers for the whole walk, so the inner loop has no LDS traffic
+// at all: per source row TPG x 24 FMAs on register operands against 3 + 3 loads.  Group g walks source rows shifted by its first
+// tap, so that at every step the three groups complete their parts of the SAME output row; two lane shuffles add them up and
+// group 0 stores.  A wave is 20 columns (five 4-column panels) x 3 groups; the walk is unrolled TPG times so that the sliding
+// window of TPG accumulators never moves between registers.  R output rows per wave; the first TPG - 1 steps only fill the window.
+template <int DK, int W>
+__global__ void __launch_bounds__(256, 2) vconv_mixed3(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+                                                       const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay, int R)
+{
+    constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2, TPG = (L + 2) / 3, NC = 20;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane / NC, cl = lane - g * NC;
+    const int gc = g < 3 ? g : 2;
+    const int m = blockIdx.x * NC + cl;
+    const bool active = g < 3 && m < Nh;
+    const int mc = m < Nh ? m : Nh - 1;
+    const int X0 = (blockIdx.y * 4 + wv) * R;          // first output row of this wave
+    if (X0 >= N0) return;
+    cplx c[FIJ][TPG];
+#pragma unroll
+    for (int t = 0; t < FIJ; ++t)
+#pragma unroll
+        for (int j = 0; j < TPG; ++j) {
+            const int q = gc * TPG + j;
+            c[t][j] = (q < L) ? Ctab[((size_t)t * L + (size_t)q) * Nhp + mc] : make_double2(0.0, 0.0);
+        }
+    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(mc), rs = (size_t)lay.rstride;
+    cplx acc[TPG];
+#pragma unroll
+    for (int j = 0; j < TPG; ++j) acc[j] = make_double2(0.0, 0.0);
+    // step s completes output row X0 - (TPG - 1) + s; group g is then at source row (that row) - (first tap of g) = ... - (g TPG - W)
+    int y = (X0 - (TPG - 1) - (gc * TPG - W)) % N0;
+    if (y < 0) y += N0;
+    const int nstep = R + TPG - 1;
+#pragma unroll 1
+    for (int s0 = 0; s0 < nstep; s0 += TPG) {
+#pragma unroll
+        for (int u = 0; u < TPG; ++u) {
+            cplx S[NJ];
+            double fx[NJ];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                S[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+                fx[jj] = jj ? kbx[(size_t)jj * N0 + y] : 1.0;
+            }
+#pragma unroll
+            for (int j = 0; j < TPG; ++j) {          // tap g TPG + j of source row y lands in the output row of window slot (u + j) mod TPG
+                const int sl = (u + j) % TPG;
+                double ax = acc[sl].x, ay = acc[sl].y;
+#pragma unroll
+                for (int jj = 0; jj <= DK; ++jj) {
+                    double ex = 0.0, ey = 0.0;                         // E_j = sum_i cx^i[y] C'_(i,j)[a]
+#pragma unroll
+                    for (int ii = 0; ii <= DK - jj; ++ii) {
+                        const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;
+                        if (ii == 0) { ex = c[t][j].x; ey = c[t][j].y; continue; }           // cx^0 = 1
+                        ex = fma(fx[ii], c[t][j].x, ex);
+                        ey = fma(fx[ii], c[t][j].y, ey);
+                    }
+                    ax = fma(S[jj].x, ex, fma(-S[jj].y, ey, ax));
+                    ay = fma(S[jj].x, ey, fma(S[jj].y, ex, ay));
+                }
+                acc[sl] = make_double2(ax, ay);
+            }
+            // window slot u is complete in all three groups
+            double vx = acc[u].x, vy = acc[u].y;
+            vx += __shfl_down(vx, NC) + __shfl_down(vx, 2 * NC);
+            vy += __shfl_down(vy, NC) + __shfl_down(vy, 2 * NC);
+            acc[u] = make_double2(0.0, 0.0);
+            const int st = s0 + u, xo = X0 - (TPG - 1) + st;
+            if (g == 0 && active && st >= TPG - 1 && st < nstep && xo < N0) D[mo + (size_t)xo * rs] = make_double2(vx, vy);
+            if (++y == N0) y = 0;
+        }
     }
 }
 

@@ -187,7 +187,11 @@ struct sfft_plan {
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
-    int vconv_rp = 2;                   // env SFFT_VCONV_RP=1: mixed-domain apply one source row at a time (KerHW <= 8 has the two-row kernel)
+    int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row,
+                                        // 3: register-stationary taps (vconv_mixed3: measured 2.5x slower, the walk is load-latency bound at 2 waves per SIMD)
+    int num_cu = 256;
+    int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
+    int vconv3_r = 0;                   // env SFFT_VCONV3_R: output rows per wave of vconv_mixed3 (0: whole resident rounds)
     int theta_mfma = 0;                 // env SFFT_THETA_MFMA=1: Theta passes in the Omega passes' matrix-core launch (3.13 -> 3.05 ms for one pair,
                                         // but 488 -> 463 pairs/s pipelined: the vector launch overlaps better with the other pairs' kernels)
     int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
@@ -515,6 +519,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (getenv("SFFT_NO_GRAPH")) p->use_graph = 0;
     if (getenv("SFFT_TEST_FAIL_CHOL")) p->test_fail_chol = 1;
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
+    if (const char* ev = getenv("SFFT_VCONV3_R")) p->vconv3_r = atoi(ev);
+    if (const char* ev = getenv("SFFT_VCONV_R")) p->vconv_r = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -551,6 +557,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         if (const char* ev = getenv("SFFT_S2_CUMASK")) pat = (uint32_t)strtoul(ev, nullptr, 0);
         hipDeviceProp_t prop;
         PLAN_HIP(hipGetDeviceProperties(&prop, device));
+        p->num_cu = prop.multiProcessorCount;
         const int nwords = (prop.multiProcessorCount + 31) / 32;
         std::vector<uint32_t> mask(nwords, pat);
         if (pat == 0 || hipExtStreamCreateWithCUMask(&p->s2, (uint32_t)nwords, mask.data()) != hipSuccess) {
@@ -1857,14 +1864,55 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         hipLaunchKernelGGL(kernel_ctab_mixed, dim3((p->Nhp + 255) / 256, p->Fij * LT), dim3(256), 0, s, d_solution, p->d_ctabm, p->L, p->L, p->w,
                            p->w, p->vw, p->Nh, p->Nhp, p->N1, p->ax1.root, (double)p->N0 * p->scale);
         constexpr int KS = 4;       // source rows per stream = KS * L (3..10 measured: 4 is best at KerHW 8)
-        const int R = KS * LT - 2 * p->vw, nstreams = (p->N0 + R - 1) / R;
-        dim3 g((p->Nh + 15) / 16, (nstreams + 15) / 16);
+        int R = KS * LT - 2 * p->vw, Rrt = 0, ntile = (p->Nh + 15) / 16, m_direct = p->Nh;
+        if (p->vconv_rp == 2 && p->vw <= 8 && p->vconv_r != 0) {
+            // the walk is fp64-VALU bound and a workgroup puts one wave on each SIMD of its CU, so the launch takes
+            // (workgroups per CU, rounded up) x (steps per stream): pick the stream length that minimises it.  A last tile of one or
+            // two columns (the Nyquist column of an even N1) goes to vconv_direct, so that it does not cost a round of its own.
+            const int rem = p->Nh % 16;
+            if (rem >= 1 && rem <= 2 && ntile > 1) { m_direct = p->Nh - rem; --ntile; }
+            if (p->vconv_r > 0) { R = Rrt = p->vconv_r; }
+            else {
+                double best = 1e30;
+                for (int y = 1; y <= (p->N0 + 255) / 256; ++y) {
+                    const int Rc = (p->N0 + 16 * y - 1) / (16 * y);
+                    if (Rc < 16 && y > 1) break;
+                    const int occ = p->DK <= 2 ? 2 : 3;          // workgroups resident per CU (launch bounds of vconv_mixed2)
+                    const int wgs = ntile * y, rounds = (wgs + occ * p->num_cu - 1) / (occ * p->num_cu);
+                    const int k = rounds > 1 ? rounds * occ : (wgs + p->num_cu - 1) / p->num_cu;
+                    const double cost = (double)k * ((Rc + 2 * p->vw + 1) / 2) * (k == 1 ? 1.6 : 1.0);      // (a lone wave issues fp64 FMAs at 0.6 of the rate)
+                    if (cost < best) { best = cost; R = Rrt = Rc; }
+                }
+            }
+        }
+        const int nstreams = (p->N0 + R - 1) / R;
+        dim3 g(ntile, (nstreams + 15) / 16);
         const size_t lds = (size_t)p->Fij * LT * 16 * sizeof(cplx);
 #define VCONV_LAUNCH(DKT, WT) do { \
-        if (p->vconv_rp == 2 && WT <= 8) { \
+        if (p->vconv_rp == 3 && WT <= 8 && ((DKT + 1) * (DKT + 2) / 2) * ((2 * WT + 3) / 3) <= 40) { \
+        /* register-stationary taps: R output rows per wave, chosen so that the launch is a whole number of resident rounds */ \
+        int R3 = p->vconv3_r; \
+        const int ctiles = (p->Nh + 19) / 20; \
+        if (R3 <= 0) { \
+            const int slots = 2 * p->num_cu;                     /* workgroups resident at 2 waves per SIMD */ \
+            int best = 0; double bestc = 1e30; \
+            for (int cand = 48; cand <= 512; ++cand) { \
+                const int wgs = ctiles * ((((p->N0 + cand - 1) / cand) + 3) / 4); \
+                const int rounds = (wgs + slots - 1) / slots; \
+                const double cost = (double)rounds * (cand + (2 * WT + 3) / 3 - 1 + 12); \
+                if (cost < bestc) { bestc = cost; best = cand; } \
+            } \
+            R3 = best; \
+        } \
+        dim3 g3(ctiles, ((p->N0 + R3 - 1) / R3 + 3) / 4); \
+        hipLaunchKernelGGL((vconv_mixed3<(DKT <= 2 || WT <= 4 ? DKT : 2), (WT <= 8 ? WT : 8)>), g3, dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
+                           p->Nhp, p->lay, R3); } else \
+        if (p->vconv_rp >= 2 && WT <= 8) { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        if (m_direct < p->Nh) hipLaunchKernelGGL(vconv_direct<DKT>, dim3((p->N0 + 255) / 256, p->Nh - m_direct), dim3(256), 0, s, FI, FD, p->d_ctabm, \
+                                                 p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, p->vw, m_direct); \
         hipLaunchKernelGGL((vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
-                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } else { \
+                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp, Rrt); } else { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
                            p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } } while (0)
