@@ -49,6 +49,6 @@ doc = {
                       "mean over the solve and apply launches scaled to the solve launch"),
     "greek_g1": entry(["greek_g1_mfma4g", "greek_g1_mfma<2, false>", "greek_g1_mfma4<2>"]),
     "greek_g1b": entry(["greek_g1<8, 2>", "greek_g1_row0", "row_moments<5>", "gamma_rows", "gamma_patches"]),
-    "construct": entry(["vconv_mixed2<2, 8, 4>", "vconv_mixed<2, 8, 4>", "kernel_ctab_mixed"]),
+    "construct": entry(["vconv_mixed2<2, 8, 4>", "vconv_mixed<2, 8, 4>", "vconv_direct<2>", "kernel_ctab_mixed"]),
 }
 print(json.dumps(doc, indent=1))
