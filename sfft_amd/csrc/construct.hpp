@@ -364,17 +364,17 @@ __global__ void __launch_bounds__(256, (DK <= 2 ? 2 : 3)) vconv_mixed2(const cpl
 // vconv_direct: the same sum, one output element per thread with no sliding window, for the last few spectrum columns [m0, Nh).
 // With Nh = N1 / 2 + 1 the 16-column tiles of vconv_mixed2 end in a tile holding the Nyquist column alone; taking that column
 // here leaves the main launch a tile count that divides the chip evenly (128 tiles x 4 = two workgroups per CU at 4096^2).
-template <int DK>
+template <int DK, int W>
 __global__ void __launch_bounds__(256) vconv_direct(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
-                                                    const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay, int W, int m0)
+                                                    const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay, int m0)
 {
-    constexpr int NJ = DK + 1;
+    constexpr int NJ = DK + 1, L = 2 * W + 1;
     const int x = blockIdx.x * 256 + threadIdx.x, m = m0 + blockIdx.y;
     if (x >= N0 || m >= Nh) return;
-    const int L = 2 * W + 1;
     const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(m), rs = (size_t)lay.rstride;
     double ax = 0.0, ay = 0.0;
-    for (int q = 0; q < L; ++q) {               // tap a = q - W: source row y = x - a
+#pragma unroll
+    for (int q = 0; q < L; ++q) {               // tap a = q - W: source row y = x - a (unrolled: the loads of all taps go out together)
         int y = x - (q - W);
         if (y < 0) y += N0;
         if (y >= N0) y -= N0;

@@ -1909,8 +1909,8 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
                            p->Nhp, p->lay, R3); } else \
         if (p->vconv_rp >= 2 && WT <= 8) { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        if (m_direct < p->Nh) hipLaunchKernelGGL(vconv_direct<DKT>, dim3((p->N0 + 255) / 256, p->Nh - m_direct), dim3(256), 0, s, FI, FD, p->d_ctabm, \
-                                                 p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, p->vw, m_direct); \
+        if (m_direct < p->Nh) hipLaunchKernelGGL((vconv_direct<DKT, (WT <= 8 ? WT : 8)>), dim3((p->N0 + 255) / 256, p->Nh - m_direct), dim3(256), 0, s, FI, FD, \
+                                                 p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, m_direct); \
         hipLaunchKernelGGL((vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
                            p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp, Rrt); } else { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \

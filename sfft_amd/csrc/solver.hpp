@@ -27,6 +27,8 @@ __global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__
     }
 }
 
+typedef double d4s __attribute__((ext_vector_type(4)));
+
 // 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no IEEE division / sqrt sequences on the
 // critical path of the factorisation)
 __device__ __forceinline__ double rsqrt_nr(double d)
@@ -60,10 +62,16 @@ struct PanelLds {
 // Factor the CB x CB diagonal block held as a[q] = D[i][cg + 4 q] by thread (i = tid >> 2, cg = tid & 3) (identity padding
 // beyond nb); on return L.Dl holds the lower-triangular factor and L.rdiag the reciprocal diagonal.  All 256 threads call.
 // Vd (optional, [CB][4]): row 4 jq + k receives row k of the INVERSE of the 4 x 4 pivot block of step jq (used by chol_inv16_mfma).
+// MF (chol_dataflow): thread (i = 16 wave + (lane & 15), cg = lane >> 4) instead -- then a[4 t .. 4 t + 3] is the accumulator of a
+// v_mfma_f64_16x16x4_f64 whose rows are the columns 16 t .. 16 t + 15 of the block and whose columns are the wave's 16 rows, and the
+// rank-4 update of step 4 is one matrix instruction per 16-column tile (A = -F[column][k], zero for the finished columns;
+// B = F[row][k], the thread's own final value) instead of up to 60 FMAs and 60 LDS reads; Vd is then computed once after the
+// last step from the factor in LDS, not on the way.
+template <bool MF = false>
 __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, int tid, int nb, bool report, int* __restrict__ status,
                                                  double (*Vd)[4] = nullptr)
 {
-    const int i = tid >> 2, cg = tid & 3;
+    const int i = MF ? 16 * (tid >> 6) + (tid & 15) : tid >> 2, cg = MF ? (tid >> 4) & 3 : tid & 3;
     double (&Rw)[CB][4] = L.Rw;
     double (&Fw)[CB][4] = L.Fw;
     double (&rdiag)[CB] = L.rdiag;
@@ -101,7 +109,7 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
         Fw[i][cg] = lf;
         if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
-        if (Vd && (tid >> 4) == 4) {         // sixteen lanes of wave 1 (off the stores above): element (k, c) of the inverse of the pivot block
+        if (!MF && Vd && (tid >> 4) == 4) {         // sixteen lanes of wave 1 (off the stores above): element (k, c) of the inverse of the pivot block
             // [[1/rs0], [t10, 1/rs1], [t20, t21, 1/rs2], [t30, t31, t32, 1/rs3]]
             const int k = (tid >> 2) & 3, c = tid & 3;
             const double v10 = -t10 * rs0 * rs1, v21 = -t21 * rs1 * rs2, v32 = -t32 * rs2 * rs3;
@@ -114,6 +122,22 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
             Vd[j0 + k][c] = (k == 0) ? r0v : (k == 1) ? r1v : (k == 2) ? r2v : r3v;
         }
         __syncthreads();
+        if (MF) {
+            if (jq < 15) {
+                const int wvm = tid >> 6, l15 = tid & 15;
+#pragma unroll
+                for (int t = (jq + 1) / 4; t < 4; ++t) {
+                    if (t <= wvm) {                  // (wave uniform) tiles right of the wave's diagonal tile are never read
+                        const int col = 16 * t + l15;
+                        const double fc = Fw[col][cg];
+                        const double aop = (col > j0 + 3) ? -fc : 0.0;
+                        d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, lf, acc, 0, 0, 0);
+                        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+                    }
+                }
+            }
+        } else
         if (jq < 15) {
             const double f0 = Fw[i][0], f1 = Fw[i][1], f2 = Fw[i][2], f3 = Fw[i][3];
 #pragma unroll
@@ -129,6 +153,22 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         L.Dl[i][c] = (c <= i) ? a[q] : 0.0;
     }
     __syncthreads();
+    if (MF && Vd) {
+        // element (k, c) of the inverse of the 4 x 4 pivot block b = [[1/rs0], [t10, 1/rs1], [t20, t21, 1/rs2], [t30, t31, t32, 1/rs3]]
+        const int b = tid >> 4, k = (tid >> 2) & 3, c = tid & 3, j0 = 4 * b;
+        const double rs0 = rdiag[j0], rs1 = rdiag[j0 + 1], rs2 = rdiag[j0 + 2], rs3 = rdiag[j0 + 3];
+        const double t10 = L.Dl[j0 + 1][j0], t20 = L.Dl[j0 + 2][j0], t21 = L.Dl[j0 + 2][j0 + 1];
+        const double t30 = L.Dl[j0 + 3][j0], t31 = L.Dl[j0 + 3][j0 + 1], t32 = L.Dl[j0 + 3][j0 + 2];
+        const double v10 = -t10 * rs0 * rs1, v21 = -t21 * rs1 * rs2, v32 = -t32 * rs2 * rs3;
+        const double v20 = -fma(t21, v10, t20 * rs0) * rs2, v31 = -fma(t32, v21, t31 * rs1) * rs3;
+        const double v30 = -fma(t32, v20, fma(t31, v10, t30 * rs0)) * rs3;
+        const double r0v = (c == 0) ? rs0 : 0.0;
+        const double r1v = (c == 0) ? v10 : (c == 1) ? rs1 : 0.0;
+        const double r2v = (c == 0) ? v20 : (c == 1) ? v21 : (c == 2) ? rs2 : 0.0;
+        const double r3v = (c == 0) ? v30 : (c == 1) ? v31 : (c == 2) ? v32 : rs3;
+        Vd[j0 + k][c] = (k == 0) ? r0v : (k == 1) ? r1v : (k == 2) ? r2v : r3v;
+        __syncthreads();
+    }
 }
 
 // X L^T = P for the workgroup's CB rows, thread (i, cg) holding P[i][cg + 4 q] in p[q]; no barriers
@@ -718,7 +758,7 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
     double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB);
     const unsigned int epoch = (*epoch_ctr << 8) | DF_EPOCH_TAG;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
-    const int ti = tid >> 2, cg = tid & 3;
+    const int ti = 16 * wv + ln, cg = lk;                    // element ownership of chol_factor_diag<true>
     DfGeom g;
     g.n = n; g.ld = ld; g.nbc = (n + CB - 1) / CB;
     const int nbc = g.nbc;
@@ -898,7 +938,7 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
         }
         __syncthreads();                    // T has been read; the PanelLds region may be overwritten
         DF_TRACE(6);
-        chol_factor_diag(a, L, tid, nbd, true, status, Vd);
+        chol_factor_diag<true>(a, L, tid, nbd, true, status, Vd);
         DF_TRACE(9);
         {   // inverses of the 16 x 16 diagonal sub-blocks, one per wave, published with the factor: lane = 4 c + h stores
             // W16t[wv][c][4 h .. 4 h + 3] = 32 contiguous bytes of w16[j][wv][c][*]
