@@ -978,6 +978,40 @@ def test_mixed_domain_apply_equals_fourier_apply_4096(dev, w, DK, DB, cpr):
     assert rms(ga - gb) <= 1e-11 * rms(pair["SCI"])
 
 
+@pytest.mark.parametrize("shape,w,DK", [((96, 66), 4, 2), ((80, 62), 3, 1), ((72, 64), 8, 2), ((130, 98), 8, 3), ((200, 34), 2, 0),
+                                        ((4096, 4096), 8, 2), ((1536, 2048), 6, 2)])
+def test_mixed_domain_apply_variants_agree(dev, shape, w, DK):
+    """The mixed-domain apply kernels against each other and against the Fourier-domain apply, on shapes whose last 16-column
+    tile holds 2 / 0 / 1 / 2 / 2 / 1 / 1 columns (1 or 2: vconv_direct takes them): the default (vconv_mixed2 with the stream
+    length balanced against the CU count), the round-1 stream length, one source row per table read (vconv_mixed), the
+    register-stationary taps (vconv_mixed3; order 3 at KerHW 8 falls back to vconv_mixed2) and construct_fd."""
+    from sfft_amd.plan import Plan
+    from sfft_amd.utils.synthetic import make_pair
+    pair = make_pair(*shape, seed=11 + w, mask=True)
+    I, J = _to(dev, pair["REF"]), _to(dev, pair["SCI"])
+    rng = np.random.default_rng(9)
+    outs = {}
+    for name, env in [("default", {}), ("r1_len", {"SFFT_VCONV_R": "0"}), ("one_row", {"SFFT_VCONV_RP": "1"}),
+                      ("stationary", {"SFFT_VCONV_RP": "3"}), ("short", {"SFFT_VCONV_R": "17"}), ("fourier", {"SFFT_NO_VCONV": "1"})]:
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            plan = Plan(shape[0], shape[1], w, DK, 1, True, device=dev.index)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        if name == "default":
+            sol = rng.normal(size=plan.NEQ)
+            sol[:plan.Fijab] *= float(shape[0]) * float(shape[1]) * 0.01
+        outs[name] = plan.apply(I, J, torch.from_numpy(sol).to(dev)).cpu().numpy()
+        plan.close()
+    ref = outs["fourier"]
+    for name, d in outs.items():
+        assert rms(d - ref) <= 1e-12 * rms(ref), name
+    for name in ("r1_len", "short", "one_row"):          # the same tap sums (vconv_direct adds the taps in the opposite order: rounding only)
+        assert rms(outs[name] - outs["default"]) <= 1e-14 * rms(ref), name
+
+
 def _subtract_with_env(dev, env, shape, w, DK, DB, pair):
     """One GSS with a plan created under the given environment switches (they are read at plan creation)."""
     from sfft_amd.plan import Plan
