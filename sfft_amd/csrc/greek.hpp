@@ -501,7 +501,14 @@ struct G1Group {
 // MASK = false: every row chunk is a whole number of 8-row iterations (4096 / 8 chunks: 512 rows), so no step ever runs past its chunk
 // and the per-step row mask (a compare, two selects, two multiplies and the masked lag-0 sums) drops out of the loop -- vector
 // instructions are not free beside the matrix pipe here.
-template <bool MASK>
+// DIT = true (whole chunks only): one radix-2 decimation step along the rows before the matrix instructions.  The twiddle of lag r at
+// row x' + N0 / 2 is (-1)^r times the one at row x', so with Ye = H(x') + H(x' + N0/2) and Yo = H(x') - H(x' + N0/2) the even lags
+// sum W_r(x') Ye over HALF the rows and the odd lags W_r(x') Yo: a step takes two rows of every plane (x' and x' + N0/2), forms both
+// products and their sum and difference (4 more vector additions per slot), and issues the same 16 matrix instructions per slot as
+// before -- for twice the rows.  Lag groups are then {2,4,6,8}, {10,..,16} on Ye and {1,3,5,7}, {9,..,15} on Yo; lane n loads the
+// twiddle of the lag its 4-lane group needs, so the ds_swizzle gather of the A operands is unchanged.  A chunk is rows_per_chunk / 2
+// rows x' and their partners.
+template <bool MASK, bool DIT = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
                                                         const G1Group* __restrict__ groups, int ngroup,
                                                         cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
@@ -524,8 +531,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     const long long gd0 = passes[k0].gp_off2;
     const bool d0 = use0 && passes[k0].dual != 0;
     const int h = passes[k0].h, PH = 2 * h + 1;
-    const int lb = chunk * rows_per_chunk;
-    const int le = min(N0, lb + rows_per_chunk);
+    const int lb = DIT ? chunk * (rows_per_chunk / 2) : chunk * rows_per_chunk;
+    const int le = DIT ? lb + rows_per_chunk / 2 : min(N0, lb + rows_per_chunk);
     const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
     const int m = m0 + n;
     const bool act = m < Nh;
@@ -533,13 +540,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     const char* __restrict__ P0 = reinterpret_cast<const char*>(spec + (size_t)gr.plane[0] * plane_sz);
     const char* __restrict__ P1 = reinterpret_cast<const char*>(spec + (size_t)gr.plane[1] * plane_sz);
     const char* __restrict__ P2 = reinterpret_cast<const char*>(spec + (size_t)gr.plane[2] * plane_sz);
-    const int tcol = min(1 + n, HM - 1);
+    // lag whose twiddle this lane loads: plain = n + 1 (group g = lags 4 g + 1 .. 4 g + 4); DIT = groups {2,4,6,8}, {10,..,16}, {1,3,5,7}, {9,..,15}
+    const int dlag = (n < 8) ? 8 * (n >> 2) + 2 * ((n & 3) + 1) : 8 * ((n >> 2) - 2) + 2 * (n & 3) + 1;
+    const int tcol = min(DIT ? dlag : 1 + n, HM - 1);
     const char* __restrict__ Wb = reinterpret_cast<const char*>(W0tab) + (size_t)tcol * sizeof(cplx);
     const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
     const unsigned rlast = (unsigned)(N0 - 1);
     const unsigned r0 = min((unsigned)(lb + kq), rlast);
     unsigned rowb = r0 * rsb, twb = r0 * hmb;
-    const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb;
+    const unsigned rowb_max = (DIT ? (unsigned)(N0 / 2 - 1) : rlast) * rsb, twb_max = rlast * hmb;      // (DIT: the partner row of the clamp is the last row)
     const bool theta = gr.tpass[0] >= 0;                    // (wave uniform) edge + dual group with the Theta passes of its two planes
     const bool three = gr.plane[2] != gr.plane[0];          // (wave uniform) a third plane is in use
     const long long gt0 = theta ? passes[gr.tpass[0]].gp_off : 0, gt1 = theta ? passes[gr.tpass[1]].gp_off : 0;
@@ -557,7 +566,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         for (int q = 0; q < 4; ++q) Sx[sl][q] = (d4v){0.0, 0.0, 0.0, 0.0};
         g0x[sl] = g0y[sl] = 0.0;
     }
-    struct LoadSet { cplx tw, v[3]; };
+    struct LoadSet { cplx tw, v[3], u[DIT ? 3 : 1]; };        // u: the partner rows x' + N0 / 2 (DIT)
+    const unsigned halfb = (unsigned)(N0 / 2) * (unsigned)(rs * sizeof(cplx));
     // (two instantiations of the loop, with and without the third plane: a run-time `three ? load : v0` makes the compiler select
     //  between ADDRESSES, which puts the whole load set in scratch)
     auto run = [&](auto MODE) {
@@ -569,6 +579,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         L.v[0] = *reinterpret_cast<const cplx*>(P0 + (cob + rowb));
         L.v[1] = *reinterpret_cast<const cplx*>(P1 + (cob + rowb));
         if (three_c) L.v[2] = *reinterpret_cast<const cplx*>(P2 + (cob + rowb)); else L.v[2] = make_double2(0.0, 0.0);
+        if (DIT) {
+            L.u[0] = *reinterpret_cast<const cplx*>(P0 + (cob + rowb + halfb));
+            L.u[1] = *reinterpret_cast<const cplx*>(P1 + (cob + rowb + halfb));
+            if (three_c) L.u[DIT ? 2 : 0] = *reinterpret_cast<const cplx*>(P2 + (cob + rowb + halfb)); else L.u[DIT ? 2 : 0] = make_double2(0.0, 0.0);
+        }
         rowb = min(rowb + 4u * rsb, rowb_max);
         twb = min(twb + 4u * hmb, twb_max);
     };
@@ -585,6 +600,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
             const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode >= 2) ? 1 : 2];
             // dual: H.x = |a|^2, H.y = |b|^2 (two real products side by side)
             const cplx H = dual ? make_double2(fma(va.x, va.x, va.y * va.y), fma(vb.x, vb.x, vb.y * vb.y)) : cmulc(va, vb);
+            if (DIT) {
+                const cplx ua = L.u[DIT ? (sl == 1 ? 1 : 0) : 0], ub = L.u[DIT ? ((sl == 0 || mode >= 2) ? 1 : 2) : 0];
+                const cplx Hh = dual ? make_double2(fma(ua.x, ua.x, ua.y * ua.y), fma(ub.x, ub.x, ub.y * ub.y)) : cmulc(ua, ub);
+                const cplx Ye = make_double2(H.x + Hh.x, H.y + Hh.y), Yo = make_double2(H.x - Hh.x, H.y - Hh.y);
+                g0x[sl] += Ye.x;
+                g0y[sl] += Ye.y;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const double bx = gq < 2 ? Ye.x : Yo.x, by = gq < 2 ? Ye.y : Yo.y;
+                    Sx[sl][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], bx, Sx[sl][0][gq], 0, 0, 0);
+                    Sx[sl][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], by, Sx[sl][1][gq], 0, 0, 0);
+                    Sx[sl][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], bx, Sx[sl][2][gq], 0, 0, 0);
+                    Sx[sl][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], by, Sx[sl][3][gq], 0, 0, 0);
+                }
+                return;
+            }
             g0x[sl] = MASK ? fma(H.x, vf, g0x[sl]) : g0x[sl] + H.x;
             g0y[sl] = MASK ? fma(H.y, vf, g0y[sl]) : g0y[sl] + H.y;
 #pragma unroll
@@ -605,6 +636,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts) {
                 const cplx H = cmulc(L.v[ts], L.v[2]);           // FI_x conj(FJ)
+                if (DIT) {      // lags 2, 4, 6, 8 on Ye (twiddle group 0) and 1, 3, 5, 7 on Yo (twiddle group 2)
+                    const cplx Hh = cmulc(L.u[DIT ? ts : 0], L.u[DIT ? 2 : 0]);
+                    const cplx Ye = make_double2(H.x + Hh.x, H.y + Hh.y), Yo = make_double2(H.x - Hh.x, H.y - Hh.y);
+                    t0x[ts] += Ye.x;
+                    t0y[ts] += Ye.y;
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq) {
+                        const double bx = gq == 0 ? Ye.x : Yo.x, by = gq == 0 ? Ye.y : Yo.y;
+                        St[ts][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[2 * gq], bx, St[ts][0][gq], 0, 0, 0);
+                        St[ts][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[2 * gq], by, St[ts][1][gq], 0, 0, 0);
+                        St[ts][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[2 * gq], bx, St[ts][2][gq], 0, 0, 0);
+                        St[ts][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[2 * gq], by, St[ts][3][gq], 0, 0, 0);
+                    }
+                    continue;
+                }
                 t0x[ts] = MASK ? fma(H.x, vf, t0x[ts]) : t0x[ts] + H.x;
                 t0y[ts] = MASK ? fma(H.y, vf, t0y[ts]) : t0y[ts] + H.y;
 #pragma unroll
@@ -651,7 +697,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
             if (kq == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = 4 * q + kq + 1;
+                const int r = DIT ? (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1) : 4 * q + kq + 1;
                 if (r <= h) {
                     g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][0][q], Sx[sl][2][q]);
                     g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][0][q], -Sx[sl][2][q]);
@@ -664,7 +710,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         if (kq == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = 4 * q + kq + 1;
+            const int r = DIT ? (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1) : 4 * q + kq + 1;
             if (r <= h) {
                 const double s1 = Sx[sl][0][q], s2 = Sx[sl][1][q], s3 = Sx[sl][2][q], s4 = Sx[sl][3][q];
                 g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
@@ -685,7 +731,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
             if (kq == 0) g[(size_t)ht * Nhp + m] = make_double2(sx, sy);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int r = 4 * q + kq + 1;
+                const int r = DIT ? (q == 0 ? 2 * (kq + 1) : 2 * kq + 1) : 4 * q + kq + 1;
                 if (r <= ht) {
                     const double s1 = St[ts][0][q], s2 = St[ts][1][q], s3 = St[ts][2][q], s4 = St[ts][3][q];
                     g[(size_t)(ht + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);

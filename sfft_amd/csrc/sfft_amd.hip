@@ -190,6 +190,7 @@ struct sfft_plan {
     int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row,
                                         // 3: register-stationary taps (vconv_mixed3: measured 2.5x slower, the walk is load-latency bound at 2 waves per SIMD)
     int num_cu = 256;
+    int g1_dit = 1;                     // env SFFT_G1_DIT=0: grouped Omega launch without the radix-2 decimation step along the rows
     int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
     int vconv3_r = 0;                   // env SFFT_VCONV3_R: output rows per wave of vconv_mixed3 (0: whole resident rounds)
     int theta_mfma = 0;                 // env SFFT_THETA_MFMA=1: Theta passes in the Omega passes' matrix-core launch (3.13 -> 3.05 ms for one pair,
@@ -521,6 +522,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV3_R")) p->vconv3_r = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_R")) p->vconv_r = atoi(ev);
+    if (const char* ev = getenv("SFFT_G1_DIT")) p->g1_dit = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -728,6 +730,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         const int JP = p->Fij;                                  // plane of J
         auto SP = [&](int s) { return p->Fij + 1 + s; };        // plane of scaling term s
         while (S < 16 && (long long)colblocks * S * npass_est < 6144 && N0 / (2 * S) >= 64) S *= 2;
+        if (const char* ev = getenv("SFFT_G1_S")) { const int v = atoi(ev); if (v >= 1 && v <= 16 && N0 / v >= 64) S = v; }      // A/B: row chunks of the Omega launch
         p->S = S;
         p->rows_per_chunk = (N0 + S - 1) / S;
         long long goff = 0;
@@ -1496,7 +1499,11 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             const int ncb16 = (p->Nh + 15) / 16;
             const int totg = ncb16 * p->S * p->n_groups;
             const bool whole = (p->rows_per_chunk % (8 * DF_BURST)) == 0 && (p->N0 % p->rows_per_chunk) == 0;      // no step runs past its chunk
-            if (whole)
+            const bool dit = whole && p->g1_dit && (p->N0 % 2) == 0 && (p->rows_per_chunk % (16 * DF_BURST)) == 0;
+            if (dit)
+                hipLaunchKernelGGL((greek_g1_mfma4g<false, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
+            else if (whole)
                 hipLaunchKernelGGL(greek_g1_mfma4g<false>, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
             else
