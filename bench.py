@@ -56,7 +56,7 @@ CONFIGS = {
 }
 
 
-def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False, omg_counts=None):
+def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False, omg_counts=None, decimated=False):
     """Algorithmic HBM bytes per stage for ONE pair (solve + apply), as built, and the
     canonical reference-algorithm figure B_alg of SURVEY.md 8(d).  n_colfac = distinct column factors of the kernel basis
     (DK + 1 for a polynomial, Fj for a B-spline tensor basis): one row transform each."""
@@ -82,6 +82,13 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False,
         out["greek_g1"] += spec                                  # keeps only the Gamma block (one read of the masked image)
         out["greek_g1b"] = r * P
         out["greek_g1_flops"] += N0 * Nh * Fij * (6 + 2 * 4 * w)
+    out["greek_g1_flops_direct"] = out["greek_g1_flops"]        # the pruned DFT taken directly: every lag over every row
+    if decimated:
+        # one radix-2 decimation step along the rows (greek_g1_mfma4g<false, true>): the products are formed for every row, their sum and
+        # difference over the row pairs (x', x' + N0/2) cost 4 (2) additions per pair, and the lag sums run over N0 / 2 rows
+        n_the = Fij if theta_fused else 0
+        out["greek_g1_flops"] = (N0 * Nh * (n_off * 6 + n_diag * 3 + n_the * 6)
+                                 + (N0 // 2) * Nh * (n_off * (4 + 2 * 4 * (2 * w)) + n_diag * (2 + 4 * (2 * w)) + n_the * (4 + 2 * 4 * w)))
     if mixed_apply:
         # polynomial kernel: row pass into stage planes, mixed-domain column convolution (reads them, writes one plane),
         # inverse row pass with the DIFF epilogue -- no column transforms
@@ -355,8 +362,9 @@ def main():
         iso_stage = {k: v / n_iso for k, v in iso_acc.items()}
         mixed = (not bspline) and w <= 12
         theta_fused = bool(plans[0].query("THETA_FUSED"))
+        decimated = bool(plans[0].query("G1_DECIMATED"))
         ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused,
-                       (plans[0].query("OMG_OFFDIAG"), plans[0].query("OMG_DIAG")))
+                       (plans[0].query("OMG_OFFDIAG"), plans[0].query("OMG_DIAG")), decimated)
         headline = (args.config == 2 and (N0, N1, w) == (4096, 4096, 8))
 
         pmc = {}
@@ -385,10 +393,15 @@ def main():
                     "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_flops"],
                     "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
                     "sustained_peak_measured": 74.5,     # profiles/r02_mfma_f64_peak.txt: a loop of independent v_mfma_f64_4x4x4_4b_f64, TFLOP/s
+                    "decimated": decimated, "alg_flops_direct": ab["greek_g1_flops_direct"],
+                    "direct_equivalent_tflops": ab["greek_g1_flops_direct"] / (stages["greek_g1"] * 1e-3) / 1e12,
                     "note": "v_mfma_f64_4x4x4_4b_f64; a loop of nothing but independent MFMAs sustains 74.5 TFLOP/s with this instruction and "
-                            "47.4 with v_mfma_f64_16x16x4_f64 on this device (scripts/micro/mfma_f64_peak.hip); the launch is not bound by the "
-                            "matrix pipe alone: memory side 0.31 ms, compute side 0.41 ms measured separately (greek.hpp); HBM side: "
-                            "%.0f GB/s of algorithmic bytes" % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
+                            "47.4 with v_mfma_f64_16x16x4_f64 on this device (scripts/micro/mfma_f64_peak.hip).  alg_flops_per_launch counts the "
+                            "arithmetic as built: with the radix-2 decimation step along the rows the lag sums run over half the rows "
+                            "(alg_flops_direct is the same pruned DFT taken directly, direct_equivalent_tflops that figure over the launch time); "
+                            "the launch is not bound by the matrix pipe alone: its loads, products and twiddles without the matrix "
+                            "instructions take 0.31 ms (greek.hpp); HBM side: %.0f GB/s of algorithmic bytes"
+                            % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
         per_pair_keys = [k for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse") if k in ab]
         if batch_mode:
             workload = ("BASELINE configs[3]: a batch of %d independent 4096x4096 pairs (config-2 geometry) dealt round-robin to %d rank(s): "

@@ -1163,6 +1163,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     return SFFT_OK;
 }
 
+static bool g1_decimated(const sfft_plan* p);
 extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
 {
     if (!p || !v) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
@@ -1192,6 +1193,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
         case SFFT_Q_THETA_FUSED: *v = (p->theta_in_groups && p->g1_mfma >= 3) ? 1 : 0; break;
         case SFFT_Q_OMG_OFFDIAG: *v = p->n_omg_off; break;
+        case SFFT_Q_G1_DECIMATED: *v = (g1_decimated(p) && 2 * p->w >= 9 && 2 * p->w <= 16) ? 1 : 0; break;
         case SFFT_Q_OMG_DIAG: *v = p->n_omg_diag; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
@@ -1486,6 +1488,13 @@ static int g1_band(int h)
 }
 static int g1_padded(int h) { const int b = g1_band(h); return ((std::max(h, 1) + b - 1) / b) * b; }
 
+// the grouped Omega launch runs with the radix-2 decimation step (greek_g1_mfma4g<false, true>): whole chunks of an even number of 8-row steps
+static bool g1_decimated(const sfft_plan* p)
+{
+    const bool whole = (p->rows_per_chunk % (8 * DF_BURST)) == 0 && (p->N0 % p->rows_per_chunk) == 0;
+    return p->g1_mfma >= 3 && p->d_groups && whole && p->g1_dit && (p->N0 % 2) == 0 && (p->rows_per_chunk % (16 * DF_BURST)) == 0;
+}
+
 static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t s, bool planes_only = false)
 {
     if (npass <= 0) return SFFT_OK;
@@ -1499,7 +1508,7 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             const int ncb16 = (p->Nh + 15) / 16;
             const int totg = ncb16 * p->S * p->n_groups;
             const bool whole = (p->rows_per_chunk % (8 * DF_BURST)) == 0 && (p->N0 % p->rows_per_chunk) == 0;      // no step runs past its chunk
-            const bool dit = whole && p->g1_dit && (p->N0 % 2) == 0 && (p->rows_per_chunk % (16 * DF_BURST)) == 0;
+            const bool dit = g1_decimated(p);
             if (dit)
                 hipLaunchKernelGGL((greek_g1_mfma4g<false, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
