@@ -238,13 +238,59 @@ __global__ void __launch_bounds__(256, (W > 8 ? 2 : 4)) vconv_mixed(const cplx* 
     }
 }
 
+// vconv_point: the same sum for ONE output element (row x of spectrum column m), taps read straight from the global table -- no sliding
+// window.  With Nh = N1 / 2 + 1 the 16-column tiles of vconv_mixed2 end in a tile holding the Nyquist column alone; that column is
+// taken point by point instead (a few rows per workgroup of the main launch, or the vconv_direct launch), which leaves the main
+// launch a tile count that divides the chip evenly (128 tiles x 4 = two workgroups per CU at 4096^2).
+template <int DK, int W>
+__device__ __forceinline__ void vconv_point(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+                                            const double* __restrict__ kbx, int N0, int Nhp, SpecLayout lay, int x, int m)
+{
+    constexpr int NJ = DK + 1, L = 2 * W + 1;
+    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(m), rs = (size_t)lay.rstride;
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int q = 0; q < L; ++q) {               // tap a = q - W: source row y = x - a
+        int y = x - (q - W);
+        if (y < 0) y += N0;
+        if (y >= N0) y -= N0;
+        double fx[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) fx[jj] = kbx[(size_t)jj * N0 + y];
+#pragma unroll
+        for (int jj = 0; jj <= DK; ++jj) {
+            const cplx S = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            double ex = 0.0, ey = 0.0;
+#pragma unroll
+            for (int ii = 0; ii <= DK - jj; ++ii) {
+                const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;
+                const cplx c = Ctab[((size_t)t * L + q) * Nhp + m];
+                if (ii == 0) { ex = c.x; ey = c.y; continue; }
+                ex = fma(fx[ii], c.x, ex);
+                ey = fma(fx[ii], c.y, ey);
+            }
+            ax = fma(S.x, ex, fma(-S.y, ey, ax));
+            ay = fma(S.x, ey, fma(S.y, ex, ay));
+        }
+    }
+    D[mo + (size_t)x * rs] = make_double2(ax, ay);
+}
+template <int DK, int W>
+__global__ void __launch_bounds__(256) vconv_direct(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+                                                    const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay, int m0)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, m = m0 + blockIdx.y;
+    if (x >= N0 || m >= Nh) return;
+    vconv_point<DK, W>(stage, D, Ctab, kbx, N0, Nhp, lay, x, m);
+}
+
 // vconv_mixed2: the same walk two source rows at a time -- the FIJ table entries of a tap are read from LDS once and serve
 // both rows (row y feeds window slot q, row y + 1 slot q + 1), which halves the LDS traffic and doubles the arithmetic behind
 // every LDS round trip; the window has L + 1 slots and slides by two.
 template <int DK, int W, int KS>
 __global__ void __launch_bounds__(256, (DK <= 2 ? 2 : 3)) vconv_mixed2(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
                                                        const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
-                                                       cplx* __restrict__ trash, int Rrt)
+                                                       cplx* __restrict__ trash, int Rrt, int m_direct)
 {
     // Rrt > 0: output rows per stream chosen by the host (a whole number of resident rounds, see apply_finish); else KS * L - 2 W
     constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2;
@@ -262,6 +308,16 @@ __global__ void __launch_bounds__(256, (DK <= 2 ? 2 : 3)) vconv_mixed2(const cpl
         ctab[e] = Ctab[(size_t)ta * Nhp + (size_t)min((int)blockIdx.x * 16 + c, Nh - 1)];
     }
     __syncthreads();
+    if (m_direct < Nh) {
+        // this workgroup's share of the columns [m_direct, Nh) that no tile of the launch covers (see vconv_point): a few points per
+        // workgroup, done first so that their loads overlap the other resident workgroup's walk
+        const int nwg = (int)(gridDim.x * gridDim.y), wg = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        const int npts = N0 * (Nh - m_direct), per = (npts + nwg - 1) / nwg;
+        for (int e = threadIdx.x; e < per; e += 256) {
+            const int idx = wg * per + e;
+            if (idx < npts) vconv_point<DK, W>(stage, D, Ctab, kbx, N0, Nhp, lay, idx % N0, m_direct + idx / N0);
+        }
+    }
     const int x0 = ((blockIdx.y * 4 + wv) * 4 + sl) * R;
     if (x0 >= N0) return;
     const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(mc), rs = (size_t)lay.rstride;
@@ -359,45 +415,6 @@ __global__ void __launch_bounds__(256, (DK <= 2 ? 2 : 3)) vconv_mixed2(const cpl
         acc[L] = make_double2(0.0, 0.0);
         y = (y1 + 1 == N0) ? 0 : y1 + 1;
     }
-}
-
-// vconv_direct: the same sum, one output element per thread with no sliding window, for the last few spectrum columns [m0, Nh).
-// With Nh = N1 / 2 + 1 the 16-column tiles of vconv_mixed2 end in a tile holding the Nyquist column alone; taking that column
-// here leaves the main launch a tile count that divides the chip evenly (128 tiles x 4 = two workgroups per CU at 4096^2).
-template <int DK, int W>
-__global__ void __launch_bounds__(256) vconv_direct(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
-                                                    const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay, int m0)
-{
-    constexpr int NJ = DK + 1, L = 2 * W + 1;
-    const int x = blockIdx.x * 256 + threadIdx.x, m = m0 + blockIdx.y;
-    if (x >= N0 || m >= Nh) return;
-    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(m), rs = (size_t)lay.rstride;
-    double ax = 0.0, ay = 0.0;
-#pragma unroll
-    for (int q = 0; q < L; ++q) {               // tap a = q - W: source row y = x - a (unrolled: the loads of all taps go out together)
-        int y = x - (q - W);
-        if (y < 0) y += N0;
-        if (y >= N0) y -= N0;
-        double fx[NJ];
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) fx[jj] = kbx[(size_t)jj * N0 + y];
-#pragma unroll
-        for (int jj = 0; jj <= DK; ++jj) {
-            const cplx S = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
-            double ex = 0.0, ey = 0.0;
-#pragma unroll
-            for (int ii = 0; ii <= DK - jj; ++ii) {
-                const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;
-                const cplx c = Ctab[((size_t)t * L + q) * Nhp + m];
-                if (ii == 0) { ex = c.x; ey = c.y; continue; }
-                ex = fma(fx[ii], c.x, ex);
-                ey = fma(fx[ii], c.y, ey);
-            }
-            ax = fma(S.x, ex, fma(-S.y, ey, ax));
-            ay = fma(S.x, ey, fma(S.y, ex, ay));
-        }
-    }
-    D[mo + (size_t)x * rs] = make_double2(ax, ay);
 }
 
 // vconv_mixed3: register-stationary taps.  Three lanes share a spectrum column; lane group g keeps the FIJ x TPG table entries of

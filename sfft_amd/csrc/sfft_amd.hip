@@ -190,6 +190,7 @@ struct sfft_plan {
     int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row,
                                         // 3: register-stationary taps (vconv_mixed3: measured 2.5x slower, the walk is load-latency bound at 2 waves per SIMD)
     int num_cu = 256;
+    int vconv_direct_launch = 0;        // env SFFT_VCONV_DIRECT=1: the leftover columns of the mixed-domain apply in a launch of their own (vconv_direct)
     int g1_dit = 1;                     // env SFFT_G1_DIT=0: grouped Omega launch without the radix-2 decimation step along the rows
     int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
     int vconv3_r = 0;                   // env SFFT_VCONV3_R: output rows per wave of vconv_mixed3 (0: whole resident rounds)
@@ -523,6 +524,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_VCONV3_R")) p->vconv3_r = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_R")) p->vconv_r = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_DIT")) p->g1_dit = atoi(ev);
+    if (const char* ev = getenv("SFFT_VCONV_DIRECT")) p->vconv_direct_launch = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -1925,10 +1927,10 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
                            p->Nhp, p->lay, R3); } else \
         if (p->vconv_rp >= 2 && WT <= 8) { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        if (m_direct < p->Nh) hipLaunchKernelGGL((vconv_direct<DKT, (WT <= 8 ? WT : 8)>), dim3((p->N0 + 255) / 256, p->Nh - m_direct), dim3(256), 0, s, FI, FD, \
-                                                 p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, m_direct); \
+        if (m_direct < p->Nh && p->vconv_direct_launch) hipLaunchKernelGGL((vconv_direct<DKT, (WT <= 8 ? WT : 8)>), dim3((p->N0 + 255) / 256, p->Nh - m_direct), \
+                                                 dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, m_direct); \
         hipLaunchKernelGGL((vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
-                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp, Rrt); } else { \
+                           p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp, Rrt, p->vconv_direct_launch ? p->Nh : m_direct); } else { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
                            p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } } while (0)

@@ -982,7 +982,7 @@ def test_mixed_domain_apply_equals_fourier_apply_4096(dev, w, DK, DB, cpr):
                                         ((4096, 4096), 8, 2), ((1536, 2048), 6, 2)])
 def test_mixed_domain_apply_variants_agree(dev, shape, w, DK):
     """The mixed-domain apply kernels against each other and against the Fourier-domain apply, on shapes whose last 16-column
-    tile holds 2 / 0 / 1 / 2 / 2 / 1 / 1 columns (1 or 2: vconv_direct takes them): the default (vconv_mixed2 with the stream
+    tile holds 2 / 0 / 1 / 2 / 2 / 1 / 1 columns (1 or 2: taken point by point, inside the main launch or by vconv_direct): the default (vconv_mixed2 with the stream
     length balanced against the CU count), the round-1 stream length, one source row per table read (vconv_mixed), the
     register-stationary taps (vconv_mixed3; order 3 at KerHW 8 falls back to vconv_mixed2) and construct_fd."""
     from sfft_amd.plan import Plan
@@ -992,7 +992,7 @@ def test_mixed_domain_apply_variants_agree(dev, shape, w, DK):
     rng = np.random.default_rng(9)
     outs = {}
     for name, env in [("default", {}), ("r1_len", {"SFFT_VCONV_R": "0"}), ("one_row", {"SFFT_VCONV_RP": "1"}),
-                      ("stationary", {"SFFT_VCONV_RP": "3"}), ("short", {"SFFT_VCONV_R": "17"}), ("fourier", {"SFFT_NO_VCONV": "1"})]:
+                      ("stationary", {"SFFT_VCONV_RP": "3"}), ("short", {"SFFT_VCONV_R": "17"}), ("own_launch", {"SFFT_VCONV_DIRECT": "1"}), ("fourier", {"SFFT_NO_VCONV": "1"})]:
         for k, v in env.items():
             os.environ[k] = v
         try:
@@ -1008,7 +1008,7 @@ def test_mixed_domain_apply_variants_agree(dev, shape, w, DK):
     ref = outs["fourier"]
     for name, d in outs.items():
         assert rms(d - ref) <= 1e-12 * rms(ref), name
-    for name in ("r1_len", "short", "one_row"):          # the same tap sums (vconv_direct adds the taps in the opposite order: rounding only)
+    for name in ("r1_len", "short", "one_row", "own_launch"):          # the same tap sums (vconv_direct adds the taps in the opposite order: rounding only)
         assert rms(outs[name] - outs["default"]) <= 1e-14 * rms(ref), name
 
 
