@@ -56,7 +56,7 @@ CONFIGS = {
 }
 
 
-def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False, omg_counts=None, decimated=False):
+def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False, omg_counts=None, decimated=False, chunks=0):
     """Algorithmic HBM bytes per stage for ONE pair (solve + apply), as built, and the
     canonical reference-algorithm figure B_alg of SURVEY.md 8(d).  n_colfac = distinct column factors of the kernel basis
     (DK + 1 for a polynomial, Fj for a B-spline tensor basis): one row transform each."""
@@ -82,6 +82,8 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False,
         out["greek_g1"] += spec                                  # keeps only the Gamma block (one read of the masked image)
         out["greek_g1b"] = r * P
         out["greek_g1_flops"] += N0 * Nh * Fij * (6 + 2 * 4 * w)
+    if chunks:           # the per-chunk partial lag sums the launch writes for greek_g2 (2 * 2w + 1 lags per Omega product, 2w + 1 per Theta pass)
+        out["greek_g1"] += chunks * c * (N1 // 2 + 4) * ((n_off + n_diag) * (4 * w + 1) + (Fij * (2 * w + 1) if theta_fused else 0))
     out["greek_g1_flops_direct"] = out["greek_g1_flops"]        # the pruned DFT taken directly: every lag over every row
     if decimated:
         # one radix-2 decimation step along the rows (greek_g1_mfma4g<false, true>): the products are formed for every row, their sum and
@@ -364,7 +366,7 @@ def main():
         theta_fused = bool(plans[0].query("THETA_FUSED"))
         decimated = bool(plans[0].query("G1_DECIMATED"))
         ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused,
-                       (plans[0].query("OMG_OFFDIAG"), plans[0].query("OMG_DIAG")), decimated)
+                       (plans[0].query("OMG_OFFDIAG"), plans[0].query("OMG_DIAG")), decimated, plans[0].query("G1_CHUNKS"))
         headline = (args.config == 2 and (N0, N1, w) == (4096, 4096, 8))
 
         pmc = {}

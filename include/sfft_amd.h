@@ -51,6 +51,7 @@ enum {
     SFFT_Q_OMG_OFFDIAG,             /* Omega products I_a x conj(I_b), a < b, that are transformed (all Fij (Fij - 1) / 2 unless SFFT_OMG_REDUCE=1) */
     SFFT_Q_OMG_DIAG,                /* the same for a = b */
     SFFT_Q_G1_DECIMATED,            /* 1: the Omega launch of this plan takes a radix-2 decimation step along the rows (half the matrix instructions) */
+    SFFT_Q_G1_CHUNKS,               /* row chunks of the Greek stage-1 launches: each writes one partial lag sum per pass, lag and spectrum column */
     SFFT_Q_COUNT
 };
 

@@ -1195,6 +1195,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
         case SFFT_Q_THETA_FUSED: *v = (p->theta_in_groups && p->g1_mfma >= 3) ? 1 : 0; break;
         case SFFT_Q_OMG_OFFDIAG: *v = p->n_omg_off; break;
+        case SFFT_Q_G1_CHUNKS: *v = p->S; break;
         case SFFT_Q_G1_DECIMATED: *v = (g1_decimated(p) && 2 * p->w >= 9 && 2 * p->w <= 16) ? 1 : 0; break;
         case SFFT_Q_OMG_DIAG: *v = p->n_omg_diag; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
