@@ -417,6 +417,100 @@ __global__ void __launch_bounds__(256, (DK <= 2 ? 2 : 3)) vconv_mixed2(const cpl
     }
 }
 
+// vconv_tensor: the mixed-domain apply for a full TENSOR basis (B-spline kernels: term t = ii NJ + jj is row factor ii x column factor jj,
+// BSplineSFFT.py's REF_ij order).  The closed form of the inverse column transform holds for any separable term:
+//   sum_l FI_t[l][m] W0^(l a) e^(+2 pi i l x / N0) = N0 * bx_ii[x - a] * S_jj[x - a][m],     S_jj = row-DFT(I * by_jj),
+// so the apply pass of a B-spline plan needs NJ row transforms instead of NI NJ plane transforms and no column transform at all
+// (config 3, 5 x 5 terms at 6144^2: 25 forward plane transforms + the inverse column pass, 12 + 2 ms, become 5 row transforms and this
+// kernel).  Same walk as vconv_mixed2 -- two source rows per table read, a sliding window of L + 1 accumulators -- with
+// E_jj = sum_ii bx_ii[y] C'_(ii,jj)[a] over all NI row factors (no factor is identically one here).  A wave is CT columns x 64 / CT
+// row streams; CT = 8 keeps the NI NJ L CT table of a workgroup at 54 KB for 5 x 5 terms (two workgroups per CU).
+template <int NI, int NJ, int W, int CT>
+__global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+                                                       const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
+                                                       cplx* __restrict__ trash, int R)
+{
+    constexpr int L = 2 * W + 1, FIJ = NI * NJ, SPW = 64 / CT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* ctab = reinterpret_cast<cplx*>(smem_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cl = lane % CT, sl = lane / CT;
+    const int m = blockIdx.x * CT + cl;
+    const bool active = m < Nh;
+    const int mc = active ? m : Nh - 1;
+    for (int e = threadIdx.x; e < FIJ * L * CT; e += 256) {
+        const int ta = e / CT, c = e % CT;
+        ctab[e] = Ctab[(size_t)ta * Nhp + (size_t)min((int)blockIdx.x * CT + c, Nh - 1)];
+    }
+    __syncthreads();
+    const int NSRC = (R + 2 * W + 1) / 2 * 2;
+    const int x0 = ((blockIdx.y * 4 + wv) * SPW + sl) * R;
+    if (x0 >= N0) return;
+    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(mc), rs = (size_t)lay.rstride;
+    cplx acc[L + 1];
+#pragma unroll
+    for (int q = 0; q <= L; ++q) acc[q] = make_double2(0.0, 0.0);
+    int y = x0 - W;
+    if (y < 0) y += N0;
+#pragma unroll 1
+    for (int sI = 0; sI < NSRC; sI += 2) {
+        int opq;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+        const cplx* __restrict__ ct = ctab + cl + opq;
+        const int y1 = (y + 1 == N0) ? 0 : y + 1;
+        cplx S0[NJ], S1[NJ];
+        double f0[NI], f1[NI];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            S0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            S1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
+        }
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+            f0[ii] = kbx[(size_t)ii * N0 + y];
+            f1[ii] = kbx[(size_t)ii * N0 + y1];
+        }
+#pragma unroll
+        for (int q = 0; q < L; ++q) {           // tap a = q - W
+            __builtin_amdgcn_sched_barrier(0);
+            double ax = acc[q].x, ay = acc[q].y, bx = acc[q + 1].x, by = acc[q + 1].y;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                double ex = 0.0, ey = 0.0, gx = 0.0, gy = 0.0;
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) {
+                    const cplx c = ct[((ii * NJ + jj) * L + q) * CT];
+                    ex = fma(f0[ii], c.x, ex); ey = fma(f0[ii], c.y, ey);
+                    gx = fma(f1[ii], c.x, gx); gy = fma(f1[ii], c.y, gy);
+                }
+                ax = fma(S0[jj].x, ex, fma(-S0[jj].y, ey, ax));
+                ay = fma(S0[jj].x, ey, fma(S0[jj].y, ex, ay));
+                bx = fma(S1[jj].x, gx, fma(-S1[jj].y, gy, bx));
+                by = fma(S1[jj].x, gy, fma(S1[jj].y, gx, by));
+            }
+            acc[q] = make_double2(ax, ay);
+            acc[q + 1] = make_double2(bx, by);
+        }
+        const int xo = x0 - 2 * W + sI;
+        {
+            const unsigned long long ok64 = 0ULL - (unsigned long long)(sI >= 2 * W && xo < N0 && xo < x0 + R && active);
+            const unsigned long long a_ok = (unsigned long long)(D + mo + (size_t)max(xo, 0) * rs), a_tr = (unsigned long long)(trash + threadIdx.x);
+            *reinterpret_cast<cplx*>((a_ok & ok64) | (a_tr & ~ok64)) = acc[0];
+        }
+        {
+            const int x1 = xo + 1;
+            const unsigned long long ok64 = 0ULL - (unsigned long long)(sI + 1 >= 2 * W && x1 < N0 && x1 < x0 + R && active);
+            const unsigned long long a_ok = (unsigned long long)(D + mo + (size_t)max(x1, 0) * rs), a_tr = (unsigned long long)(trash + threadIdx.x);
+            *reinterpret_cast<cplx*>((a_ok & ok64) | (a_tr & ~ok64)) = acc[1];
+        }
+#pragma unroll
+        for (int q = 0; q + 2 <= L; ++q) acc[q] = acc[q + 2];
+        acc[L - 1] = make_double2(0.0, 0.0);
+        acc[L] = make_double2(0.0, 0.0);
+        y = (y1 + 1 == N0) ? 0 : y1 + 1;
+    }
+}
+
 // vconv_mixed3: register-stationary taps.  Three lanes share a spectrum column; lane group g keeps the FIJ x TPG table entries of
 // the taps q = g TPG .. g TPG + TPG - 1 (TPG = ceil(L / 3)) in registers for the whole walk, so the inner loop has no LDS traffic
 // at all: per source row TPG x 24 FMAs on register operands against 3 + 3 loads.  Group g walks source rows shifted by its first
