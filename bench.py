@@ -362,7 +362,7 @@ def main():
         value = n_total * args.steps / elapsed
         ms_step = elapsed * 1e3 / args.steps
         iso_stage = {k: v / n_iso for k, v in iso_acc.items()}
-        mixed = (not bspline) and w <= 12
+        mixed = (w <= 12) if not bspline else (w <= 8 and 4 <= n_colfac <= 6)     # (B-spline tensor bases of 4 x 4 .. 6 x 6 terms: vconv_tensor)
         theta_fused = bool(plans[0].query("THETA_FUSED"))
         decimated = bool(plans[0].query("G1_DECIMATED"))
         ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused,
@@ -379,7 +379,7 @@ def main():
                      "fwd_rows": "rows_r2c_4096" if fast else "rows_r2c",
                      "greek_g1": "greek_g1_mfma4g (Omega passes in groups%s)" % (" + the Theta passes" if theta_fused else ""),
                      "greek_g1b": ("" if theta_fused else "greek_g1<8, 2> (Theta passes) + ") + "row_moments / gamma_rows / gamma_patches (Gamma block)",
-                     "construct": "vconv_mixed2<2, 8, 4>" if mixed and w <= 8 else ("vconv_mixed" if mixed else "construct_fd")}
+                     "construct": ("vconv_tensor" if bspline else "vconv_mixed2<2, 8, 4>") if mixed and w <= 8 else ("vconv_mixed" if mixed else "construct_fd")}
 
         def roof(stages, dom="fwd_cols"):
             ach = ab[dom] / (stages[dom] * 1e-3) / 1e9

@@ -148,6 +148,7 @@ struct sfft_plan {
     double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
     // mixed-domain apply (polynomial kernels on the staged fast path, KerHW <= 8): no column transforms in the apply pass
+    int vtensor = 0, vncf = 0;          // vtensor = n: n x n tensor basis through vconv_tensor; vncf = stage planes (column factors) of the mixed-domain apply
     int use_vconv = 0, vw = 8;          // vw = compile-time half width the tables are padded to (4, 8 or 12)
     bool staged_solve = false;          // the solve pass leaves the stage planes of I first in d_stage (4096^2 fast path)
     cplx* d_stage_a = nullptr;          // [DK+1] stage planes of the full image (apply pass)
@@ -617,9 +618,23 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->staged_solve = both_fast && !p->no_staged;
         if (DK >= 0 && DK <= 3 && p->mode != 3 && KerHW >= 1 && KerHW <= 12 && !getenv("SFFT_NO_VCONV")) {
             p->use_vconv = 1;
+            p->vncf = DK + 1;
             p->vw = KerHW <= 4 ? 4 : KerHW <= 8 ? 8 : 12;
             PLAN_TRY(dev_alloc(p, &p->d_stage_a, (size_t)(DK + 1) * N0 * p->Nhp));
             PLAN_TRY(dev_alloc(p, &p->d_ctabm, (size_t)p->Fij * (2 * p->vw + 1) * p->Nhp + 256));   // + 256: trash slots of vconv_mixed
+        }
+        // basis plans whose terms are the full tensor product of nkx row factors and nky column factors in (ii, jj) order -- the B-spline
+        // kernels of BSplineSFFT -- take the same route through vconv_tensor (4 x 4 .. 6 x 6 terms, KerHW <= 8)
+        if (DK < 0 && p->mode != 3 && KerHW >= 1 && KerHW <= 8 && BS.nkx == BS.nky && BS.nkx >= 4 && BS.nkx <= 6 && p->Fij == BS.nkx * BS.nky &&
+            !getenv("SFFT_NO_VCONV")) {
+            bool tensor = true;
+            for (int t = 0; t < p->Fij; ++t) tensor = tensor && BS.kpair[2 * t] == t / BS.nky && BS.kpair[2 * t + 1] == t % BS.nky;
+            if (tensor) {
+                p->use_vconv = 1; p->vtensor = BS.nkx; p->vncf = BS.nky;
+                p->vw = KerHW <= 4 ? 4 : 8;
+                PLAN_TRY(dev_alloc(p, &p->d_stage_a, (size_t)p->vncf * N0 * p->Nhp));
+                PLAN_TRY(dev_alloc(p, &p->d_ctabm, (size_t)p->Fij * (2 * p->vw + 1) * p->Nhp + 256));
+            }
         }
     }
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
@@ -1866,8 +1881,8 @@ static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t 
     if (p->use_vconv) {      // only the row pass: DK + 1 stage planes I * cy^j, j = 0 .. DK
         RowsArgs ra;
         for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = nullptr; ra.wy[u] = nullptr; }
-        for (int jj = 0; jj <= p->DK; ++jj) { ra.src[jj] = d_I; ra.wy[jj] = p->d_kby + (size_t)jj * p->N1; }
-        return forward_planes(p, ra, p->DK + 1, p->d_stage_a, s, -1, -1, true);
+        for (int jj = 0; jj < p->vncf; ++jj) { ra.src[jj] = d_I; ra.wy[jj] = p->d_kby + (size_t)jj * p->N1; }
+        return forward_planes(p, ra, p->vncf, p->d_stage_a, s, -1, -1, true);
     }
     return forward_basis_planes(p, d_I, nullptr, dst, s);
 }
@@ -1882,6 +1897,33 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         const int LT = 2 * p->vw + 1;
         hipLaunchKernelGGL(kernel_ctab_mixed, dim3((p->Nhp + 255) / 256, p->Fij * LT), dim3(256), 0, s, d_solution, p->d_ctabm, p->L, p->L, p->w,
                            p->w, p->vw, p->Nh, p->Nhp, p->N1, p->ax1.root, (double)p->N0 * p->scale);
+        if (p->vtensor) {
+            // tensor basis: 8-column tiles, 8 streams per wave; stream length from the same cost model (workgroups per CU x steps per stream)
+            constexpr int CT = 8;
+            const int ntile_t = (p->Nh + CT - 1) / CT;
+            int Rt = 4 * LT - 2 * p->vw; double best = 1e30;
+            for (int y = 1; y <= (p->N0 + 511) / 512; ++y) {
+                const int Rc = (p->N0 + 32 * y - 1) / (32 * y);
+                if (Rc < 16 && y > 1) break;
+                const int wgs = ntile_t * y, rounds = (wgs + 2 * p->num_cu - 1) / (2 * p->num_cu);
+                const int k = rounds > 1 ? rounds * 2 : (wgs + p->num_cu - 1) / p->num_cu;
+                const double cost = (double)k * ((Rc + 2 * p->vw + 1) / 2) * (k == 1 ? 1.6 : 1.0);
+                if (cost < best) { best = cost; Rt = Rc; }
+            }
+            if (p->vconv_r > 0) Rt = p->vconv_r;
+            const int nstr = (p->N0 + Rt - 1) / Rt;
+            dim3 gt(ntile_t, (nstr + 31) / 32);
+            const size_t ldst = (size_t)p->Fij * LT * CT * sizeof(cplx);
+            cplx* trash = p->d_ctabm + (size_t)p->Fij * LT * p->Nhp;
+#define VT_LAUNCH(NN, WT) do { \
+            HIPCHK(hipFuncSetAttribute((const void*)vconv_tensor<NN, NN, WT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((vconv_tensor<NN, NN, WT, CT>), gt, dim3(256), ldst, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, trash, Rt); } while (0)
+#define VT_W(NN) do { if (p->vw == 4) VT_LAUNCH(NN, 4); else VT_LAUNCH(NN, 8); } while (0)
+            switch (p->vtensor) { case 4: VT_W(4); break; case 5: VT_W(5); break; default: VT_W(6); break; }
+#undef VT_W
+#undef VT_LAUNCH
+            LAUNCH_CHECK();
+        } else {
         constexpr int KS = 4;       // source rows per stream = KS * L (3..10 measured: 4 is best at KerHW 8)
         int R = KS * LT - 2 * p->vw, Rrt = 0, ntile = (p->Nh + 15) / 16, m_direct = p->Nh;
         if (p->vconv_rp == 2 && p->vw <= 8 && p->vconv_r != 0) {
@@ -1940,6 +1982,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
 #undef VCONV_DK
 #undef VCONV_LAUNCH
         LAUNCH_CHECK();
+        }
     } else {
         StageTimer t(p, SFFT_ST_CONSTRUCT, s);
         hipLaunchKernelGGL(kernel_rtab, dim3((p->N0 + 255) / 256, p->w + 1, p->Fij), dim3(256), 0, s, d_solution, p->d_rtab, p->Fij,

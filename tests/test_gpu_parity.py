@@ -660,6 +660,45 @@ def test_bspline_packet_fits_and_unsupported_modes(dev, tmp_path):
         BSSC.SSC(64, 48, 2, KerSpType="B-Spline", KerSpDegree=2, REGULARIZE_KERNEL=True, VERBOSE_LEVEL=0)
 
 
+@pytest.mark.parametrize("shape,w,deg,nk,sep", [((256, 200), 4, 2, 2, True), ((200, 162), 3, 1, 2, False), ((288, 256), 8, 2, 1, True),
+                                                ((320, 258), 6, 3, 2, True), ((1536, 1024), 8, 2, 2, True)])
+def test_bspline_mixed_domain_apply_equals_fourier_apply(dev, shape, w, deg, nk, sep):
+    """B-spline kernels with a full tensor basis (4 x 4 .. 6 x 6 terms, KerHW <= 8) take the mixed-domain apply too (vconv_tensor:
+    nky row transforms instead of nkx nky plane transforms, no column transform): same DIFF as the Fourier-domain apply
+    (SFFT_NO_VCONV=1) for a random solution vector, and the same end-to-end result."""
+    import sfft_amd.BSplineSFFT as B
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1 = shape
+    pair = make_pair(N0, N1, seed=3 + w, mask=True)
+    kx = [N0 * (k + 1) / (nk + 1) + 0.5 for k in range(nk)]
+    ky = [N1 * (k + 1) / (nk + 1) + 0.5 for k in range(nk)]
+    outs = []
+    sol = None
+    for no_vconv in (False, True):
+        B._PLANS.clear()
+        if no_vconv:
+            os.environ["SFFT_NO_VCONV"] = "1"
+        try:
+            cfg = B.SingleSFFTConfigure.SSC(NX=N0, NY=N1, KerHW=w, KerSpType="B-Spline", KerSpDegree=deg, KerIntKnotX=kx, KerIntKnotY=ky,
+                                            SEPARATE_SCALING=sep, ScaSpDegree=0, BkgSpType="Polynomial", BkgSpDegree=1, VERBOSE_LEVEL=0,
+                                            CUDA_DEVICE_4SUBTRACT=dev.index)
+        finally:
+            os.environ.pop("SFFT_NO_VCONV", None)
+        assert cfg[0]["Fij"] == (deg + 1 + nk) ** 2
+        if sol is None:
+            rng = np.random.default_rng(17)
+            sol = rng.normal(size=cfg[0]["NEQ"])
+            sol[:cfg[0]["Fijab"]] *= float(N0) * float(N1) * 0.01
+        d_rand = B.ElementalSFFTSubtract.ESS(pair["REF"], pair["SCI"], cfg, SFFTSolution=sol, Subtract=True, VERBOSE_LEVEL=0)[1]
+        s2, d2, _ = B.GeneralSFFTSubtract.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)
+        outs.append((np.asarray(d_rand), np.asarray(s2), np.asarray(d2)))
+    B._PLANS.clear()
+    (da, sa, ga), (db, sb, gb) = outs
+    assert rms(da - db) <= 1e-12 * rms(db)
+    assert np.array_equal(sa, sb)
+    assert rms(ga - gb) <= 1e-11 * rms(pair["SCI"])
+
+
 # ------------------------------------------------------------------------------------------------
 # (e2) separately varying scaling + kernel regularisation (BSplineSFFT.py SCALING_MODE 'SEPARATE-VARYING', REGULARIZE_KERNEL).
 # The reference has no CPU code for these ("parity unpinned"): the comparison is oracle/bspline_sv_oracle.py, itself pinned
