@@ -50,7 +50,28 @@ __device__ __forceinline__ void g1_row(const cplx av, const cplx bv, const cplx*
     }
 }
 
-template <int HBW, int U>
+// The same for a row pair (x', x' + N0 / 2) after one radix-2 decimation step: the twiddle of lag r at the partner row is (-1)^r times
+// the one at row x', so even lags take the sum of the two products and odd lags their difference, and the lag sums run over half
+// the rows (see greek_g1_mfma4g<.., true>).  The band starts at an odd lag (r_base is even): t even -> odd lag.
+template <int HBW>
+__device__ __forceinline__ void g1_row_dit(const cplx av, const cplx bv, const cplx av2, const cplx bv2, const cplx* __restrict__ trow,
+                                           double (&S1)[HBW], double (&S2)[HBW], double (&S3)[HBW], double (&S4)[HBW], double& g0x, double& g0y)
+{
+    const cplx H = cmulc(av, bv), H2 = cmulc(av2, bv2);
+    const cplx Ye = make_double2(H.x + H2.x, H.y + H2.y), Yo = make_double2(H.x - H2.x, H.y - H2.y);
+    g0x += Ye.x; g0y += Ye.y;
+#pragma unroll
+    for (int t = 0; t < HBW; ++t) {
+        const cplx w = trow[t];
+        const cplx Y = (t & 1) ? Ye : Yo;
+        S1[t] = fma(Y.x, w.x, S1[t]);
+        S2[t] = fma(Y.y, w.y, S2[t]);
+        S3[t] = fma(Y.x, w.y, S3[t]);
+        S4[t] = fma(Y.y, w.x, S4[t]);
+    }
+}
+
+template <int HBW, int U, bool DIT = false>
 __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
                                                cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay, int rows_per_chunk,
                                                int r_base, const cplx* __restrict__ W0tab, int HM, const cplx* __restrict__ Xp,
@@ -70,8 +91,8 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
     const G1Pass pr = passes[pass0 + (logical - tile * npass)];
     const int h = pr.h;
     const int PH = 2 * h + 1;
-    const int lb = chunk * rows_per_chunk;
-    const int le = min(N0, lb + rows_per_chunk);
+    const int lb = chunk * rows_per_chunk;              // (DIT: rows_per_chunk counts rows x' of the first half; their partners are x' + N0 / 2)
+    const int le = min(DIT ? N0 / 2 : N0, lb + rows_per_chunk);
     const bool active = m < Nh;
     const int mc = active ? m : 0;
     const size_t plane_sz = (size_t)N0 * Nhp;
@@ -87,6 +108,36 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
     // W0tab[l][r] = W0^(l r): one contiguous, wave-uniform row of twiddles per image row
     const cplx* __restrict__ trow = W0tab + (size_t)lb * HM + rfirst;
     int l = lb;
+    if (DIT) {
+        const size_t half = (size_t)(N0 / 2);
+        const cplx* __restrict__ A2 = A + half * rs;
+        if (!colfac) {
+            const cplx* __restrict__ B = spec + (size_t)pr.b_plane * plane_sz + mo;
+            const cplx* __restrict__ B2 = B + half * rs;
+            for (; l + U <= le; l += U, trow += (size_t)U * HM) {
+                cplx av[U], bv[U], av2[U], bv2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { av[u] = A[(size_t)(l + u) * rs]; av2[u] = A2[(size_t)(l + u) * rs]; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { bv[u] = B[(size_t)(l + u) * rs]; bv2[u] = B2[(size_t)(l + u) * rs]; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) g1_row_dit<HBW>(av[u], bv[u], av2[u], bv2[u], trow + (size_t)u * HM, S1, S2, S3, S4, g0x, g0y);
+            }
+            for (; l < le; ++l, trow += HM)
+                g1_row_dit<HBW>(A[(size_t)l * rs], B[(size_t)l * rs], A2[(size_t)l * rs], B2[(size_t)l * rs], trow, S1, S2, S3, S4, g0x, g0y);
+        } else {
+            const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
+            for (; l + U <= le; l += U, trow += (size_t)U * HM) {
+                cplx av[U], av2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { av[u] = A[(size_t)(l + u) * rs]; av2[u] = A2[(size_t)(l + u) * rs]; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) g1_row_dit<HBW>(av[u], xp[l + u], av2[u], xp[l + u + half], trow + (size_t)u * HM, S1, S2, S3, S4, g0x, g0y);
+            }
+            for (; l < le; ++l, trow += HM)
+                g1_row_dit<HBW>(A[(size_t)l * rs], xp[l], A2[(size_t)l * rs], xp[l + half], trow, S1, S2, S3, S4, g0x, g0y);
+        }
+    } else
     if (!colfac) {
         const cplx* __restrict__ B = spec + (size_t)pr.b_plane * plane_sz + mo;
         for (; l + U <= le; l += U, trow += (size_t)U * HM) {

@@ -1483,9 +1483,15 @@ static void launch_g1(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
     const int ncb = (p->Nh + 63) / 64;
     const int total = ncb * p->S * npass;
     dim3 g(8 * ((total + 7) / 8));
-    for (int rb = 0; rb < h || rb == 0; rb += HBW)
-        hipLaunchKernelGGL((greek_g1<HBW, U>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
-                           p->Nhp, p->lay, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+    // even N0: one radix-2 decimation step along the rows (half the lag arithmetic; the chunks split the first half of the rows)
+    const bool dit = p->g1_dit && (p->N0 % 2) == 0 && (HBW % 2) == 0 && p->N0 / (2 * p->S) >= 8;
+    const int rpc2 = (p->N0 / 2 + p->S - 1) / p->S;
+    for (int rb = 0; rb < h || rb == 0; rb += HBW) {
+        if (dit) hipLaunchKernelGGL((greek_g1<HBW, U, true>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
+                                    p->Nhp, p->lay, rpc2, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+        else hipLaunchKernelGGL((greek_g1<HBW, U>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
+                                p->Nhp, p->lay, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+    }
 }
 
 // lags per launch: the whole band in one launch up to 16 lags (64 accumulators per lane), else the split with the
