@@ -746,7 +746,10 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                               + nsca * p->Fij + nsca * (nsca + 1) / 2 + nsca * (BS.nbx + 1);
         const int JP = p->Fij;                                  // plane of J
         auto SP = [&](int s) { return p->Fij + 1 + s; };        // plane of scaling term s
-        while (S < 16 && (long long)colblocks * S * npass_est < 6144 && N0 / (2 * S) >= 64) S *= 2;
+        // (with the decimation step of the stage-1 kernels a wave covers its rows in half the steps: half the chunks -- and half the partial
+        //  sums -- fill the chip as well; measured at 4096^2: 4 chunks 675 pairs/s, 8 chunks 665, 2 chunks 663)
+        const long long fill_target = (p->g1_dit && N0 % 2 == 0) ? 3072 : 6144;
+        while (S < 16 && (long long)colblocks * S * npass_est < fill_target && N0 / (2 * S) >= 64) S *= 2;
         if (const char* ev = getenv("SFFT_G1_S")) { const int v = atoi(ev); if (v >= 1 && v <= 16 && N0 / v >= 64) S = v; }      // A/B: row chunks of the Omega launch
         p->S = S;
         p->rows_per_chunk = (N0 + S - 1) / S;
