@@ -382,7 +382,7 @@ def main():
                      "construct": ("vconv_tensor" if bspline else "vconv_mixed2<2, 8, 4>") if mixed and w <= 8 else ("vconv_mixed" if mixed else "construct_fd")}
 
         def roof(stages, dom="fwd_cols"):
-            ach = ab[dom] / (stages[dom] * 1e-3) / 1e9
+            ach = ab[dom] / (max(stages[dom], 1e-6) * 1e-3) / 1e9      # (a stage that was not timed separately, e.g. SFFT_STAGE_INTERLEAVE=1, reads 0)
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if headline else None
             return {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "sustained_peak_measured": 5000.0,   # profiles/r01_hbm_stream.txt: a plain copy kernel on this device, GB/s

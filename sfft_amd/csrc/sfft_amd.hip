@@ -191,6 +191,7 @@ struct sfft_plan {
     int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row,
                                         // 3: register-stationary taps (vconv_mixed3: measured 2.5x slower, the walk is load-latency bound at 2 waves per SIMD)
     int num_cu = 256;
+    int stage_interleave = 0;           // env SFFT_STAGE_INTERLEAVE=1: forward transforms plane at a time (row pass, then the column pass of its outputs)
     int vconv_direct_launch = 0;        // env SFFT_VCONV_DIRECT=1: the leftover columns of the mixed-domain apply in a launch of their own (vconv_direct)
     int g1_dit = 1;                     // env SFFT_G1_DIT=0: grouped Omega launch without the radix-2 decimation step along the rows
     int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
@@ -525,6 +526,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_VCONV3_R")) p->vconv3_r = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_R")) p->vconv_r = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_DIT")) p->g1_dit = atoi(ev);
+    if (const char* ev = getenv("SFFT_STAGE_INTERLEAVE")) p->stage_interleave = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_DIRECT")) p->vconv_direct_launch = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
@@ -1398,8 +1400,36 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
         if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
         return SFFT_OK;
     }
-    if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
     const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
+    if (p->stage_interleave && p->colq && p->lay.rstride == 4 && p->lay.mask == 3) {
+        // A/B (SFFT_STAGE_INTERLEAVE=1): plane at a time -- the row pass of one stage plane, then the column pass of its outputs, so that the
+        // column pass finds the 134 MB it reads in the 256 MB memory-side cache; the image is then read once per stage plane
+        if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
+        const int nquads = (p->Nh + 3) / 4;
+        bool momI = false, momJ = false;
+        for (int k = 0; k < nst; ++k) {
+            RowsArgs ra;
+            for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = p->d_ones; ra.wy[u] = p->d_ones; }
+            RowGroups grp; grp.ngroups = 1; grp.first[0] = 0; grp.count[0] = 1;
+            for (int u = 0; u < SFFT_MAX_PLANES; ++u) { grp.mom_out[u] = nullptr; grp.mom_nq[u] = 0; }
+            ra.src[0] = stages[k].src; ra.wy[0] = stages[k].wy;
+            if (p->rowmom_fused && d_J) {
+                if (stages[k].src == d_J && !momJ) { grp.mom_out[0] = p->d_rowmom; grp.mom_nq[0] = p->nby; momJ = true; }
+                else if (stages[k].src == d_I && !momI) { grp.mom_out[0] = p->d_rowmomI; grp.mom_nq[0] = p->gam_nmu; momI = true; }
+            }
+            hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, 1), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp,
+                               p->d_stage + (size_t)k * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
+            ColOuts g; memset(&g, 0, sizeof(g));
+            for (const Out& o : stages[k].outs) { g.stage_plane[g.nout] = k; g.out_plane[g.nout] = o.plane; g.wx[g.nout] = o.wx; ++g.nout; }
+            const int total = nquads * g.nout;
+            hipLaunchKernelGGL(cols_fwd_weighted_4096_q, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
+                               p->Nhp, p->lay, p->ax0.tw, nquads);
+        }
+        LAUNCH_CHECK();
+        if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
+        return SFFT_OK;
+    }
+    if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
     for (int k0 = 0; k0 < nst; k0 += SFFT_MAX_PLANES) {
         const int n = std::min(SFFT_MAX_PLANES, nst - k0);
         RowsArgs ra;
