@@ -580,6 +580,37 @@ def test_config2_full_size_matches_oracle(dev, big):
     assert rel_rms_err(diff.cpu().numpy(), D_o) <= 1e-6
 
 
+def test_config5_strip_matches_oracle(dev):
+    """BASELINE config 5's geometry on a 9232 x 128 strip: the four-step 9232-point axis (16 x 577), KerHW 12 (49 x 49 Omega lag patches: the
+    decimated vector kernel in two lag bands), orders 3 / 3 (NEQ 6260: the outer-blocked Cholesky), vconv_mixed<3,12> -- against the oracle:
+    LHMAT / RHb <= 1e-11 block by block, apply-only DIFF <= 1e-10 RMS(J), end to end <= 1e-6."""
+    from oracle import sfft_oracle as O
+    from sfft_amd.plan import Plan
+    N0, N1, w = 9232, 128, 12
+    REF, SCI, mREF, mSCI = _blob_pair(N0, N1, 5)
+    plan = Plan(N0, N1, w, 3, 3, True, device=dev.index)
+    assert plan.NEQ == 6260
+    ncpu = min(64, os.cpu_count() or 1)
+    p = O.SSC(N0, N1, w, 3, 3, True)
+    LH_o, rhs_o = O.establish_system(mREF, mSCI, p, workers=ncpu)
+    R, S, mR, mS = _to(dev, REF), _to(dev, SCI), _to(dev, mREF), _to(dev, mSCI)
+    sol, diff = plan.subtract(R, S, mR, mS)
+    assert plan.query("LAST_SOLVER") == 1
+    LH, rhs = plan.get_system()
+    LH, rhs = LH.cpu().numpy(), rhs.cpu().numpy()
+    nk = p["Fijab"]
+    for blk, blk_o in ((LH[:nk, :nk], LH_o[:nk, :nk]), (LH[:nk, nk:], LH_o[:nk, nk:]), (LH[nk:, nk:], LH_o[nk:, nk:]),
+                       (rhs[:nk], rhs_o[:nk]), (rhs[nk:], rhs_o[nk:])):
+        assert np.max(np.abs(blk - blk_o)) <= 1e-11 * np.max(np.abs(blk_o))
+    del LH
+    sol_o = O.solve_system(LH_o, rhs_o, p)
+    D_o = O.ESS(REF, SCI, p, sol_o, True, ncpu)[1]
+    Da = plan.apply(R, S, _to(dev, sol_o)).cpu().numpy()
+    assert rms(Da - D_o) <= 1e-10 * rms(SCI)
+    assert rel_rms_err(diff.cpu().numpy(), D_o) <= 1e-6
+    plan.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # (e) B-spline form (sfft_amd.BSplineSFFT): golden vectors from the reference's dev-version Numpy backend
 # ------------------------------------------------------------------------------------------------
