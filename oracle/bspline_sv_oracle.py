@@ -125,14 +125,17 @@ def establish_system(PixA_I, PixA_J, p, basis, sca, workers=1):
     MOD_a, MOD_b = np.mod(-a_, N0), np.mod(-b_, N1)
     MODda, MODdb = np.mod(a_[:, None] - a_[None, :], N0), np.mod(b_[:, None] - b_[None, :], N1)
     pre = lambda H: f2(H).real
+    # place-holder scaling planes are exactly zero (ScaREF_ij == (-1, -1)), and so is every product with them: skip the transform
+    Sz = [not np.any(sca['sca_pairs'][k] >= 0) for k in range(Fij)]
+    ZERO = np.zeros((N0, N1))
     LHMAT = np.empty((NEQ, NEQ))
     RHb = np.empty(NEQ)
     for i8 in range(Fij):
         for ij in range(Fij):
             P11 = pre(FI[i8] * CFI[ij]) * SCALE
-            P01 = pre(FS[i8] * CFI[ij]) * SCALE
-            P10 = pre(FI[i8] * CFS[ij]) * SCALE
-            P00 = pre(FS[i8] * CFS[ij]) * SCALE
+            P01 = ZERO if Sz[i8] else pre(FS[i8] * CFI[ij]) * SCALE
+            P10 = ZERO if Sz[ij] else pre(FI[i8] * CFS[ij]) * SCALE
+            P00 = ZERO if (Sz[i8] or Sz[ij]) else pre(FS[i8] * CFS[ij]) * SCALE
             blk = -P11[MODa, MODb][:, None] - P11[MOD_a, MOD_b][None, :] + P11[MODda, MODdb] + P11[0, 0]
             blk[cen, :] = (P01[MOD_a, MOD_b] - P01[0, 0])[None, :]
             blk[:, cen] = (P10[MODa, MODb] - P10[0, 0])[:, None]

@@ -17,8 +17,29 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "sfft_cpu.cpp")
-LIB = os.path.join(HERE, "_build", "libsfft_cpu.so")
 CXXFLAGS = ["-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", "-std=c++17"]
+
+
+def _host_tag():
+    """-march=native binds the library to the build host's instruction set; the file name carries a hash of the CPU model, its
+    feature flags and the compiler flags, so a library built on one host is never loaded (SIGILL) on another -- the GPU box
+    rebuilds its own on first use."""
+    import hashlib
+    model = flags = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = line.split(":", 1)[1].strip()
+            if model and flags:
+                break
+    except OSError:
+        pass
+    return hashlib.sha1((model + "|" + flags + "|" + " ".join(CXXFLAGS)).encode()).hexdigest()[:12]
+
+
+LIB = os.path.join(HERE, "_build", "libsfft_cpu.%s.so" % _host_tag())
 
 _lib = None
 

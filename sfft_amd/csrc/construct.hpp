@@ -669,46 +669,60 @@ __global__ void copy_spectrum(const cplx* __restrict__ src, cplx* __restrict__ d
 //   out(x, y) = sum_ab K[label(x, y)][a][b] * in(x + w0 - a, y + w1 - b),   w = (L - 1) / 2,   zeros beyond the image
 // (= scipy / cupyx convolve2d(mode='same', boundary='fill') of every box segment with its own kernel; the reference
 // extends each box by w + 1 pixels before convolving, so inside a box only the image border ever supplies zeros).
-// 16 x 16 output pixels per workgroup; the input tile with its halo sits in LDS; a wave whose pixels share one label reads
-// the kernel through scalar loads.
+// 16 x 16 output pixels per workgroup.  The kernel stamp is walked in bands of A rows: the (16 + A - 1) x (16 + L1 - 1) input
+// pixels a band needs sit in LDS (A is chosen by the host so that a band fits 64 KB: any stamp size runs, e.g. the 411 x 411
+// decorrelation kernels of the reference's NIRCam example, where the whole halo would be 1.4 MB).  A wave reads the stamp of
+// its label through scalar loads; a wave that straddles box borders walks the band once per distinct label among its lanes
+// with the other lanes' sums discarded, so the stamp reads stay scalar.
+// Two partial sums per pixel (even / odd stamp columns) keep two fp64 FMA chains in flight.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) grid_convolve(const double* __restrict__ in, const int* __restrict__ labels,
                                                      const double* __restrict__ kers, int N0, int N1, int Nseg, int L0, int L1,
-                                                     double* __restrict__ out)
+                                                     int A, double* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* tile = reinterpret_cast<double*>(smem_raw);
     const int w0 = (L0 - 1) / 2, w1 = (L1 - 1) / 2;
-    const int TH = 16 + L0 - 1, TW = 16 + L1 - 1;
+    const int TW = 16 + L1 - 1;
     const int x0 = blockIdx.y * 16, y0 = blockIdx.x * 16;
-    const int ox = x0 - (L0 - 1 - w0), oy = y0 - (L1 - 1 - w1);       // image coordinates of tile[0][0]
-    for (int e = threadIdx.x; e < TH * TW; e += 256) {
-        const int tx = e / TW, ty = e - tx * TW;
-        const int gx = ox + tx, gy = oy + ty;
-        tile[e] = (gx >= 0 && gx < N0 && gy >= 0 && gy < N1) ? in[(size_t)gx * N1 + gy] : 0.0;
-    }
-    __syncthreads();
+    const int oy = y0 - (L1 - 1 - w1);                                  // image column of tile[.][0]
     const int lx = threadIdx.x >> 4, ly = threadIdx.x & 15;
     const int x = x0 + lx, y = y0 + ly;
     const bool inside = x < N0 && y < N1;
     int lab = inside ? labels[(size_t)x * N1 + y] : -1;
     if (lab >= Nseg) lab = -1;
-    const int lab_u = __builtin_amdgcn_readfirstlane(lab);
     double acc = 0.0;
-    // tile row of in(x + w0 - a, .) is lx + (L0 - 1) - a; column of in(., y + w1 - b) is ly + (L1 - 1) - b
-    if (__all(lab == lab_u)) {
-        if (lab_u >= 0) {
-            const double* __restrict__ K = kers + (size_t)lab_u * L0 * L1;          // wave-uniform
-            for (int a = 0; a < L0; ++a) {
-                const double* trow = tile + (lx + (L0 - 1) - a) * TW + ly + (L1 - 1);
-                for (int b = 0; b < L1; ++b) acc = fma(K[a * L1 + b], trow[-b], acc);
-            }
+    for (int a0 = 0; a0 < L0; a0 += A) {
+        const int na = min(A, L0 - a0);
+        // rows of the image this band touches: x + w0 - a for a in [a0, a0 + na) and the 16 rows of the block
+        const int TH = 16 + na - 1;
+        const int ox = x0 + w0 - (a0 + na - 1);                         // image row of tile[0][.]
+        __syncthreads();
+        for (int e = threadIdx.x; e < TH * TW; e += 256) {
+            const int tx = e / TW, ty = e - tx * TW;
+            const int gx = ox + tx, gy = oy + ty;
+            tile[e] = (gx >= 0 && gx < N0 && gy >= 0 && gy < N1) ? in[(size_t)gx * N1 + gy] : 0.0;
         }
-    } else if (lab >= 0) {
-        const double* __restrict__ K = kers + (size_t)lab * L0 * L1;
-        for (int a = 0; a < L0; ++a) {
-            const double* trow = tile + (lx + (L0 - 1) - a) * TW + ly + (L1 - 1);
-            for (int b = 0; b < L1; ++b) acc = fma(K[a * L1 + b], trow[-b], acc);
+        __syncthreads();
+        int pending = lab;
+        for (;;) {                                                      // one walk of the band per distinct label of this wave
+            const unsigned long long m = __ballot(pending >= 0);
+            if (!m) break;
+            const int cur = __builtin_amdgcn_readlane(pending, __ffsll((long long)m) - 1);      // wave-uniform
+            const double* __restrict__ K = kers + ((size_t)cur * L0 + a0) * L1;
+            double s0 = 0.0, s1 = 0.0;
+            for (int da = 0; da < na; ++da) {
+                // tile row of in(x + w0 - (a0 + da), .) is lx + (na - 1) - da; column of in(., y + w1 - b) is ly + (L1 - 1) - b
+                const double* trow = tile + (lx + (na - 1) - da) * TW + ly + (L1 - 1);
+                const double* __restrict__ Kr = K + (size_t)da * L1;
+                int b = 0;
+                for (; b + 1 < L1; b += 2) {
+                    s0 = fma(Kr[b], trow[-b], s0);
+                    s1 = fma(Kr[b + 1], trow[-b - 1], s1);
+                }
+                if (b < L1) s0 = fma(Kr[b], trow[-b], s0);
+            }
+            if (pending == cur) { acc += s0 + s1; pending = -1; }
         }
     }
     if (inside) out[(size_t)x * N1 + y] = acc;

@@ -1805,6 +1805,10 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
 {
     ON_DEVICE(p->dev);
     int rc;
+    // The fused row moments give each row-pass group (one per distinct source image) ONE moment output.  solve(I, I) has a single
+    // group, so only one of the two moment sets would be written: such a call takes the separate row_moments launches.
+    struct ScopedInt { int& r; int old; ScopedInt(int& ref, int v) : r(ref), old(ref) { r = v; } ~ScopedInt() { r = old; } }
+        rowmom_scope(p->rowmom_fused, d_I == d_J ? 0 : p->rowmom_fused);
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
         if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS))) return rc;
@@ -2260,12 +2264,17 @@ extern "C" int sfft_grid_convolve(const double* d_in, const int* d_labels, const
 {
     if (!d_in || !d_labels || !d_kerstack || !d_out) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
     if (N0 < 1 || N1 < 1 || Nseg < 1 || L0 < 1 || L1 < 1) return set_err(SFFT_ERR_INVALID_ARG, "bad size");
-    const size_t lds = (size_t)(16 + L0 - 1) * (16 + L1 - 1) * sizeof(double);
-    if (lds > 150 * 1024) return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "kernel stamp too large for the on-chip tile of this build");
+    // stamp rows per LDS band: the whole stamp when its halo fits 64 KB (two workgroups per CU), else as many rows as do
+    const size_t row_bytes = (size_t)(16 + L1 - 1) * sizeof(double);
+    if (16 * row_bytes > 150 * 1024) return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "kernel stamp too wide for the on-chip band of this build");
+    long long A = (long long)(64 * 1024 / row_bytes) - 15;
+    if (A < 1) A = 1;
+    if (A > L0) A = L0;
+    const size_t lds = (size_t)(16 + A - 1) * row_bytes;
     ON_DEVICE(device);
     HIPCHK(hipFuncSetAttribute((const void*)grid_convolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(grid_convolve, dim3((N1 + 15) / 16, (N0 + 15) / 16), dim3(256), lds, (hipStream_t)stream, d_in, d_labels, d_kerstack,
-                       N0, N1, Nseg, L0, L1, d_out);
+                       N0, N1, Nseg, L0, L1, (int)A, d_out);
     LAUNCH_CHECK();
     return SFFT_OK;
 }

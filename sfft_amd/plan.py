@@ -133,6 +133,7 @@ class Plan:
         f8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
         ireg, sst, csst, dsst = f8(ireg), f8(sst), f8(csst), f8(dsst)
         ptr = lambda a: None if a is None else a.ctypes.data
+        self._reg_token = None          # a direct call: whatever config's penalty the plan carried is gone (see _bound_plan)
         _lib.check(_lib.lib().sfft_plan_set_regularization(self._h, float(lam), ptr(ireg), ptr(sst), ptr(csst), ptr(dsst)))
 
     def set_timing(self, enable=True):

@@ -345,6 +345,25 @@ def test_baseline_size_identity_kernel_and_background(dev, big):
     assert rms(D - expect) <= 1e-10 * rms(pair["SCI"])
 
 
+def test_baseline_size_one_tensor_as_both_images(dev, big):
+    """solve(I, I) on the 4096^2 path: the fused row pass writes one row-moment set per distinct source image, so a call whose
+    two images are ONE buffer must fall back to the separate moment launches (round-2 advice).  The system of (I, I) must equal
+    the system of (I, copy of I) and the solution must be the identity kernel with zero background."""
+    plan, pair, g = big
+    I = g["mREF"]
+    sol_a = plan.solve(I, I)
+    LH_a, rhs_a = plan.get_system()
+    sol_b = plan.solve(I, I.clone())
+    LH_b, rhs_b = plan.get_system()
+    assert torch.equal(LH_a, LH_b) and torch.equal(rhs_a, rhs_b)
+    assert torch.equal(sol_a, sol_b)
+    s = sol_a.cpu().numpy()
+    N = plan.N0
+    expect = np.zeros(plan.NEQ)
+    expect[8 * 17 + 8] = float(N * N)
+    assert np.abs(s - expect).max() <= 1e-5 * N * N
+
+
 def test_baseline_size_shift_kernel_and_linearity(dev, big):
     """A pure shift kernel (delta at (a,b)) reproduces a circularly shifted I; apply is linear in the solution."""
     plan, pair, g = big
