@@ -20,10 +20,15 @@ the pipelined run must equal it bit for bit (`post_check`); the same isolated la
 `roofline` objects (HIP events on the launch stream).
 
 Rank 0 prints ONE JSON line.  `value` = image pairs per second over all ranks.  Extra objects:
-  roofline      the dominant KERNEL by time per pair: the Omega passes of the Greek stage (v_mfma_f64_16x16x4_f64) against
-                the fp64 MFMA peak; roofline_hbm: the dominant HBM-bound kernel, the forward column pass
+  roofline      the stage with the most kernel time per pair among ALL timed stages (one pair in flight, HIP events): an HBM-bound
+                transform pass against 8 TB/s, the Omega + Theta launch (v_mfma_f64_4x4x4_4b_f64) or the dense solve (n^3 / 3
+                flops of the Cholesky factorisation, latency-bound) against the fp64 matrix peak.  roofline_hbm: the dominant
+                HBM-bound kernel; roofline_greek: the Omega + Theta launch; roofline_solve: the factorisation
   cpu_baseline  the CPU restatement of the reference's Numpy path timed on this host (N = 1, config 2 only)
   host_arrays   the same workload with CP semantics: host (pinned) arrays in, host arrays out, PCIe both ways -- never `value`
+  other_configs short legs of the other BASELINE configs after the headline's timed region (never part of `value`): 3 (B-spline,
+                6144^2) and 5 (9232 x 9216, KerHW 12) at N = 1, and 4 (a batch of 62 config-2 pairs dealt to the ranks) at every N;
+                each with its own value, timed region, single-pair stage times, roofline and post_check (`--no-other-configs` skips)
 """
 import argparse
 import json
@@ -44,6 +49,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # fp64 vector = fp64 matrix (MFMA) peak on MI355X (public spec; the guide has no fp64 MFMA row)
+HBM_COPY_MEASURED_GBS = 5000.0   # a plain 16-byte-per-lane copy kernel on the boxes this was run on (scripts/micro/hbm_stream.hip,
+                                 # profiles/r01_hbm_stream.txt); the guide quotes 6290 for its float4 copy
+COLS_KERNEL = {(9232, 9216): "strided_dft (four-step 9232 = 16 x 577 column axis)", (6144, 6144): "cols_fwd_weighted (6144-point mixed-radix axis)"}
 
 CONFIGS = {
     2: dict(N0=4096, N1=4096, w=8, DK=2, DB=2, batch=64, streams=4,
@@ -91,6 +99,11 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False,
         n_the = Fij if theta_fused else 0
         out["greek_g1_flops"] = (N0 * Nh * (n_off * 6 + n_diag * 3 + n_the * 6)
                                  + (N0 // 2) * Nh * (n_off * (4 + 2 * 4 * (2 * w)) + n_diag * (2 + 4 * (2 * w)) + n_the * (4 + 2 * 4 * w)))
+    # the part of greek_g1_flops that is lag sums (what runs on the matrix cores when the lag half-width allows); the rest -- complex
+    # products and decimation butterflies -- runs on the vector ALUs
+    n_the = Fij if theta_fused else 0
+    rows_l = (N0 // 2) if decimated else N0
+    out["greek_g1_mfma_flops"] = rows_l * Nh * (n_off * 2 * 4 * (2 * w) + n_diag * 4 * (2 * w) + n_the * 2 * 4 * w)
     if mixed_apply:
         # polynomial kernel: row pass into stage planes, mixed-domain column convolution (reads them, writes one plane),
         # inverse row pass with the DIFF epilogue -- no column transforms
@@ -147,7 +160,7 @@ def derive_pair(torch, base, k, dev):
             "mSCI": torch.where(keep, SCI, z).contiguous()}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -162,26 +175,23 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline with the full protocol (3 warm-ups, median of 10) instead of the bounded one")
     ap.add_argument("--no-host-arrays", action="store_true", help="skip the host-array (PCIe-inclusive) variant")
-    args = ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of configs 3, 4 and 5 after the headline run")
+    return ap.parse_args(argv)
 
+
+def run_config(args, rank, world, local_rank, headline_extras=True):
+    """One bench leg: `args.config` (or config 4 with `args.pairs`), `args.warmup` untimed + `args.steps` timed steps between
+    barriers.  Returns the JSON object on rank 0, None elsewhere.  headline_extras: also run the host-array variant and the
+    cpu_baseline leg (config 2 at N = 1 only)."""
     import threading
     import torch
     import torch.distributed as dist
+    from sfft_amd import _lib
     from sfft_amd.plan import Plan
     from sfft_amd.sharding import shard_pair_ids, pack_record, gather_records, run_shard
     from sfft_amd.utils.synthetic import make_pair
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     cfg = dict(CONFIGS[args.config])
     if args.size:
         cfg["N0"] = cfg["N1"] = args.size
@@ -233,11 +243,22 @@ def main():
     diffs = [torch.empty((N0, N1), dtype=torch.float64, device=dev) for _ in my_ids]
     torch.cuda.synchronize(dev)
 
+    status = [0] * len(my_ids)       # the C ABI's return code of each pair's last sfft_subtract (static mode; run_shard keeps its own)
+
     def subtract(wi, k):
         """pair k of this rank's shard on worker wi's plan and stream"""
         g = pairs[k]
         plans[wi].subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"], out_solution=sols[k], out_diff=diffs[k])
         return sols[k]
+
+    def subtract_recorded(wi, k):
+        try:
+            subtract(wi, k)
+            status[k] = 0
+        except np.linalg.LinAlgError:
+            status[k] = _lib.SFFT_ERR_SINGULAR
+        except _lib.SfftError as e:
+            status[k] = e.code
 
     last_records = [None]
 
@@ -247,7 +268,7 @@ def main():
             with torch.cuda.stream(streams[wi]):
                 for _ in range(n):
                     for k in range(wi, len(my_ids), S):
-                        subtract(wi, k)
+                        subtract_recorded(wi, k)
         if not batch_mode:
             if S == 1:
                 static_worker(0)
@@ -312,13 +333,13 @@ def main():
     if batch_mode:
         recs = last_records[0]
     else:
-        recs = [pack_record(my_ids[k], 0, elapsed * 1e3 / max(args.steps * len(my_ids), 1), sols[k]) for k in range(len(my_ids))]
+        recs = [pack_record(my_ids[k], status[k], elapsed * 1e3 / max(args.steps * len(my_ids), 1), sols[k]) for k in range(len(my_ids))]
     table = gather_records(recs, n_total, NEQ, dev)
     n_failed = int((table[:, 1] != 0).sum().item())
 
     # ---- host-array variant (CP semantics): pinned host arrays in, host arrays out, H2D / D2H overlapped across streams ----
     host = None
-    if world == 1 and args.config == 2 and not batch_mode and not args.no_host_arrays:
+    if headline_extras and world == 1 and args.config == 2 and not batch_mode and not args.no_host_arrays:
         nh = min(len(my_ids), 2 * S)
         hin = [{k: v.cpu().pin_memory() for k, v in pairs[k].items()} for k in range(nh)]
         hout = [torch.empty((N0, N1), dtype=torch.float64).pin_memory() for _ in range(nh)]
@@ -358,6 +379,7 @@ def main():
                         "never `value`" % S}
         del hin, hout, dbuf, dd
 
+    out = None
     if rank == 0:
         value = n_total * args.steps / elapsed
         ms_step = elapsed * 1e3 / args.steps
@@ -368,6 +390,7 @@ def main():
         ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused,
                        (plans[0].query("OMG_OFFDIAG"), plans[0].query("OMG_DIAG")), decimated, plans[0].query("G1_CHUNKS"))
         headline = (args.config == 2 and (N0, N1, w) == (4096, 4096, 8))
+        n_sys = plans[0].query("NEQ_FSfree")              # unknowns of the system that is factorised
 
         pmc = {}
         try:   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json; see profiles/README.md)
@@ -375,35 +398,56 @@ def main():
         except Exception:
             pass
         fast = (N0 == 4096 and N1 == 4096)
-        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if fast else "cols_fwd_weighted / strided_dft",
+        g1_mfma = bool(plans[0].query("G1_MFMA"))
+        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if fast else COLS_KERNEL.get((N0, N1), "cols_fwd_weighted"),
                      "fwd_rows": "rows_r2c_4096" if fast else "rows_r2c",
-                     "greek_g1": "greek_g1_mfma4g (Omega passes in groups%s)" % (" + the Theta passes" if theta_fused else ""),
+                     "greek_g1": ("greek_g1_mfma4g (Omega passes in groups%s)" % (" + the Theta passes" if theta_fused else "")) if g1_mfma
+                                 else "greek_g1<12, 2, true> (Omega passes, vector kernel in two lag bands)",
                      "greek_g1b": ("" if theta_fused else "greek_g1<8, 2> (Theta passes) + ") + "row_moments / gamma_rows / gamma_patches (Gamma block)",
+                     "prelim_apply": "rows_r2c_4096 (apply pass)" if fast else "rows_r2c (+ cols_fwd_weighted) of the apply pass",
+                     "inverse": "rows_c2r_diff_4096" if fast else "rows_c2r_diff (+ cols_c2c)",
+                     "solve": "chol_dataflow (+ chol_inv_diag, chol_back_all, scatter_solution)" if plans[0].query("CHOL_DATAFLOW") else
+                              "chol_step / chol_panel / chol_syrk chain (+ chol_back_all)",
                      "construct": ("vconv_tensor" if bspline else "vconv_mixed2<2, 8, 4>") if mixed and w <= 8 else ("vconv_mixed" if mixed else "construct_fd")}
 
         def roof(stages, dom="fwd_cols"):
             ach = ab[dom] / (max(stages[dom], 1e-6) * 1e-3) / 1e9      # (a stage that was not timed separately, e.g. SFFT_STAGE_INTERLEAVE=1, reads 0)
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if headline else None
             return {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "sustained_peak_measured": 5000.0,   # profiles/r01_hbm_stream.txt: a plain copy kernel on this device, GB/s
+                    "sustained_peak_measured": HBM_COPY_MEASURED_GBS,
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": stages[dom]}
 
         def roof_flops(stages):
-            tf = ab["greek_g1_flops"] / (stages["greek_g1"] * 1e-3) / 1e12
+            # `achieved` prices the MATRIX-pipe work only (the lag sums); the products and butterflies on the vector ALUs are listed beside it
+            tf = ab["greek_g1_mfma_flops"] / (stages["greek_g1"] * 1e-3) / 1e12
             traffic = pmc.get("greek_g1", {}).get("hbm_bytes_per_launch") if headline else None
             return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_flops"],
+                    "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_mfma_flops"],
+                    "valu_flops_per_launch": ab["greek_g1_flops"] - ab["greek_g1_mfma_flops"],
+                    "all_flops_tflops": ab["greek_g1_flops"] / (stages["greek_g1"] * 1e-3) / 1e12,
                     "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
+                    "hbm_GBs_of_alg_bytes": ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9,
                     "sustained_peak_measured": 74.5,     # profiles/r02_mfma_f64_peak.txt: a loop of independent v_mfma_f64_4x4x4_4b_f64, TFLOP/s
                     "decimated": decimated, "alg_flops_direct": ab["greek_g1_flops_direct"],
                     "direct_equivalent_tflops": ab["greek_g1_flops_direct"] / (stages["greek_g1"] * 1e-3) / 1e12,
-                    "note": "v_mfma_f64_4x4x4_4b_f64; a loop of nothing but independent MFMAs sustains 74.5 TFLOP/s with this instruction and "
-                            "47.4 with v_mfma_f64_16x16x4_f64 on this device (scripts/micro/mfma_f64_peak.hip).  alg_flops_per_launch counts the "
-                            "arithmetic as built: with the radix-2 decimation step along the rows the lag sums run over half the rows "
-                            "(alg_flops_direct is the same pruned DFT taken directly, direct_equivalent_tflops that figure over the launch time); "
-                            "the launch is not bound by the matrix pipe alone: its loads, products and twiddles without the matrix "
-                            "instructions take 0.31 ms (greek.hpp); HBM side: %.0f GB/s of algorithmic bytes"
-                            % (ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9)}
+                    "note": "alg_flops_per_launch = the lag sums as built (on the matrix cores when the lag half-width allows: "
+                            "v_mfma_f64_4x4x4_4b_f64, 74.5 TFLOP/s sustained in a loop of nothing else); with the radix-2 decimation step along "
+                            "the rows they run over half the rows (alg_flops_direct: the same pruned DFT taken directly).  The launch is "
+                            "as much HBM-side as matrix-side: see hbm_GBs_of_alg_bytes"}
+
+        def roof_solve(stages):
+            fl = n_sys ** 3 / 3.0                       # Cholesky factorisation (the triangular solves are O(n^2))
+            tf = fl / (max(stages["solve"], 1e-6) * 1e-3) / 1e12
+            return {"bound": "mfma", "regime": "latency: a chain of dependent 64-column block steps, not throughput", "kernel": KERNEL_OF["solve"],
+                    "stage": "solve", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
+                    "alg_flops_per_launch": fl, "unknowns": n_sys, "avg_ms": stages["solve"]}
+
+        # the dominant stage by kernel time of one pair, among everything that is timed
+        HBM_STAGES = [k for k in ("fwd_rows", "fwd_cols", "prelim_apply", "construct", "inverse") if k in ab]
+        cand = {k: iso_stage.get(k, 0.0) for k in HBM_STAGES + ["greek_g1", "solve"]}
+        dom = max(cand, key=lambda k: cand[k])
+        roofline = roof_solve(iso_stage) if dom == "solve" else roof_flops(iso_stage) if (dom == "greek_g1" and g1_mfma) else roof(iso_stage, dom)
+        dom_hbm = max(HBM_STAGES, key=lambda k: cand[k])
         per_pair_keys = [k for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse") if k in ab]
         if batch_mode:
             workload = ("BASELINE configs[3]: a batch of %d independent 4096x4096 pairs (config-2 geometry) dealt round-robin to %d rank(s): "
@@ -422,13 +466,16 @@ def main():
                        "pairs_per_step": n_total, "pairs_in_flight_per_gpu": S, "timed_region_s": elapsed,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "plan_create_s": plan_s, "NEQ": NEQ,
                        "solver": {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")},
-            "roofline": dict(roof_flops(iso_stage) if iso_stage["greek_g1"] >= iso_stage["fwd_cols"] else roof(iso_stage),
-                             measured="HIP events on the launch stream around the kernel, %d launches with one pair in flight right after "
-                             "the timed region (same process, same buffers)" % n_iso,
-                             kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "construct", "solve")}),
-            "roofline_hbm": dict(roof(iso_stage), measured="same events, same launches (the forward column launch of the solve pass: "
-                                 "%d stage planes in, %d planes out)" % (n_colfac + 1, Fij + 1)),
+            "roofline": dict(roofline,
+                             measured="HIP events on the launch stream around the stage's kernels, %d launches with one pair in flight right after "
+                             "the timed region (same process, same buffers); the stage with the most kernel time per pair" % n_iso,
+                             kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "greek_g2", "fill", "solve",
+                                                                           "prelim_apply", "construct", "inverse") if k in iso_stage}),
+            "roofline_hbm": dict(roof(iso_stage, dom_hbm), measured="same events, same launches: the HBM-bound stage with the most time"),
             "roofline_greek": dict(roof_flops(iso_stage), measured="same events, same launches"),
+            "roofline_solve": dict(roof_solve(iso_stage), measured="same events, same launches"),
+            "hbm_stages": {k: {"GBs": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9, "frac": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "ms": iso_stage[k], "alg_bytes": ab[k], "kernel": KERNEL_OF.get(k, k)} for k in HBM_STAGES},
             "single_pair": {"ms": float(np.median(iso_ms)), "pairs_per_s": 1e3 / float(np.median(iso_ms)), "stage_ms": iso_stage,
                             "note": "one pair in flight: latency of one GSS and per-stage times without interleaving"},
             "post_check": dict(post, note="after the timed region each listed pair is subtracted again alone (one pair in flight, fresh "
@@ -436,6 +483,7 @@ def main():
             "pair_effective": {"B_alg_reference_bytes": ab["B_alg_reference"], "n_fft_reference": ab["n_fft_reference"],
                                "effective_GBs_per_gpu": ab["B_alg_reference"] * (value / world) / 1e9,
                                "as_built_bytes_per_pair": sum(ab[k] for k in per_pair_keys),
+                               "as_built_GBs_per_gpu": sum(ab[k] for k in per_pair_keys) * (value / world) / 1e9,
                                "note": "reference-algorithm bytes (SURVEY 8d) x pairs/s per GPU; context, not the roofline: the build's own "
                                        "algorithmic bytes per pair are listed beside it"},
             "gathered_pairs": int(table.shape[0]), "failed_pairs": n_failed,
@@ -447,8 +495,59 @@ def main():
             assert int(table.shape[0]) == args.pairs
         if host is not None:
             out["host_arrays"] = host
-        if world == 1 and headline and not batch_mode and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(cfg, quick=not args.cpu_full)
+    # release this leg's device memory before the next one (plans hold GBs of workspace)
+    for pl in plans:
+        pl.close()
+    del plans, pairs, sols, diffs
+    torch.cuda.empty_cache()
+    if out is not None and headline_extras and world == 1 and headline and not batch_mode and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(cfg, quick=not args.cpu_full)
+    return out
+
+
+def main():
+    args = parse_args()
+    import copy
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    out = run_config(args, rank, world, local_rank, headline_extras=True)
+
+    # Short legs of the other BASELINE configs, after the headline's timed region and never part of its `value`: the driver only ever
+    # runs the default command, and these make configs 3 / 4 / 5 measurements instead of claims.
+    default_run = (args.config == 2 and not args.pairs and not args.size and not args.kerhw and not args.no_other_configs)
+    if default_run:
+        legs = {}
+        plan_of = {3: dict(config=3, pairs=0, steps=5, warmup=3), 5: dict(config=5, pairs=0, steps=5, warmup=3),
+                   4: dict(config=2, pairs=62, steps=5, warmup=3)}
+        order = [4] if world > 1 else [4, 3, 5]           # configs 3 and 5 are single-GPU configs; config 4 is the sharded batch
+        for cid in order:
+            a = copy.copy(args)
+            a.batch, a.streams = 0, 0
+            for k, v in plan_of[cid].items():
+                setattr(a, k, v)
+            try:
+                leg = run_config(a, rank, world, local_rank, headline_extras=False)
+            except Exception as e:      # a failing leg must not take the headline line with it
+                leg = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+                if world > 1:
+                    raise
+            if rank == 0:
+                legs[str(cid)] = leg
+        if rank == 0:
+            out["other_configs"] = dict(legs, note="short legs run after the headline's timed region (3 warm-up + 5 timed steps each, own "
+                                        "barriers, plans and data); not part of `value`")
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

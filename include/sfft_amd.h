@@ -52,6 +52,8 @@ enum {
     SFFT_Q_OMG_DIAG,                /* the same for a = b */
     SFFT_Q_G1_DECIMATED,            /* 1: the Omega launch of this plan takes a radix-2 decimation step along the rows (half the matrix instructions) */
     SFFT_Q_G1_CHUNKS,               /* row chunks of the Greek stage-1 launches: each writes one partial lag sum per pass, lag and spectrum column */
+    SFFT_Q_G1_MFMA,                 /* 1: the Omega passes of this plan run on the matrix cores (lag half-width 9 .. 16), 0: on the vector kernel */
+    SFFT_Q_CHOL_DATAFLOW,           /* 1: the Cholesky factorisation of this plan is the single-launch dataflow kernel, 0: the launch chain */
     SFFT_Q_COUNT
 };
 
@@ -138,6 +140,14 @@ int sfft_subtract(sfft_plan* plan, const double* d_I, const double* d_J, const d
  * stripe removal, exactly as ESS holds it (LHMAT[NEQ][NEQ], RHb[NEQ]; SFFTSubtract.py:616-617).
  * Either pointer may be NULL. Synchronises. */
 int sfft_get_system(sfft_plan* plan, double* d_LHMAT, double* d_RHb, void* stream);
+
+/* Parity aid: the system the factorisation actually receives for the most recent solve -- after Remove_LSFStripes
+ * (SFFTConfigure.py:693-711) / TweakLS (BSplineSFFT.py:2170-2338), with the regularisation term added -- written by the same
+ * kernel launch (`fill_system`) that fills the solver's workspace.  n = SFFT_Q_NEQ_FSFREE unknowns.
+ *   d_bordered [n+1][n+1] float64: rows / columns 0 .. n-1 the matrix, row n (and column n) the right-hand side, [n][n] = 0;
+ *   d_index    [n] int32, may be NULL: position of reduced unknown k in the full Solution vector (identity when nothing was removed).
+ * Synchronises. */
+int sfft_get_solver_system(sfft_plan* plan, double* d_bordered, int* d_index, void* stream);
 
 /* Parity aid: SCALE * DFT2(I * kbx[i][row] * kby[j][col]) (= I * cx^i * cy^j for polynomial plans with i, j <= DK)
  * in the plan's half-spectrum layout, d_spec: [N0][N1/2+1] complex128 (interleaved re,im) -- items 3+4 of SURVEY.md 8(a). */

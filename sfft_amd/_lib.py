@@ -19,18 +19,28 @@ SFFT_ERR_NOMEM = -5
 
 QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1", "Fab", "Fij", "Fpq", "NEQ", "Fijab",
                 "NEQ_FSfree", "FOMG", "FGAM", "FTHE", "FPSI", "FPHI", "FDEL", "WORKSPACE_BYTES", "LAST_SOLVER",
-                "NUM_GREEK_PAIRS", "ScaFij", "SOLVE_GRAPH", "THETA_FUSED", "OMG_OFFDIAG", "OMG_DIAG", "G1_DECIMATED", "G1_CHUNKS"]
+                "NUM_GREEK_PAIRS", "ScaFij", "SOLVE_GRAPH", "THETA_FUSED", "OMG_OFFDIAG", "OMG_DIAG", "G1_DECIMATED", "G1_CHUNKS", "G1_MFMA",
+                "CHOL_DATAFLOW"]
 STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b",
           "fwd_rows", "fwd_cols"]
 
 EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_create_varscale", "sfft_plan_set_regularization", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
-           "sfft_get_system", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",
+           "sfft_get_system", "sfft_get_solver_system", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",
            "sfft_grid_convolve", "sfft_spec_abs2_accumulate", "sfft_real_rsqrt", "sfft_spec_multiply", "sfft_half_to_full_real", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",
            "sfft_last_error", "sfft_version"]
 
 
 class SfftLibraryMissing(RuntimeError):
     pass
+
+
+class SfftError(Exception):
+    """A non-zero status of the C ABI, in the reference's convention (an Exception whose text starts 'MeLOn ERROR:');
+    `.code` keeps the ABI's return code (include/sfft_amd.h) for callers that record it, e.g. sharding.run_shard."""
+
+    def __init__(self, code, msg):
+        super().__init__("MeLOn ERROR: %s" % msg)
+        self.code = int(code)
 
 
 def _load():
@@ -51,6 +61,7 @@ def _load():
     lib.sfft_apply.argtypes = [vp, dp, dp, dp, dp, vp]
     lib.sfft_subtract.argtypes = [vp, dp, dp, dp, dp, dp, dp, vp]
     lib.sfft_get_system.argtypes = [vp, dp, dp, vp]
+    lib.sfft_get_solver_system.argtypes = [vp, dp, dp, vp]
     lib.sfft_dbg_forward_spectrum.argtypes = [vp, dp, ip, ip, dp, vp]
     dbl, ll = ctypes.c_double, ctypes.c_longlong
     lib.sfft_fft_plan_create.argtypes = [ctypes.POINTER(vp), ip, ip, ip]
@@ -95,4 +106,4 @@ def check(rc):
     if rc == SFFT_ERR_SINGULAR:
         import numpy as np
         raise np.linalg.LinAlgError(msg)      # what numpy.linalg.solve raises in the reference's Numpy backend
-    raise Exception("MeLOn ERROR: %s" % msg)
+    raise SfftError(rc, msg)

@@ -1218,6 +1218,8 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_G1_CHUNKS: *v = p->S; break;
         case SFFT_Q_G1_DECIMATED: *v = (g1_decimated(p) && 2 * p->w >= 9 && 2 * p->w <= 16) ? 1 : 0; break;
         case SFFT_Q_OMG_DIAG: *v = p->n_omg_diag; break;
+        case SFFT_Q_G1_MFMA: *v = (p->g1_mfma && 2 * p->w >= 9 && 2 * p->w <= 16) ? 1 : 0; break;
+        case SFFT_Q_CHOL_DATAFLOW: *v = (p->dataflow && p->NEQfs < p->chol_outer_min) ? 1 : 0; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
     return SFFT_OK;
@@ -2150,6 +2152,29 @@ extern "C" int sfft_get_system(sfft_plan* p, double* d_LHMAT, double* d_RHb, voi
     ON_DEVICE(p->dev);
     dim3 g((p->NEQ + 15) / 16, (p->NEQ + 15) / 16);
     hipLaunchKernelGGL(fill_plain, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->NEQ, d_LHMAT, d_RHb);
+    LAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(s));
+    return SFFT_OK;
+}
+
+__global__ void iota_or_copy(const int* __restrict__ idx, int n, int* __restrict__ out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = idx ? idx[k] : k;
+}
+
+extern "C" int sfft_get_solver_system(sfft_plan* p, double* d_bordered, int* d_index, void* stream)
+{
+    if (!p || !d_bordered) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    if (!p->have_system) return set_err(SFFT_ERR_INVALID_ARG, "no linear system yet: call sfft_solve first");
+    hipStream_t s = (hipStream_t)stream;
+    ON_DEVICE(p->dev);
+    const int n = p->NEQfs;
+    dim3 g((n + 1 + 15) / 16, (n + 1 + 15) / 16);
+    // the launch of run_fill with the caller's buffer (leading dimension n + 1) in place of the solver's workspace, both triangles
+    hipLaunchKernelGGL(fill_system, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->d_idx, n, p->NEQ,
+                       d_bordered, n + 1, (double*)nullptr, 0);
+    if (d_index) hipLaunchKernelGGL(iota_or_copy, dim3((n + 255) / 256), dim3(256), 0, s, p->d_idx, n, d_index);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;

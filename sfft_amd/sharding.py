@@ -16,7 +16,8 @@ import torch.distributed as dist
 
 __all__ = ["shard_pair_ids", "pack_record", "gather_records", "run_shard", "STATUS_OK", "STATUS_SINGULAR", "STATUS_ERROR"]
 
-# per-pair status in the gathered record: the C ABI's return code of the pair's sfft_subtract (include/sfft_amd.h)
+# per-pair status in the gathered record: the C ABI's return code of the pair's sfft_subtract (include/sfft_amd.h):
+# 0 ok, -1 invalid argument, -2 unsupported size, -3 HIP error, -4 singular system, -5 out of memory
 STATUS_OK, STATUS_ERROR, STATUS_SINGULAR = 0, -1, -4
 
 
@@ -63,17 +64,22 @@ def run_shard(pair_ids, n_workers, work_fn, neq, device):
     reference's scheme (one thread per device queue taking tasks from a shared status table,
     sfft/MultiEasyCrowdedPacket.py:361-399, 698-710), with several queues on one GPU.
 
-    work_fn(worker_index, pair_id) -> Solution tensor [neq]; it raises on failure (numpy.linalg.LinAlgError for a singular
-    system, as the operators do).  A failed pair does not stop the shard: its record carries the status code and a zero
-    solution, and the worker's plan goes on to the next pair.  Returns one record per pair, in shard order."""
+    work_fn(worker_index, pair_id) -> Solution tensor [neq]; it raises on failure like the operators do:
+    numpy.linalg.LinAlgError for a singular system, _lib.SfftError (with the ABI's return code) for every other status of the
+    C ABI.  Such a pair does not stop the shard: its record carries the ABI's code and a zero solution, and the worker's plan
+    goes on to the next pair.  Anything else (TypeError, a bad index, torch's own errors ...) is a programming or device
+    error, not a per-pair failure: the workers stop taking pairs and the first such exception is re-raised here.
+    Returns one record per pair, in shard order."""
     import numpy as np
+    from ._lib import SfftError
     pair_ids = list(pair_ids)
     records = [None] * len(pair_ids)
     nxt = itertools.count()
     lock = threading.Lock()
+    fatal = []
 
     def worker(wi):
-        while True:
+        while not fatal:
             with lock:
                 k = next(nxt)
             if k >= len(pair_ids):
@@ -85,8 +91,11 @@ def run_shard(pair_ids, n_workers, work_fn, neq, device):
                 status = STATUS_OK
             except np.linalg.LinAlgError:
                 sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_SINGULAR
-            except Exception:
-                sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_ERROR
+            except SfftError as e:
+                sol, status = torch.zeros(neq, dtype=torch.float64, device=device), e.code
+            except BaseException as e:      # not a per-pair failure
+                fatal.append(e)
+                return
             records[k] = pack_record(pid, status, (time.perf_counter() - t0) * 1e3, sol)
 
     if n_workers <= 1:
@@ -95,4 +104,6 @@ def run_shard(pair_ids, n_workers, work_fn, neq, device):
         th = [threading.Thread(target=worker, args=(i,)) for i in range(n_workers)]
         [t.start() for t in th]
         [t.join() for t in th]
+    if fatal:
+        raise fatal[0]
     return records

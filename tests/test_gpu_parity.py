@@ -76,6 +76,17 @@ def test_linear_system_matches_reference(dev, name):
     LH, rhs = LH.cpu().numpy(), rhs.cpu().numpy()
     assert np.max(np.abs(LH - g["LHMAT"])) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
     assert np.max(np.abs(rhs - g["RHb"])) <= 1e-11 * np.max(np.abs(g["RHb"]))
+    # ... and the system the factorisation itself received (same fill_system launch, caller's buffer): the reference's
+    # LHMAT_FSfree / RHb_FSfree = LHMAT, RHb with the rows / columns ij00[1:] removed (Remove_LSFStripes, SFFTSubtract.py:386-394)
+    m = g["meta"]
+    A, b, idx = (t.cpu().numpy() for t in plan.get_solver_system())
+    L = 2 * m["KerHW"] + 1
+    Fij = (m["DK"] + 1) * (m["DK"] + 2) // 2
+    ij00 = np.arange(m["KerHW"] * L + m["KerHW"], Fij * L * L, L * L)
+    keep = np.setdiff1d(np.arange(g["LHMAT"].shape[0]), ij00[1:]) if bool(m["CPR"]) else np.arange(g["LHMAT"].shape[0])
+    assert np.array_equal(idx, keep)
+    assert np.max(np.abs(A - g["LHMAT"][np.ix_(keep, keep)])) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
+    assert np.max(np.abs(b - g["RHb"][keep])) <= 1e-11 * np.max(np.abs(g["RHb"]))
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -355,9 +366,14 @@ def test_baseline_size_one_tensor_as_both_images(dev, big):
     LH_a, rhs_a = plan.get_system()
     sol_b = plan.solve(I, I.clone())
     LH_b, rhs_b = plan.get_system()
-    assert torch.equal(LH_a, LH_b) and torch.equal(rhs_a, rhs_b)
-    assert torch.equal(sol_a, sol_b)
+    LH_a, LH_b, rhs_a, rhs_b = LH_a.cpu().numpy(), LH_b.cpu().numpy(), rhs_a.cpu().numpy(), rhs_b.cpu().numpy()
+    nk = plan.Fijab                       # the two moment routes sum in different orders: equal block by block to the usual 1e-11
+    for blk in (np.s_[:nk, :nk], np.s_[:nk, nk:], np.s_[nk:, nk:]):
+        assert np.abs(LH_a[blk] - LH_b[blk]).max() <= 1e-11 * np.abs(LH_b[blk]).max()
+    for blk in (np.s_[:nk], np.s_[nk:]):
+        assert np.abs(rhs_a[blk] - rhs_b[blk]).max() <= 1e-11 * np.abs(rhs_b[blk]).max()
     s = sol_a.cpu().numpy()
+    assert np.abs(s - sol_b.cpu().numpy()).max() <= 1e-5 * plan.N0 * plan.N1
     N = plan.N0
     expect = np.zeros(plan.NEQ)
     expect[8 * 17 + 8] = float(N * N)
@@ -658,6 +674,19 @@ def test_bspline_matches_reference(dev, name):
     LH, rhs = plan.get_system()
     assert np.max(np.abs(LH.cpu().numpy() - g["LHMAT"])) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
     assert np.max(np.abs(rhs.cpu().numpy() - g["RHb"])) <= 1e-11 * np.max(np.abs(g["RHb"]))
+    # the system the factorisation received: TweakLS of the reference (BSplineSFFT.py:2170-2338) -- polynomial kernels drop the
+    # ij00[1:] unknowns, B-spline kernels tie them to ij00[0] (rows and columns summed): P^T LHMAT P, P^T RHb
+    A, b, idx = (t.cpu().numpy() for t in plan.get_solver_system())
+    NEQ, Lk = m["NEQ"], 2 * m["w"] + 1
+    ij00_ = np.arange(m["w"] * Lk + m["w"], m["Fij"] * Lk * Lk, Lk * Lk)
+    keep = np.setdiff1d(np.arange(NEQ), ij00_[1:]) if bool(m["CPR"]) else np.arange(NEQ)
+    assert np.array_equal(idx, keep)
+    P = np.zeros((NEQ, len(keep)))
+    P[keep, np.arange(len(keep))] = 1.0
+    if bool(m["CPR"]) and m["KerSpType"] == "B-Spline":
+        P[ij00_[1:], int(np.where(keep == ij00_[0])[0][0])] = 1.0
+    assert np.max(np.abs(A - P.T @ g["LHMAT"] @ P)) <= 1e-11 * np.max(np.abs(g["LHMAT"]))
+    assert np.max(np.abs(b - P.T @ g["RHb"])) <= 1e-11 * np.max(np.abs(g["RHb"]))
     D = BESS.ESS(g["REF"], g["SCI"], cfg, SFFTSolution=g["Solution"], Subtract=True, VERBOSE_LEVEL=0)[1]
     assert rms(D - g["DIFF"]) <= 1e-10 * rms(g["SCI"])
     sol, D2, _ = BGSS.GSS(g["REF"], g["SCI"], g["mREF"], g["mSCI"], cfg, VERBOSE_LEVEL=0)

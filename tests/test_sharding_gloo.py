@@ -112,3 +112,25 @@ def test_two_rank_batch_with_uneven_shards_and_a_failed_pair(tmp_path):
         else:
             assert t0[pid, 1] == STATUS_OK and np.array_equal(t0[pid, 3:], _solve_pair(pid))
         assert t0[pid, 2] > 0.0              # measured milliseconds of that pair
+
+
+def test_run_shard_records_abi_codes_and_reraises_programming_errors():
+    """Per-pair failures are the operator's own (LinAlgError -> -4, _lib.SfftError -> its code); anything else stops the shard."""
+    from sfft_amd._lib import SfftError
+
+    def work(wi, pid):
+        if pid == 1:
+            raise SfftError(-3, "HIP error: out of memory")
+        if pid == 2:
+            raise np.linalg.LinAlgError("Singular matrix")
+        return torch.full((4,), float(pid), dtype=torch.float64)
+    recs = run_shard([0, 1, 2, 3], 2, work, 4, torch.device("cpu"))
+    assert [int(r[1]) for r in recs] == [0, -3, STATUS_SINGULAR, 0]
+    assert not recs[1][3:].any() and recs[3][3] == 3.0
+
+    def broken(wi, pid):
+        if pid == 2:
+            raise TypeError("not a per-pair failure")
+        return torch.zeros(4, dtype=torch.float64)
+    with pytest.raises(TypeError, match="not a per-pair failure"):
+        run_shard([0, 1, 2, 3, 4, 5], 2, broken, 4, torch.device("cpu"))
