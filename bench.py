@@ -324,6 +324,14 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             if not same:
                 rel = float(((fresh_d - diffs[k]).abs().max() / fresh_d.abs().max()).item())
                 post["max_rel_diff"] = max(post["max_rel_diff"], rel)
+                ds = (fresh_s - sols[k]).abs()
+                post.setdefault("solution_mismatch", []).append({"pair": my_ids[k], "entries": int((fresh_s != sols[k]).sum().item()),
+                                                                 "max_abs": float(ds.max().item()), "max_rel": float((ds.max() / fresh_s.abs().max()).item()),
+                                                                 "first_index": int(torch.nonzero(fresh_s != sols[k])[0].item()) if bool((fresh_s != sols[k]).any()) else -1,
+                                                                 "diff_entries": int((fresh_d != diffs[k]).sum().item()),
+                                                                 "where": torch.nonzero(fresh_s != sols[k]).reshape(-1)[:8].tolist(),
+                                                                 "fresh": fresh_s[fresh_s != sols[k]][:8].tolist(),
+                                                                 "pipelined": sols[k][fresh_s != sols[k]][:8].tolist()})
             assert bool(torch.isfinite(fresh_d).all()), "non-finite DIFF"
         n_iso = len(iso_ms)
     plans[0].set_timing(False)
@@ -390,7 +398,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         ab = alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed, theta_fused,
                        (plans[0].query("OMG_OFFDIAG"), plans[0].query("OMG_DIAG")), decimated, plans[0].query("G1_CHUNKS"))
         headline = (args.config == 2 and (N0, N1, w) == (4096, 4096, 8))
-        n_sys = plans[0].query("NEQ_FSfree")              # unknowns of the system that is factorised
+        n_sys = plans[0].query("SOLVER_N")              # unknowns of the system that is factorised
 
         pmc = {}
         try:   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json; see profiles/README.md)

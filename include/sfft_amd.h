@@ -54,6 +54,8 @@ enum {
     SFFT_Q_G1_CHUNKS,               /* row chunks of the Greek stage-1 launches: each writes one partial lag sum per pass, lag and spectrum column */
     SFFT_Q_G1_MFMA,                 /* 1: the Omega passes of this plan run on the matrix cores (lag half-width 9 .. 16), 0: on the vector kernel */
     SFFT_Q_CHOL_DATAFLOW,           /* 1: the Cholesky factorisation of this plan is the single-launch dataflow kernel, 0: the launch chain */
+    SFFT_Q_SOLVER_N,                /* unknowns of the system the factorisation receives (NEQ when nothing is removed or tied; NEQ_FSFREE is the
+                                       reference's dictionary entry, defined whether or not the stripes are removed) */
     SFFT_Q_COUNT
 };
 
@@ -143,7 +145,7 @@ int sfft_get_system(sfft_plan* plan, double* d_LHMAT, double* d_RHb, void* strea
 
 /* Parity aid: the system the factorisation actually receives for the most recent solve -- after Remove_LSFStripes
  * (SFFTConfigure.py:693-711) / TweakLS (BSplineSFFT.py:2170-2338), with the regularisation term added -- written by the same
- * kernel launch (`fill_system`) that fills the solver's workspace.  n = SFFT_Q_NEQ_FSFREE unknowns.
+ * kernel launch (`fill_system`) that fills the solver's workspace.  n = SFFT_Q_SOLVER_N unknowns.
  *   d_bordered [n+1][n+1] float64: rows / columns 0 .. n-1 the matrix, row n (and column n) the right-hand side, [n][n] = 0;
  *   d_index    [n] int32, may be NULL: position of reduced unknown k in the full Solution vector (identity when nothing was removed).
  * Synchronises. */

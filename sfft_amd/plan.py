@@ -121,7 +121,7 @@ class Plan:
     @_locked
     def get_solver_system(self):
         """(A [n][n], rhs [n], index [n]) of the reduced system the factorisation received (sfft_get_solver_system)."""
-        n = self.query("NEQ_FSfree")
+        n = self.query("SOLVER_N")
         B = torch.empty((n + 1, n + 1), dtype=torch.float64, device=self._dev())
         idx = torch.empty(n, dtype=torch.int32, device=self._dev())
         _lib.check(_lib.lib().sfft_get_solver_system(self._h, B.data_ptr(), idx.data_ptr(), self._stream_ptr(self._dev())))
