@@ -7,7 +7,7 @@ import ctypes
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libsfft_amd.so")
+LIB_PATH = os.environ.get("SFFT_AMD_LIB") or os.path.join(PKG_DIR, "libsfft_amd.so")     # (override: A/B builds of the same sources)
 
 # error codes / query fields / stage ids: keep in sync with include/sfft_amd.h
 SFFT_OK = 0

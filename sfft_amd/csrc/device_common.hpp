@@ -22,6 +22,47 @@ struct SpecLayout {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
+// Streaming accesses of the transform passes (planes far larger than the L2, written once / read once): SFFT_NT bit 0 = non-temporal
+// loads, bit 1 = non-temporal stores (a plain 16-byte copy gains 5 - 9 % from both on this device, scripts/micro/hbm_stream2.hip).
+#ifndef SFFT_NT
+#define SFFT_NT 0
+#endif
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(cplx* p, cplx z)
+{
+#if SFFT_NT & 2
+    v2d_t v = {z.x, z.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_t*>(p));
+#else
+    *p = z;
+#endif
+}
+__device__ __forceinline__ void st_stream(double* p, double z)
+{
+#if SFFT_NT & 2
+    __builtin_nontemporal_store(z, p);
+#else
+    *p = z;
+#endif
+}
+__device__ __forceinline__ cplx ld_stream(const cplx* p)
+{
+#if SFFT_NT & 1
+    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double ld_stream(const double* p)
+{
+#if SFFT_NT & 1
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ cplx cmulc(cplx a, cplx b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
 __device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
@@ -408,10 +449,144 @@ __device__ __forceinline__ void lds_fft_mixed(cplx* s, int M, int log2p, int n3,
     for (int l = 0; l < n3; ++l) { lds_stage_mixed<3>(s, M, p, nb, stride, tw); p *= 3; }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Prime-length sub-transform of a four-step axis by Rader's algorithm (config 5's 9232 = 16 x 577 column axis): with g a primitive
+// root mod N, a[r] = x[g^r] and b[t] = W_N^(g^-t), X[g^-q] = x[0] + (a (*) b)[q] -- a cyclic convolution of length N - 1 = 576 =
+// 16 * 4 * 9 -- and X[0] = x[0] + sum a.  Two 576-point transforms instead of Bluestein's two 2048-point ones, a third of the LDS
+// per sequence (eight sequences per workgroup instead of two: 128 contiguous bytes per row instead of 32).
+// The 576-point transform is a Stockham autosort with COMPILE-TIME radices (16, 4, 9), so that the index arithmetic of every stage
+// divides by constants; intermediate stages use the padded layout of lds_fft_r16, first read and last write are in natural order.
+// POST on the last stage's output k: 1: conj(X[k] * post[k]) (the next forward transform then inverts), 3: conj(X[k]).
+// ------------------------------------------------------------------------------------------------------------------------
+// forward 9-point DFT, outputs in natural order
+__device__ __forceinline__ void dft9(const cplx (&x)[9], cplx (&X)[9])
+{
+    const double S3 = 0.86602540378443864676;
+    const cplx w1 = make_double2(0.76604444311897803520, -0.64278760968653932632);      // W9^1
+    const cplx w2 = make_double2(0.17364817766693034885, -0.98480775301220805937);      // W9^2
+    const cplx w4 = make_double2(-0.93969262078590838405, -0.34202014332566873304);     // W9^4
+    cplx t[3][3];                                        // t[n2][k1] = DFT3 over n1 of x[3 n1 + n2]
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) {
+        const cplx u0 = x[n2], u1 = x[3 + n2], u2 = x[6 + n2];
+        const cplx a = cadd(u1, u2), d = csub(u1, u2);
+        const cplx m = make_double2(u0.x - 0.5 * a.x, u0.y - 0.5 * a.y);
+        t[n2][0] = cadd(u0, a);
+        t[n2][1] = make_double2(m.x + S3 * d.y, m.y - S3 * d.x);
+        t[n2][2] = make_double2(m.x - S3 * d.y, m.y + S3 * d.x);
+    }
+    t[1][1] = cmul(t[1][1], w1); t[1][2] = cmul(t[1][2], w2);
+    t[2][1] = cmul(t[2][1], w2); t[2][2] = cmul(t[2][2], w4);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {                     // X[k1 + 3 k2] = DFT3 over n2 of t[n2][k1]
+        const cplx u0 = t[0][k1], u1 = t[1][k1], u2 = t[2][k1];
+        const cplx a = cadd(u1, u2), d = csub(u1, u2);
+        const cplx m = make_double2(u0.x - 0.5 * a.x, u0.y - 0.5 * a.y);
+        X[k1] = cadd(u0, a);
+        X[k1 + 3] = make_double2(m.x + S3 * d.y, m.y - S3 * d.x);
+        X[k1 + 6] = make_double2(m.x - S3 * d.y, m.y + S3 * d.x);
+    }
+}
+
+// one Stockham stage of radix R on nb sequences of length M; P = product of the earlier radices.  nb * M <= 16 * blockDim.x.
+template <int M, int R, int P, bool FIRST, bool LAST, int POST>
+__device__ __forceinline__ void ct_stage(cplx* s, int nb, int stride, const cplx* __restrict__ tw, const cplx* __restrict__ post)
+{
+    constexpr int T = M / R, IT = (16 + R - 1) / R, STEP = T / P;
+    const int tid = threadIdx.x, nt = blockDim.x, total = nb * T;
+    // nb is a power of two and the SEQUENCE index runs fastest over the threads: the nb lanes that work on the same butterfly of
+    // different sequences read the same twiddle / filter entries (one cache line per nb lanes instead of one per lane)
+    const int lnb = __builtin_ctz(nb);
+    cplx y[IT][R];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g & (nb - 1), i = g >> lnb, k = i % P;
+            const cplx* b = s + f * stride;
+            cplx u[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = FIRST ? b[i + r * T] : b[pad16(i + r * T)];
+            if (P > 1) {
+                const int q = k * STEP;
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[q * r]);
+            }
+            if constexpr (R == 16) {
+                cplx v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = u[r];
+                dft16(v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[it][r] = v[R16_OUT(r)];
+            } else if constexpr (R == 4) {
+                dft4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[it][r] = u[r];
+            } else {
+                dft9(u, y[it]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int g = tid + it * nt;
+        if (g < total) {
+            const int f = g & (nb - 1), i = g >> lnb, k = i % P;
+            cplx* b = s + f * stride;
+            const int o = (i - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                cplx v = y[it][r];
+                const int kk = o + r * P;
+                if (LAST) {
+                    if (POST == 1) v = cconj(cmul(v, post[kk]));
+                    if (POST == 3) v = cconj(v);
+                    b[kk] = v;
+                } else b[pad16(kk)] = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int POST>
+__device__ __forceinline__ void ct_fft576(cplx* s, int nb, int stride, const cplx* __restrict__ tw, const cplx* __restrict__ post)
+{
+    ct_stage<576, 16, 1, true, false, 0>(s, nb, stride, tw, nullptr);
+    ct_stage<576, 4, 16, false, false, 0>(s, nb, stride, tw, nullptr);
+    ct_stage<576, 9, 64, false, true, POST>(s, nb, stride, tw, post);
+}
+
+#define RADER_M 576
+#define RADER_XS (RADER_M + RADER_M / 16)            // slot of x[0] / X[0] behind the padded transform region: a sequence needs RADER_XS + 1 elements
+// 577-point DFT of nb sequences (nb a power of two) by Rader's algorithm, in LDS.  The caller's load phase has already put the
+// sequence in Rader order -- a[r] = x[g^r] at s[r], r < 576, and x[0] at s[RADER_XS] (it stores element n at s[rin[n]]) -- and its store
+// phase reads output n from s[rout[n]]: c[q] = X[g^-q] at s[q], X[0] at s[RADER_XS].  No permutation passes over LDS.
+// bf = FFT_576(b) / 576 with b[t] = W_N^(g^-t) and bf[0] = -1 / 576 exactly.
+__device__ __forceinline__ void lds_rader577(cplx* s, int nb, int stride, const cplx* __restrict__ tw, const cplx* __restrict__ bf)
+{
+    constexpr int M = RADER_M;
+    const int tid = threadIdx.x;
+    ct_fft576<1>(s, nb, stride, tw, bf);             // s[k] = conj(A[k] bf[k])
+    if (tid < nb) {
+        const cplx x0 = s[tid * stride + RADER_XS];
+        const cplx t = s[tid * stride];              // conj(A[0] bf[0]) = -conj(A[0]) / M
+        s[tid * stride + RADER_XS] = make_double2(x0.x - (double)M * t.x, x0.y + (double)M * t.y);       // X[0] = x[0] + A[0]
+        s[tid * stride] = make_double2(t.x + x0.x, t.y - x0.y);                                          // + x[0] on every c[q]
+    }
+    __syncthreads();
+    ct_fft576<3>(s, nb, stride, tw, nullptr);        // s[q] = x[0] + (a (*) b)[q]
+}
+
 // One 1-D axis: length N transformed either directly (N = M power of two) or by Bluestein's chirp-z
 // (M = power of two >= 2N-1), or directly with N = M = 2^logM * 3^n3.  All tables live in device memory.
 struct AxisDev {
     int N, M, logM, blue, n3, r16;     // r16: power-of-two M >= 16 on the radix-16 stages (sequence needs M + M/16 LDS elements)
+    int rader;                         // 1: N = 577 by Rader's algorithm (M = 576; bf, rin, rout below)
+    const int* rin;     // [N]   LDS slot of input element n: r with g^r = n (mod N); RADER_XS for n = 0
+    const int* rout;    // [N]   LDS slot of output element n: q with g^-q = n (mod N); RADER_XS for n = 0
     const cplx* tw;     // [M]   exp(-2 pi i k / M)
     const cplx* chirp;  // [N]   exp(-i pi n^2 / N)            (Bluestein only)
     const cplx* bf;     // [M]   FFT_M(conj-chirp filter) / M  (Bluestein only)
@@ -429,6 +604,7 @@ __device__ __forceinline__ void lds_fft_pow2(cplx* s, const AxisDev& ax, int nb,
 __device__ __forceinline__ void lds_dft(cplx* s, const AxisDev& ax, int nb, int stride)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
+    // (Rader sub-axes never come through here: strided_rader577 loads and stores in Rader order itself)
     if (ax.n3 && !ax.blue) {
         if (ax.r16) lds_fft_r16<false, 0>(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw, nullptr, 0, nullptr, 0);
         else lds_fft_mixed(s, ax.M, ax.logM, ax.n3, nb, stride, ax.tw);

@@ -16,6 +16,8 @@ struct PassDesc {
     int twiddle, N;                        // multiply output k of sequence j by rootN[(j k) mod N]
     int conj_in, conj_out;
     double scale;
+    const double* w;                       // optional real weight of input element (j, e): w[j * w_js + e * w_es] (the row factor of a staged
+    int w_js, w_es;                        //   forward column pass: the transform reads a stage plane and applies kbx[i][row] on the way in)
 };
 
 __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) strided_dft(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax,
@@ -24,7 +26,7 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) strided_dft(const cplx* 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* s = reinterpret_cast<cplx*>(smem_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int M = ax.M;
+    const int M = ax.rader ? ax.N : ax.M;            // tile extent per sequence (Rader transforms N points on M = N - 1)
     {   // at most 16 elements per thread (the block has >= TC * M / 16 threads): every load is issued before the first use
         cplx zz[16];
 #pragma unroll
@@ -36,6 +38,7 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) strided_dft(const cplx* 
             const int line = (d.mode == 2) ? (int)blockIdx.x * TC + c : (int)blockIdx.y;
             const bool ok = x < TC * M && e < d.len && j < d.J && line < d.nlines;
             zz[it] = ok ? in[(long long)line * d.lst_in + (long long)j * d.js_in + (long long)e * d.es_in] : make_double2(0.0, 0.0);
+            if (d.w) { const double f = ok ? d.w[j * d.w_js + e * d.w_es] : 0.0; zz[it].x *= f; zz[it].y *= f; }
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -57,6 +60,56 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) strided_dft(const cplx* 
             if (d.twiddle) z = cmul(z, rootN[(int)(((long long)j * e) % d.N)]);
             if (d.conj_out) z.y = -z.y;
             out[(long long)line * d.lst_out + (long long)j * d.js_out + (long long)e * d.es_out] = make_double2(z.x * d.scale, z.y * d.scale);
+        }
+    }
+}
+
+// The same pass for a Rader sub-axis (N = 577, config 5's 9232 = 16 x 577 column axis), lines fastest (mode 2): a kernel of its own so that
+// the compiler sees one transform, not every path of lds_dft (strided_dft is 52 k instructions and sits at its register cap).
+// RADER_TC lines (columns) x 577 elements per workgroup: each row of the tile is RADER_TC x 16 contiguous bytes.
+// Measured per 9232 x 4609 plane: 8 lines x 320 threads (80 KB, two workgroups per CU) 737 us; 4 lines x 192 threads (40 KB, four per
+// CU) 455 us; 4 x 256 threads 480 us.  (The same pass without its two transforms: 318 us; Bluestein on 2048 points: 1378 us.)
+#ifndef RADER_TC
+#define RADER_TC 4
+#define RADER_NT 192
+#endif
+#define RADER_LTC (RADER_TC == 8 ? 3 : RADER_TC == 4 ? 2 : 4)
+static_assert(RADER_TC * (RADER_M + 1) <= 15 * RADER_NT && RADER_TC * RADER_M <= 16 * RADER_NT, "Rader tile: at most 15 elements per thread");
+__global__ void __launch_bounds__(RADER_NT) strided_rader577(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax, int MS)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* s = reinterpret_cast<cplx*>(smem_raw);
+    constexpr int N = RADER_M + 1, TC = RADER_TC, TOT = TC * N;
+    const int tid = threadIdx.x;
+    const int j = (int)blockIdx.y;
+    const long long base_in = (long long)j * d.js_in, base_out = (long long)j * d.js_out;
+    {
+        cplx zz[15];                                 // RADER_TC x 577 elements over RADER_NT threads: at most 15 each
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int x = min(tid + it * RADER_NT, TOT - 1);
+            const int e = x >> RADER_LTC, c = x & (TC - 1);
+            const int line = min((int)blockIdx.x * TC + c, d.nlines - 1);
+            zz[it] = in[(long long)line * d.lst_in + base_in + (long long)e * d.es_in];
+        }
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int x = tid + it * RADER_NT;
+            const int e = x >> RADER_LTC, c = x & (TC - 1);
+            if (x < TOT) s[c * MS + ax.rin[e]] = d.conj_in ? cconj(zz[it]) : zz[it];
+        }
+    }
+    __syncthreads();
+    lds_rader577(s, TC, MS, ax.tw, ax.bf);
+#pragma unroll
+    for (int it = 0; it < 15; ++it) {
+        const int x = tid + it * RADER_NT;
+        const int e = x >> RADER_LTC, c = x & (TC - 1);
+        const int line = (int)blockIdx.x * TC + c;
+        if (x < TOT && line < d.nlines) {
+            cplx z = s[c * MS + ax.rout[e]];
+            if (d.conj_out) z.y = -z.y;
+            out[(long long)line * d.lst_out + base_out + (long long)e * d.es_out] = make_double2(z.x * d.scale, z.y * d.scale);
         }
     }
 }

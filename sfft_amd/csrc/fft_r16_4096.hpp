@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256, 2) rows_r2c_4096(RowsArgs a, RowGroups gr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = j + 256 * r;
-        x0[r] = r0p[n];
-        x1[r] = r1p[n] * h1;
+        x0[r] = ld_stream(r0p + n);
+        x1[r] = ld_stream(r1p + n) * h1;
     }
     const int mnq = grp.mom_nq[blockIdx.y];
     if (mnq > 0) {                          // (workgroup uniform)
@@ -135,8 +135,8 @@ __global__ void __launch_bounds__(256, 2) rows_r2c_4096(RowsArgs a, RowGroups gr
                 const cplx zp = lds[(N1 - m) & (N1 - 1)];
                 const cplx zc = make_double2(zp.x, -zp.y);
                 const size_t mo = lay.col(m);
-                o0[mo] = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y));
-                if (has1) o1[mo] = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+                st_stream(o0 + mo, make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y)));
+                if (has1) st_stream(o1 + mo, make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x)));
             }
         }
     }
@@ -252,8 +252,8 @@ __global__ void __launch_bounds__(512) cols_fwd_weighted_4096_q(const cplx* __re
         double f[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            la[r] = src[(size_t)(rowA + 256 * (8 * hb + r)) * 4];
-            lb[r] = src[(size_t)(rowA + 1 + 256 * (8 * hb + r)) * 4];
+            la[r] = ld_stream(src + (size_t)(rowA + 256 * (8 * hb + r)) * 4);
+            lb[r] = ld_stream(src + (size_t)(rowA + 1 + 256 * (8 * hb + r)) * 4);
             f[r] = w[j + 256 * (8 * hb + r)];
         }
 #pragma unroll
@@ -274,8 +274,8 @@ __global__ void __launch_bounds__(512) cols_fwd_weighted_4096_q(const cplx* __re
     for (int sx = 0; sx < 16; ++sx) {
         const cplx o1 = u1[R16_OUT(sx)], o2 = u2[R16_OUT(sx)];
         const cplx got = dpp_swap2(csel(even, o2, o1));
-        dst[(size_t)(rowA + 256 * sx) * 4] = csel(even, o1, got);
-        dst[(size_t)(rowA + 1 + 256 * sx) * 4] = csel(even, got, o2);
+        st_stream(dst + (size_t)(rowA + 256 * sx) * 4, csel(even, o1, got));
+        st_stream(dst + (size_t)(rowA + 1 + 256 * sx) * 4, csel(even, got, o2));
     }
 }
 
@@ -300,8 +300,8 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
         const bool mir = m > N1 / 2;
         const int mm = mir ? N1 - m : m;
         const size_t mo = lay.col(mm);
-        cplx x0 = f0[mo];
-        cplx x1 = has1 ? f1[mo] : make_double2(0.0, 0.0);
+        cplx x0 = ld_stream(f0 + mo);
+        cplx x1 = has1 ? ld_stream(f1 + mo) : make_double2(0.0, 0.0);
         if (mm == 0 || mm == N1 / 2) { x0.y = 0.0; x1.y = 0.0; }
         if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
         u[r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
 #pragma unroll
         for (int e = 0; e < BS; ++e) {
             const int n = j + 256 * (b0 + e);
-            jv0[e] = j0[n];
-            jv1[e] = j1[n];
+            jv0[e] = ld_stream(j0 + n);
+            jv1[e] = ld_stream(j1 + n);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) tb[e][q] = bk.tby[(size_t)min(q, bk.nq - 1) * N1 + n];      // clamped: always valid
         }
@@ -341,8 +341,8 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
                 B0 = fma(on ? c0[q] : 0.0, tb[e][q], B0);
                 B1 = fma(on ? c1[q] : 0.0, tb[e][q], B1);
             }
-            d0[n] = jv0[e] - B0 - z.x;
-            if (has1) d1[n] = jv1[e] - B1 + z.y;
+            st_stream(d0 + n, jv0[e] - B0 - z.x);
+            if (has1) st_stream(d1 + n, jv1[e] - B1 + z.y);
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -89,6 +89,8 @@ struct AxisHost {
     int N = 0, M = 0, logM = 0, blue = 0, n3 = 0;   // n3 > 0: M = N = 2^logM * 3^n3 (mixed-radix on-chip transform)
     cplx *tw = nullptr, *chirp = nullptr, *bf = nullptr, *root = nullptr;
     bool root_is_tw = false;
+    int rader = 0;                                  // N = 577 as a four-step sub-transform: Rader's algorithm on M = 576 points (lds_rader577)
+    int *rin = nullptr, *rout = nullptr;            // [N] each: LDS slot of input / output element n in Rader order
     // four-step decomposition for lengths that do not fit one on-chip transform: N = A * B
     bool big = false;
     int A = 0, B = 0;
@@ -353,7 +355,8 @@ static bool fits_on_chip(int N)
     return bluestein_len(N) != 0;
 }
 
-static int build_axis(sfft_plan* p, AxisHost& ax, int N);
+static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis = false);
+static bool rader_ok(int N) { return N == RADER_M + 1 && !getenv("SFFT_NO_RADER") && !getenv("SFFT_NO_R16"); }
 
 // N = A * B with A the largest power-of-two factor (<= 4096) such that B fits on chip too
 static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
@@ -364,6 +367,7 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
     auto cost = [](int len) {
         int e2, e3;
         if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return 1.0;
+        if (rader_ok(len)) return 2.5;               // two transforms of len - 1 points and two permutation passes
         return 4.0 * bluestein_len(len) / len;
     };
     int A = 0, B = 0;
@@ -382,8 +386,8 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
     ax.N = N; ax.big = true; ax.A = A; ax.B = B; ax.M = 0; ax.logM = 0; ax.blue = 0;
     ax.subA = new AxisHost(); ax.subB = new AxisHost();
     int rc;
-    if ((rc = build_axis(p, *ax.subA, A))) return rc;
-    if ((rc = build_axis(p, *ax.subB, B))) return rc;
+    if ((rc = build_axis(p, *ax.subA, A, true))) return rc;
+    if ((rc = build_axis(p, *ax.subB, B, true))) return rc;
     std::vector<cplx> r(N);
     for (int k = 0; k < N; ++k) {
         const long double ang = -2.0L * PI * k / N;
@@ -394,10 +398,58 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
     return SFFT_OK;
 }
 
-static int build_axis(sfft_plan* p, AxisHost& ax, int N)
+// Rader tables of a prime N whose N - 1 = RADER_M (only strided_dft, the four-step kernel, sizes its tiles for M < N)
+static int build_rader_axis(sfft_plan* p, AxisHost& ax, int N)
+{
+    const long double PI = acosl(-1.0L);
+    const int M = N - 1;
+    ax.N = N; ax.M = M; ax.blue = 0; ax.rader = 1; ax.n3 = 0; ax.logM = 0; ax.r16 = 1;       // (r16: padded LDS layout, M + M/16 elements)
+    auto powmod = [&](long long b, long long e) { long long r = 1; b %= N; while (e) { if (e & 1) r = r * b % N; b = b * b % N; e >>= 1; } return r; };
+    int g = 0;
+    for (int c = 2; c < N && !g; ++c) {             // smallest primitive root: c^((N-1)/q) != 1 for every prime q | N - 1
+        bool ok = true;
+        int m = M;
+        for (int q = 2; q <= m && ok; ++q)
+            if (m % q == 0) { if (powmod(c, M / q) == 1) ok = false; while (m % q == 0) m /= q; }
+        if (ok) g = c;
+    }
+    if (!g) return set_err(SFFT_ERR_INVALID_ARG, "Rader: length is not prime");
+    const long long ginv = powmod(g, N - 2);
+    std::vector<int> rin(N, 0), rout(N, 0);         // LDS slots of input / output element n (strided_rader577)
+    std::vector<long double> br(M), bi(M);
+    for (int r = 0; r < M; ++r) rin[(int)powmod(g, r)] = r;
+    rin[0] = RADER_XS; rout[0] = RADER_XS;
+    for (int q = 0; q < M; ++q) {
+        const int n = (int)powmod(ginv, q);
+        rout[n] = q;
+        const long double ang = -2.0L * PI * n / N;   // b[q] = W_N^(g^-q)
+        br[q] = cosl(ang); bi[q] = sinl(ang);
+    }
+    host_fft_23(br, bi);
+    std::vector<cplx> bf(M), tw(M), root(N);
+    for (int k = 0; k < M; ++k) {
+        bf[k] = make_double2((double)(br[k] / M), (double)(bi[k] / M));
+        const long double ang = -2.0L * PI * k / M;
+        tw[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    bf[0] = make_double2(-1.0 / M, 0.0);            // sum of the non-trivial N-th roots of unity: lds_rader577 reads A[0] back through it
+    for (int k = 0; k < N; ++k) { const long double ang = -2.0L * PI * k / N; root[k] = make_double2((double)cosl(ang), (double)sinl(ang)); }
+    int rc;
+    if ((rc = dev_alloc(p, &ax.tw, M)) || (rc = dev_alloc(p, &ax.bf, M)) || (rc = dev_alloc(p, &ax.root, N)) ||
+        (rc = dev_alloc(p, &ax.rin, N)) || (rc = dev_alloc(p, &ax.rout, N))) return rc;
+    HIPCHK(hipMemcpy(ax.tw, tw.data(), M * sizeof(cplx), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ax.bf, bf.data(), M * sizeof(cplx), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ax.root, root.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ax.rin, rin.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ax.rout, rout.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    return SFFT_OK;
+}
+
+static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis)
 {
     const long double PI = acosl(-1.0L);
     if (!fits_on_chip(N)) return build_big_axis(p, ax, N);
+    if (sub_axis && rader_ok(N)) return build_rader_axis(p, ax, N);
     ax.N = N;
     int e2 = 0, e3 = 0;
     if (is_pow2(N)) { ax.M = N; ax.blue = 0; }
@@ -445,7 +497,7 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N)
 }
 
 // LDS elements one sequence of this axis needs
-static int axis_lds_len(const AxisHost& a) { return a.r16 ? a.M + a.M / 16 : a.M; }
+static int axis_lds_len(const AxisHost& a) { return a.rader ? RADER_XS + 1 : a.r16 ? a.M + a.M / 16 : a.M; }
 
 // threads of an on-chip FFT workgroup over `elems` LDS elements: one radix-16 butterfly each, whole waves
 static int fft_threads(int elems) { return std::min(SFFT_FFT_MAX_THREADS, ((elems + 15) / 16 + 63) / 64 * 64); }
@@ -466,6 +518,7 @@ static void pick_col_tile(const AxisHost& a, int* TC, int* MS, size_t budget = 0
 static AxisDev axis_dev(const AxisHost& a)
 {
     AxisDev d; d.N = a.N; d.M = a.M; d.logM = a.logM; d.blue = a.blue; d.n3 = a.n3; d.r16 = a.r16; d.tw = a.tw; d.chirp = a.chirp; d.bf = a.bf; d.root = a.root;
+    d.rader = a.rader; d.rin = a.rin; d.rout = a.rout;
     return d;
 }
 
@@ -651,6 +704,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->lds_cols = (size_t)p->TC * p->MS * sizeof(cplx);
     }
     PLAN_HIP(hipFuncSetAttribute((const void*)strided_dft, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)strided_rader577, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (p->ax1.big) {          // two packed-row work arrays [ceil(N0/2)][N1]
         PLAN_TRY(dev_alloc(p, &p->d_big1, (size_t)((N0 + 1) / 2) * N1));
         PLAN_TRY(dev_alloc(p, &p->d_big2, (size_t)((N0 + 1) / 2) * N1));
@@ -1162,7 +1216,9 @@ static void free_axis(AxisHost& a)
     if (!a.root_is_tw) dev_free(a.root);
     dev_free(a.chirp);
     dev_free(a.bf);
+    dev_free(a.rin); dev_free(a.rout);
     a.tw = a.root = a.chirp = a.bf = nullptr;
+    a.rin = a.rout = nullptr;
 }
 
 extern "C" int sfft_plan_destroy(sfft_plan* p)
@@ -1259,7 +1315,15 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
     // Bluestein sub-transforms run two passes over the tile with barriers throughout: two workgroups per CU (half the LDS each)
     // hide more than a wider tile gains (9232-point columns: 22.4 -> 20.1 ms for 11 planes)
     pick_col_tile(sub, &TC, &MS, sub.blue ? std::min((size_t)4800, (size_t)LDS_COL_ELEMS) : 0);
-    const int nt = fft_threads(TC * sub.M);
+    if (sub.rader) {                                // RADER_TC sequences of RADER_XS + 1 elements (fft_fourstep.hpp)
+        TC = RADER_TC; MS = (RADER_XS + 1 + 15) / 16 * 16 + 16 / TC;
+        if (d.mode == 2 && !d.twiddle) {            // (the second pass of a column transform: its own kernel)
+            hipLaunchKernelGGL(strided_rader577, dim3((d.nlines + TC - 1) / TC, d.J), dim3(RADER_NT), (size_t)TC * MS * sizeof(cplx), s, in, out, d,
+                               axis_dev(sub), MS);
+            return;
+        }
+    }
+    const int nt = fft_threads(TC * (sub.rader ? sub.N : sub.M));
     const int ngroups = (d.mode == 2) ? (d.nlines + TC - 1) / TC : (d.J + TC - 1) / TC;
     const int gy = (d.mode == 2) ? d.J : d.nlines;
     hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, ilog2(TC), MS);
@@ -1267,15 +1331,18 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
 
 // four-step transform of `nlines` lines of length ax.N; element stride st, line stride lst (complex elements).
 // Result lands in `data` again (scr is a same-shaped scratch).  inverse: e^{+i} (conjugation on the way in and out).
+// src / wrow (optional): read the input from another plane of the same shape and multiply input element (row) by wrow[row] -- the
+// weighted forward column pass of the staged transforms (columns only: the element index is the row).
 static void big_axis_transform(sfft_plan* p, const AxisHost& ax, cplx* data, cplx* scr, long long st, long long lst, int nlines,
-                               bool lines_fastest, int inverse, hipStream_t s)
+                               bool lines_fastest, int inverse, hipStream_t s, const cplx* src = nullptr, const double* wrow = nullptr)
 {
     PassDesc d1; memset(&d1, 0, sizeof(d1));
+    d1.w = wrow; d1.w_js = 1; d1.w_es = ax.B;
     d1.len = ax.A; d1.J = ax.B; d1.nlines = nlines; d1.mode = lines_fastest ? 2 : 1;
     d1.js_in = st; d1.es_in = (long long)ax.B * st; d1.lst_in = lst;
     d1.js_out = d1.js_in; d1.es_out = d1.es_in; d1.lst_out = lst;
     d1.twiddle = 1; d1.N = ax.N; d1.conj_in = inverse; d1.conj_out = 0; d1.scale = 1.0;
-    launch_pass(p, data, scr, d1, *ax.subA, ax.root, s);
+    launch_pass(p, src ? src : data, scr, d1, *ax.subA, ax.root, s);
     PassDesc d2; memset(&d2, 0, sizeof(d2));
     d2.len = ax.B; d2.J = ax.A; d2.nlines = nlines; d2.mode = lines_fastest ? 2 : 0;
     d2.js_in = (long long)ax.B * st; d2.es_in = st; d2.lst_in = lst;
@@ -1387,6 +1454,17 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             if (rc) return rc;
         }
         if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
+        if (p->ax0.big) {
+            // four-step column axis: every output plane is the transform of its stage plane times the row factor, applied as the first
+            // pass reads the stage plane (same traffic as transforming a finished plane; the row pass ran once per column factor)
+            for (int k = 0; k < nst; ++k)
+                for (const Out& o : stages[k].outs)
+                    big_axis_transform(p, p->ax0, dst + (size_t)o.plane * plane_sz, p->d_colscr, p->Nhp, 1, p->Nh, true, 0, s,
+                                       p->d_stage + (size_t)k * plane_sz, o.wx == p->d_ones ? nullptr : o.wx);
+            LAUNCH_CHECK();
+            if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
+            return SFFT_OK;
+        }
         const int G = p->TC >= 8 ? 1 : 8 / p->TC;
         const int ntiles = (p->Nh + p->TC - 1) / p->TC;
         const int ntg = (ntiles + 8 * G - 1) / (8 * G);           // tile groups per XCD
@@ -1486,8 +1564,8 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
 static int forward_basis_planes(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca = false,
                                 int st_rows = -1, int st_cols = -1)
 {
-    // staged: one row transform per distinct column factor.  Needs an on-chip column pass; pays when planes share factors
-    if (!p->no_staged && !p->ax0.big)
+    // staged: one row transform per distinct column factor (the column pass applies the row factor); pays when planes share factors
+    if (!p->no_staged)
         return forward_basis_planes_staged(p, d_I, d_J, dst, s, with_sca, st_rows, st_cols);
     const int total = p->Fij + (d_J ? 1 : 0) + ((with_sca && d_J) ? p->nsca : 0);
     const size_t plane_sz = (size_t)p->N0 * p->Nhp;
