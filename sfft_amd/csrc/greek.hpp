@@ -559,12 +559,15 @@ struct G1Group {
 // before -- for twice the rows.  Lag groups are then {2,4,6,8}, {10,..,16} on Ye and {1,3,5,7}, {9,..,15} on Yo; lane n loads the
 // twiddle of the lag its 4-lane group needs, so the ds_swizzle gather of the A operands is unchanged.  A chunk is rows_per_chunk / 2
 // rows x' and their partners.
-template <bool MASK, bool DIT = false>
+// lag0 / HALF (lag half-widths 17 .. 32, e.g. KerHW 12: h = 24): a launch covers the 16 lags lag0 + 1 .. lag0 + 16 (lag0 = 0 or 16; the lag-0
+// sums belong to the first launch); HALF = true (DIT only) issues just the lag groups lag0 + {2,4,6,8} and lag0 + {1,3,5,7} -- the second
+// launch of h <= 24 needs no others -- i.e. half the matrix instructions of a step.
+template <bool MASK, bool DIT = false, bool HALF = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
                                                         const G1Group* __restrict__ groups, int ngroup,
                                                         cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
                                                         int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S,
-                                                        unsigned long long* __restrict__ trace)
+                                                        unsigned long long* __restrict__ trace, int lag0)
 {
     const unsigned long long t_start = trace ? wall_clock64() : 0ULL;      // (SFFT_G1_TRACE: start / end stamp and XCD of every wave)
     const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
@@ -583,7 +586,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     const bool d0 = use0 && passes[k0].dual != 0;
     const int h = passes[k0].h, PH = 2 * h + 1;
     const int lb = DIT ? chunk * (rows_per_chunk / 2) : chunk * rows_per_chunk;
-    const int le = DIT ? lb + rows_per_chunk / 2 : min(N0, lb + rows_per_chunk);
+    const int le = DIT ? min(N0 / 2, lb + rows_per_chunk / 2) : min(N0, lb + rows_per_chunk);      // (DIT: the last chunk may be shorter, always whole 8-row steps)
     const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
     const int m = m0 + n;
     const bool act = m < Nh;
@@ -593,7 +596,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
     const char* __restrict__ P2 = reinterpret_cast<const char*>(spec + (size_t)gr.plane[2] * plane_sz);
     // lag whose twiddle this lane loads: plain = n + 1 (group g = lags 4 g + 1 .. 4 g + 4); DIT = groups {2,4,6,8}, {10,..,16}, {1,3,5,7}, {9,..,15}
     const int dlag = (n < 8) ? 8 * (n >> 2) + 2 * ((n & 3) + 1) : 8 * ((n >> 2) - 2) + 2 * (n & 3) + 1;
-    const int tcol = min(DIT ? dlag : 1 + n, HM - 1);
+    const int tcol = min(lag0 + (DIT ? dlag : 1 + n), HM - 1);
     const char* __restrict__ Wb = reinterpret_cast<const char*>(W0tab) + (size_t)tcol * sizeof(cplx);
     const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
     const unsigned rlast = (unsigned)(N0 - 1);
@@ -659,6 +662,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
                 g0y[sl] += Ye.y;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
+                    if (HALF && (gq & 1)) continue;
                     const double bx = gq < 2 ? Ye.x : Yo.x, by = gq < 2 ? Ye.y : Yo.y;
                     Sx[sl][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], bx, Sx[sl][0][gq], 0, 0, 0);
                     Sx[sl][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], by, Sx[sl][1][gq], 0, 0, 0);
@@ -745,10 +749,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         cplx* g = Gp + gp_off + (size_t)chunk * PH * Nhp;
         if (dual) {     // two real, even sequences: G(+-r) = S1 +- i S3 for |A|^2 (Sx[0], Sx[2]) and for |B|^2 (Sx[3], Sx[1])
             cplx* g2 = Gp + gp_off2 + (size_t)chunk * PH * Nhp;
-            if (kq == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
+            if (kq == 0 && lag0 == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = DIT ? (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1) : 4 * q + kq + 1;
+                if (HALF && (q & 1)) continue;
+                const int r = lag0 + (DIT ? (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1) : 4 * q + kq + 1);
                 if (r <= h) {
                     g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][0][q], Sx[sl][2][q]);
                     g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][0][q], -Sx[sl][2][q]);
@@ -758,10 +763,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
             }
             return;
         }
-        if (kq == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
+        if (kq == 0 && lag0 == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = DIT ? (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1) : 4 * q + kq + 1;
+            if (HALF && (q & 1)) continue;
+            const int r = lag0 + (DIT ? (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1) : 4 * q + kq + 1);
             if (r <= h) {
                 const double s1 = Sx[sl][0][q], s2 = Sx[sl][1][q], s3 = Sx[sl][2][q], s4 = Sx[sl][3][q];
                 g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);

@@ -158,6 +158,7 @@ struct sfft_plan {
     cplx* d_stage = nullptr;            // fast path: row-pass output, one plane per distinct (image, column factor) (lazy)
     int n_stage_alloc = 0;
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
+    hipStream_t s3 = nullptr; hipEvent_t ev_la_panel = nullptr, ev_la_side = nullptr;   // solver side stream of the outer-blocked Cholesky's look-ahead (SFFT_CHOL_LA=1; off by default)
     hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr, ev_mom = nullptr, ev_gam = nullptr; int no_overlap = 0;
     const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
     cplx* d_gp = nullptr;
@@ -355,19 +356,20 @@ static bool fits_on_chip(int N)
     return bluestein_len(N) != 0;
 }
 
-static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis = false);
+// rader: this axis may use Rader sub-transforms (the COLUMN axis only: strided_rader577 is the lines-fastest pass of a column transform)
+static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis = false, bool rader = false);
 static bool rader_ok(int N) { return N == RADER_M + 1 && !getenv("SFFT_NO_RADER") && !getenv("SFFT_NO_R16"); }
 
 // N = A * B with A the largest power-of-two factor (<= 4096) such that B fits on chip too
-static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
+static int build_big_axis(sfft_plan* p, AxisHost& ax, int N, bool rader)
 {
     const long double PI = acosl(-1.0L);
     // any factorisation N = A * B with both factors on chip; cost per element ~ passes over LDS of the two sub-transforms
     // (1 for a direct power-of-two / 2^a 3^b length, 4 M / len for Bluestein: two transforms of M >= 2 len - 1 plus products)
-    auto cost = [](int len) {
+    auto cost = [rader](int len) {
         int e2, e3;
         if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return 1.0;
-        if (rader_ok(len)) return 2.5;               // two transforms of len - 1 points and two permutation passes
+        if (rader && rader_ok(len)) return 2.5;      // two transforms of len - 1 points
         return 4.0 * bluestein_len(len) / len;
     };
     int A = 0, B = 0;
@@ -386,8 +388,8 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N)
     ax.N = N; ax.big = true; ax.A = A; ax.B = B; ax.M = 0; ax.logM = 0; ax.blue = 0;
     ax.subA = new AxisHost(); ax.subB = new AxisHost();
     int rc;
-    if ((rc = build_axis(p, *ax.subA, A, true))) return rc;
-    if ((rc = build_axis(p, *ax.subB, B, true))) return rc;
+    if ((rc = build_axis(p, *ax.subA, A, true, false))) return rc;       // (the first pass carries the four-step twiddles: strided_dft)
+    if ((rc = build_axis(p, *ax.subB, B, true, rader))) return rc;
     std::vector<cplx> r(N);
     for (int k = 0; k < N; ++k) {
         const long double ang = -2.0L * PI * k / N;
@@ -445,11 +447,11 @@ static int build_rader_axis(sfft_plan* p, AxisHost& ax, int N)
     return SFFT_OK;
 }
 
-static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis)
+static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis, bool rader)
 {
     const long double PI = acosl(-1.0L);
-    if (!fits_on_chip(N)) return build_big_axis(p, ax, N);
-    if (sub_axis && rader_ok(N)) return build_rader_axis(p, ax, N);
+    if (!fits_on_chip(N)) return build_big_axis(p, ax, N, rader);
+    if (sub_axis && rader && rader_ok(N)) return build_rader_axis(p, ax, N);
     ax.N = N;
     int e2 = 0, e3 = 0;
     if (is_pow2(N)) { ax.M = N; ax.blue = 0; }
@@ -657,7 +659,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->bk.npq = p->Fpq; p->bk.nq = BS.nby; p->bk.tbx = p->d_tbx; p->bk.tby = p->d_tby;
         for (int t = 0; t < p->Fpq; ++t) { p->bk.p[t] = BS.bpair[2 * t]; p->bk.q[t] = BS.bpair[2 * t + 1]; }
     }
-    PLAN_TRY(build_axis(p, p->ax0, N0));
+    PLAN_TRY(build_axis(p, p->ax0, N0, false, true));
     PLAN_TRY(build_axis(p, p->ax1, N1));
     p->lay = rowmajor_layout(p->Nhp);
     {   // panel layout: whenever both passes run on chip (the four-step kernels are row-major)
@@ -808,8 +810,22 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         const long long fill_target = (p->g1_dit && N0 % 2 == 0) ? 3072 : 6144;
         while (S < 16 && (long long)colblocks * S * npass_est < fill_target && N0 / (2 * S) >= 64) S *= 2;
         if (const char* ev = getenv("SFFT_G1_S")) { const int v = atoi(ev); if (v >= 1 && v <= 16 && N0 / v >= 64) S = v; }      // A/B: row chunks of the Omega launch
-        p->S = S;
+        // The grouped matrix-core launch shares a tile's planes between its sibling waves through the XCD's L2, which works while the
+        // siblings stay within a few hundred rows of each other: row chunks of at most ~1200 rows (4096 / 4 = 1024 at the headline size;
+        // 9232 rows in one chunk: 11.2 ms for config 5's two launches, 8 chunks: see DESIGN).  With the decimation step a chunk is
+        // rows_per_chunk / 2 rows x' and their partners, a whole number of 8-row steps: rows_per_chunk is a multiple of 16 and the last
+        // chunk takes what is left (N0 a multiple of 16).
+        if (p->g1_mfma >= 3 && hO >= 9 && hO <= 32 && p->g1_dit && N0 % 16 == 0 && !getenv("SFFT_G1_S")) {
+            // ... as long as the per-chunk partial sums (pass x chunk x lag x column) stay a fraction of the planes the launch reads
+            const double cap = 0.25 * (double)(p->Fij + 1) * N0 / ((double)(p->Fij * (p->Fij + 1) / 2) * PHo);
+            while (S < 16 && N0 / S > 1200 && 2 * S <= cap) S *= 2;
+        }
         p->rows_per_chunk = (N0 + S - 1) / S;
+        if (p->g1_dit && N0 % 16 == 0 && p->rows_per_chunk % 16 != 0) {
+            p->rows_per_chunk = (p->rows_per_chunk + 15) / 16 * 16;
+            S = (N0 + p->rows_per_chunk - 1) / p->rows_per_chunk;
+        }
+        p->S = S;
         long long goff = 0;
         auto add_pass = [&](int a, int b, int bp, int h) {
             G1Pass d; d.a_plane = a; d.b_plane = b; d.bp = bp; d.h = h; d.gp_off = goff; d.gp_off2 = 0; d.dual = 0;
@@ -820,7 +836,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         std::vector<int> sk_pass, ss_pass, st_pass, sg_pass((size_t)nsca * BS.nbx);
         // Omega passes.  On the matrix-core path the diagonal passes (a, a) go in pairs: one "dual" pass carries |A_a|^2 and |A_b|^2
         // (greek_g1_mfma, DG) and the partner's record only owns its partial buffer; partner records sit behind the launched ones.
-        const bool dual_diag = p->g1_mfma && hO >= 9 && hO <= 16 && p->Fij >= 2 && !getenv("SFFT_NO_DUAL_DIAG");
+        const bool dual_diag = p->g1_mfma && hO >= 9 && (hO <= 16 || (hO <= 32 && p->g1_mfma >= 3)) && p->Fij >= 2 && !getenv("SFFT_NO_DUAL_DIAG");
         omg_pass.assign((size_t)p->Fij * (p->Fij + 1) / 2, -1);
         auto okey = [&](int a, int b) { return a * p->Fij - (a * (a - 1)) / 2 + (b - a); };      // (a <= b) -> k, the job / patch order
         // Polynomial kernel bases: the passes of one "moment class" (i + i', j + j') differ by known combinations of lower moments and
@@ -922,7 +938,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         (void)PHo; (void)PHg;
         PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
         PLAN_HIP(hipMemcpy(p->d_passes, p->passes.data(), p->passes.size() * sizeof(G1Pass), hipMemcpyHostToDevice));
-        if (p->g1_mfma >= 3 && hO >= 9 && hO <= 16) {
+        if (p->g1_mfma >= 3 && hO >= 9 && hO <= 32) {
             // Pass groups of the Omega launch (greek_g1_mfma4g): an edge (x, y) with the dual-diagonal pass of the same two planes;
             // then triangles (x,y), (y,z), (x,z) among the remaining ordinary passes, greedily; then pairs of passes that share a
             // plane; then single passes.
@@ -1070,6 +1086,14 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
         if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
         if (const char* ev = getenv("SFFT_SOL_MEMSET")) p->sol_memset = atoi(ev);
+        // SFFT_CHOL_LA=1 (default off): look-ahead of the outer-blocked factorisation -- measured at n = 7207: 8.56 -> 8.25 ms as a graph,
+        // 8.5 -> 8.2 ms eager, 14.9 ms with the side stream at low priority: a rank-256 update workgroup lives ~145 us and holds its CU's
+        // registers, so the dependent panel launches beside it wait for slots and lose what the overlap gains
+        if (p->NEQfs >= p->chol_outer_min && getenv("SFFT_CHOL_LA") && atoi(getenv("SFFT_CHOL_LA")) == 1) {
+            PLAN_HIP(hipStreamCreateWithFlags(&p->s3, hipStreamNonBlocking));
+            PLAN_HIP(hipEventCreateWithFlags(&p->ev_la_panel, hipEventDisableTiming));
+            PLAN_HIP(hipEventCreateWithFlags(&p->ev_la_side, hipEventDisableTiming));
+        }
         if (const char* ev = getenv("SFFT_CHOL_DF_WG")) p->df_groups = std::max(1, atoi(ev));
         if (const char* ev = getenv("SFFT_FUSED_STEP")) p->fused_step = atoi(ev);
         if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
@@ -1234,6 +1258,9 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     for (void* q : ptrs) dev_free(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
+    if (p->s3) { hipStreamSynchronize(p->s3); hipStreamDestroy(p->s3); }
+    if (p->ev_la_panel) hipEventDestroy(p->ev_la_panel);
+    if (p->ev_la_side) hipEventDestroy(p->ev_la_side);
     if (p->ev_in) hipEventDestroy(p->ev_in);
     if (p->ev_pre) hipEventDestroy(p->ev_pre);
     if (p->ev_mom) hipEventDestroy(p->ev_mom);
@@ -1274,9 +1301,9 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_THETA_FUSED: *v = (p->theta_in_groups && p->g1_mfma >= 3) ? 1 : 0; break;
         case SFFT_Q_OMG_OFFDIAG: *v = p->n_omg_off; break;
         case SFFT_Q_G1_CHUNKS: *v = p->S; break;
-        case SFFT_Q_G1_DECIMATED: *v = (g1_decimated(p) && 2 * p->w >= 9 && 2 * p->w <= 16) ? 1 : 0; break;
+        case SFFT_Q_G1_DECIMATED: *v = (g1_decimated(p) && 2 * p->w >= 9 && 2 * p->w <= 32) ? 1 : 0; break;
         case SFFT_Q_OMG_DIAG: *v = p->n_omg_diag; break;
-        case SFFT_Q_G1_MFMA: *v = (p->g1_mfma && 2 * p->w >= 9 && 2 * p->w <= 16) ? 1 : 0; break;
+        case SFFT_Q_G1_MFMA: *v = (p->g1_mfma && 2 * p->w >= 9 && (2 * p->w <= 16 || (2 * p->w <= 32 && p->g1_mfma >= 3 && p->d_groups))) ? 1 : 0; break;
         case SFFT_Q_CHOL_DATAFLOW: *v = (p->dataflow && p->NEQfs < p->chol_outer_min) ? 1 : 0; break;
         case SFFT_Q_SOLVER_N: *v = p->NEQfs; break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
@@ -1631,8 +1658,8 @@ static int g1_padded(int h) { const int b = g1_band(h); return ((std::max(h, 1) 
 // the grouped Omega launch runs with the radix-2 decimation step (greek_g1_mfma4g<false, true>): whole chunks of an even number of 8-row steps
 static bool g1_decimated(const sfft_plan* p)
 {
-    const bool whole = (p->rows_per_chunk % (8 * DF_BURST)) == 0 && (p->N0 % p->rows_per_chunk) == 0;
-    return p->g1_mfma >= 3 && p->d_groups && whole && p->g1_dit && (p->N0 % 2) == 0 && (p->rows_per_chunk % (16 * DF_BURST)) == 0;
+    // whole 8-row steps of x' in every chunk, the (possibly shorter) last one included
+    return p->g1_mfma >= 3 && p->d_groups && p->g1_dit && (p->N0 % (16 * DF_BURST)) == 0 && (p->rows_per_chunk % (16 * DF_BURST)) == 0;
 }
 
 static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t s, bool planes_only = false)
@@ -1641,23 +1668,30 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
     (void)planes_only;
     // 9 .. 16 lags (the Omega passes at KerHW 5 .. 8): on the matrix cores.  For <= 8 lags the pass is not FMA bound and the
     // vector kernel is as fast or faster (measured 0.33 vs 0.34 - 0.38 ms with the 8-lag packing <NT, true>).
-    if (h >= 9 && h <= 16 && p->g1_mfma) {
+    const bool grouped = p->g1_mfma >= 3 && p->d_groups && pass0 == 0 && npass == p->n_omg_launch;
+    if (h >= 9 && (h <= 16 || (h <= 32 && grouped)) && p->g1_mfma) {
         const int ncb = (p->Nh + 31) / 32;
         const int total = ncb * p->S * npass;
-        if (p->g1_mfma >= 3 && p->d_groups && pass0 == 0 && npass == p->n_omg_launch) {
+        if (grouped) {
             const int ncb16 = (p->Nh + 15) / 16;
             const int totg = ncb16 * p->S * p->n_groups;
             const bool whole = (p->rows_per_chunk % (8 * DF_BURST)) == 0 && (p->N0 % p->rows_per_chunk) == 0;      // no step runs past its chunk
             const bool dit = g1_decimated(p);
-            if (dit)
+            // lag half-widths beyond 16 (KerHW 9 .. 16): the 16 lags lag0 + 1 .. lag0 + 16 per launch (the planes are read once per launch)
+            for (int lag0 = 0; lag0 < h; lag0 += 16) {
+            if (dit && lag0 > 0 && h - lag0 <= 8)
+                hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
+            else if (dit)
                 hipLaunchKernelGGL((greek_g1_mfma4g<false, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else if (whole)
                 hipLaunchKernelGGL(greek_g1_mfma4g<false>, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else
                 hipLaunchKernelGGL(greek_g1_mfma4g<true>, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace);
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
+            }
             if (p->d_g1trace) {     // development aid (SFFT_G1_TRACE=file): dump the wave stamps of this launch
                 hipStreamSynchronize(s);
                 std::vector<unsigned long long> h((size_t)3 * 8 * ((totg + 7) / 8));
@@ -1720,6 +1754,7 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
     if (p->fused_step && n >= p->chol_outer_min) {
         // outer blocks of 256 columns (see chol_syrk): the inner steps stay inside the block, one rank-256 update per block
         const int OB = 4 * CB;
+        bool side_pending = false;
         while (n - kb >= OB + CB) {
             hipLaunchKernelGGL(chol_panel, dim3(1 + (n + 1 - kb - CB + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
             for (int st = 1; st < 4; ++st) {
@@ -1730,10 +1765,26 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
             }
             const int r0 = kb + OB;
             const int nt = (n + 1 - r0 + SYRK_T - 1) / SYRK_T;
-            hipLaunchKernelGGL(chol_syrk, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0);
+            const int NA = OB / SYRK_T;         // tile columns of the NEXT outer block
+            if (p->s3 && nt > NA) {
+                // Look-ahead: the rank-256 update of the next outer block's columns stays on this stream and the panel steps of that
+                // block follow it at once; the update of everything to the right runs on the plan's solver side stream beside them.
+                // Dependencies: the side update needs this block's panel; the next near update needs the previous side update.
+                HIPCHK(hipEventRecord(p->ev_la_panel, s));
+                if (side_pending) HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0));
+                hipLaunchKernelGGL(chol_syrk, dim3(NA, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
+                HIPCHK(hipStreamWaitEvent(p->s3, p->ev_la_panel, 0));
+                hipLaunchKernelGGL(chol_syrk, dim3(nt - NA, nt), dim3(256), 0, p->s3, p->d_A, p->ld, n, kb, OB, r0, NA);
+                HIPCHK(hipEventRecord(p->ev_la_side, p->s3));
+                side_pending = true;
+            } else {
+                if (side_pending) { HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0)); side_pending = false; }
+                hipLaunchKernelGGL(chol_syrk, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
+            }
             kb = r0;
             hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A + (size_t)kb * p->ld + kb, p->ld, std::min(CB, n - kb), p->d_dbuf);
         }
+        if (side_pending) HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0));       // join: the remaining steps touch every column
     }
     int k_start = kb;
     if (p->fused_step && n - kb >= 2 * CB) {

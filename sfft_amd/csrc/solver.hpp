@@ -980,9 +980,10 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
 #define SYRK_T 128
 #define SYRK_KC 16
 #define SYRK_S (SYRK_KC + 4)
-__global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int ld, int n, int K0, int KB, int r0)
+// tj0: first tile column of this launch (the look-ahead splits the update into the next panel's two tile columns and the rest)
+__global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int ld, int n, int K0, int KB, int r0, int tj0)
 {
-    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int ti = blockIdx.y, tj = blockIdx.x + tj0;
     if (tj > ti) return;
     __shared__ double Li[SYRK_T][SYRK_S];
     __shared__ double Lj[SYRK_T][SYRK_S];
