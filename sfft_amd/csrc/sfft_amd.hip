@@ -817,7 +817,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         // chunk takes what is left (N0 a multiple of 16).
         if (p->g1_mfma >= 3 && hO >= 9 && hO <= 32 && p->g1_dit && N0 % 16 == 0 && !getenv("SFFT_G1_S")) {
             // ... as long as the per-chunk partial sums (pass x chunk x lag x column) stay a fraction of the planes the launch reads
-            const double cap = 0.25 * (double)(p->Fij + 1) * N0 / ((double)(p->Fij * (p->Fij + 1) / 2) * PHo);
+            const double cap = 0.5 * (double)(p->Fij + 1) * N0 / ((double)(p->Fij * (p->Fij + 1) / 2) * PHo);
             while (S < 16 && N0 / S > 1200 && 2 * S <= cap) S *= 2;
         }
         p->rows_per_chunk = (N0 + S - 1) / S;
