@@ -49,8 +49,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # fp64 vector = fp64 matrix (MFMA) peak on MI355X (public spec; the guide has no fp64 MFMA row)
-HBM_COPY_MEASURED_GBS = 5000.0   # a plain 16-byte-per-lane copy kernel on the boxes this was run on (scripts/micro/hbm_stream.hip,
-                                 # profiles/r01_hbm_stream.txt); the guide quotes 6290 for its float4 copy
+HBM_COPY_MEASURED_GBS = 5700.0   # a plain 16-byte-per-lane copy kernel on this device: 5.6 - 5.8 TB/s for contiguous chunks with non-temporal
+                                 # accesses, 5.2 - 5.6 plain (scripts/micro/hbm_stream2.hip, profiles/r03_hbm_stream2.txt); the guide quotes 6290
 COLS_KERNEL = {(9232, 9216): "strided_dft (four-step 9232 = 16 x 577 column axis)", (6144, 6144): "cols_fwd_weighted (6144-point mixed-radix axis)"}
 
 CONFIGS = {
