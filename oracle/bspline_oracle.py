@@ -10,7 +10,7 @@ which is the only CPU implementation the reference has of the algorithm in sfft/
 CuPy-only).  It covers BSplineSFFT's scaling modes ENTANGLED (ConstPhotRatio=False) and SEPARATE-CONSTANT
 (ConstPhotRatio=True; same TweakLS rule: BSplineSFFT.py:3707-3768 vs SFFTConfigure.py:1615-1699 of the dev version)
 without kernel regularisation.  SEPARATE-VARYING scaling and regularisation have no CPU implementation in the
-reference; they are restated (parity unpinned) in oracle/bspline_sv_oracle.py.
+reference; they are restated in oracle/bspline_sv_oracle.py (pinned since round 3 through the reference's NIRCam golden, see there).
 
 Parity status: PINNED by tests/golden/bs_*.npz (tests/golden/make_golden_bspline.py imports the dev-version modules
 in the build container); tests/test_oracle_golden.py checks this file against them.

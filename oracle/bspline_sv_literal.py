@@ -7,7 +7,8 @@ loops line by line -- one Python loop nest per `kmain`, the same index tables, t
 scalings -- so that a reading mistake would have to be made twice, in two differently shaped programs, to go unnoticed.
 tests/test_oracle_sv.py requires the two to agree to 1e-13 (relative to the block maximum) on small cases.
 
-Parity status: still UNPINNED (no reference-made vector exists for these modes); "two transcriptions agree" is evidence, not
+Parity status: the vectorised oracle this file cross-checks is pinned since round 3 through the reference's NIRCam golden
+(oracle/nircam_chain.py); this file itself is not run on it; "two transcriptions agree" is evidence, not
 a golden vector.  Only tests/ may import this module.
 
 Kernels transcribed (sfft/BSplineSFFT.py, v1.7.3):

@@ -10,8 +10,12 @@ numpy restatement, by reading, of the CuPy-only code
     sfft/BSplineSFFT.py:2293-2342, 3732-3785   TweakLS / Restore_Solution for NEQt < NEQ
     sfft/BSplineSFFT.py:2429-2527           Construct_FDIFF with the separate scaling planes
 
-PARITY UNPINNED: the reference cannot run this code here (CuPy only, no CPU backend, no golden vectors), so nothing
-produced by the reference pins this file.  What does pin it (tests/test_oracle_sv.py):
+PARITY: pinned since round 3 by an artefact of the reference, for the configuration the reference itself demonstrates --
+oracle/nircam_chain.py replays the NIRCam example (test/subtract_test_nircam/subtract4nircam.ipynb: B-spline kernel of degree 2
+with 2 x 2 knots, SEPARATE polynomial scaling of degree 2, Tikhonov regularisation on 512 seeded points) through this file and
+reproduces the reference's shipped 4check SNR map to 2.5e-8 relative RMS, the rounding of its float32 pixels
+(tests/test_nircam_chain.py).  NOT pinned by it: B-spline scaling bases, B-spline backgrounds, non-uniform WEIGHT_REGULARIZE.
+The reference cannot run this code here (CuPy only, no CPU backend).  What pins the rest (tests/test_oracle_sv.py):
   * the linear system equals the normal equations of the stated model, built by brute force in real space;
   * with the scaling basis equal to the kernel basis it reduces to the ENTANGLED system of oracle/bspline_oracle.py,
     which IS pinned by reference-generated goldens;

@@ -3,9 +3,10 @@
 The reference runs the per-segment convolutions with cupyx.scipy.signal.convolve2d / fftconvolve; scipy.signal has the same
 functions with the same semantics, so this is the reference's loop with `cp` replaced by `np` / scipy.
 
-PARITY UNPINNED: neither CuPy nor astropy (needed by the reference's GSVC_CPU) is importable in the build container, so no
-reference-generated vector exists for this function; the restatement leans on scipy.signal.convolve2d being the
-documented twin of the cupyx function.  Only tests/ may import this module."""
+PARITY: neither CuPy nor astropy (needed by the reference's GSVC_CPU) is importable in the build container, so no
+reference-generated vector exists for this function alone; the restatement leans on scipy.signal.convolve2d / fftconvolve
+being the documented twins of the cupyx functions.  Since round 3 its FFT branch is pinned end to end through the reference's
+NIRCam golden (oracle/nircam_chain.py, tests/test_nircam_chain.py: 81 tiles, 411 x 411 kernels).  Only tests/ may import this module."""
 import numpy as np
 from scipy.signal import convolve2d, fftconvolve
 

@@ -780,7 +780,8 @@ def test_bspline_mixed_domain_apply_equals_fourier_apply(dev, shape, w, deg, nk,
 
 # ------------------------------------------------------------------------------------------------
 # (e2) separately varying scaling + kernel regularisation (BSplineSFFT.py SCALING_MODE 'SEPARATE-VARYING', REGULARIZE_KERNEL).
-# The reference has no CPU code for these ("parity unpinned"): the comparison is oracle/bspline_sv_oracle.py, itself pinned
+# The reference has no CPU code for these: the comparison is oracle/bspline_sv_oracle.py (pinned by the reference's NIRCam golden for the
+# notebook's configuration, tests/test_nircam_chain.py), itself pinned
 # by tests/test_oracle_sv.py (brute-force normal equations, reduction to the golden-pinned ENTANGLED system).
 # ------------------------------------------------------------------------------------------------
 SV_CASES = [
@@ -1010,7 +1011,7 @@ def test_bspline_decorrelation_matches_reference(dev):
 
 @pytest.mark.parametrize("shape,TiHW,L,norm", [((200, 170), 10, (7, 7), True), ((96, 131), 7, (5, 9), False), ((64, 64), 31, (21, 21), True)])
 def test_grid_convolve_matches_oracle(dev, shape, TiHW, L, norm):
-    """BSpline_GridConvolve.GSVC_GPU against the scipy restatement of the reference's loop (parity unpinned: the reference
+    """BSpline_GridConvolve.GSVC_GPU against the scipy restatement of the reference's loop (pinned only through the NIRCam chain: the reference
     needs CuPy / astropy); both of its branches (direct and FFT) are reproduced by the same direct sums."""
     from oracle import gridconv_oracle as GO
     from sfft_amd.BSplineSFFT import BSpline_GridConvolve

@@ -1,6 +1,7 @@
 """Pins for oracle/bspline_sv_oracle.py (SEPARATE-VARYING scaling + kernel regularisation of sfft/BSplineSFFT.py).
 
-The reference has no CPU implementation of these modes, so no reference-generated golden exists ("parity unpinned").
+The reference has no CPU implementation of these modes; its one artefact that went through them, the NIRCam example's SNR map, pins
+the oracle end to end (tests/test_nircam_chain.py); these tests pin the modes that example does not use.
 These tests pin the restatement from three independent sides: brute-force normal equations, the reduction to the
 ENTANGLED system that IS pinned by goldens, and structural properties of the regularisation matrix."""
 import numpy as np
@@ -166,7 +167,7 @@ def test_lambda_zero_is_no_regularisation_and_large_lambda_smooths():
 # ---------------------------------------------------------------------------------------------------
 # Two transcriptions must agree: oracle/bspline_sv_literal.py follows the reference's CUDA kernels and host loops line by
 # line (per-element loops, the same index tables and cIdx loops); oracle/bspline_sv_oracle.py is the vectorised restatement
-# the GPU tests use.  Agreement to 1e-13 narrows -- does not close -- the "parity unpinned" label of these modes.
+# the GPU tests use.  Agreement to 1e-13 guards the vectorisation; the reference-made pin is tests/test_nircam_chain.py.
 # ---------------------------------------------------------------------------------------------------
 from oracle import bspline_sv_literal as lit
 
