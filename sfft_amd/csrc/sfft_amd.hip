@@ -210,6 +210,8 @@ struct sfft_plan {
     int n_groups = 0;
     int omg_reduce = 0;                 // env SFFT_OMG_REDUCE=1: one Omega pass per moment class is transformed, the others are derived (measured: no net gain, off)
     OmgReduce omgr; double* d_edge = nullptr; double* d_strip = nullptr; hipEvent_t ev_strip = nullptr;
+    int panel4 = 1, ncu = 0;            // env SFFT_PANEL4=0: the panel steps of the outer-blocked factorisation as four launches (chol_panel + 3 chol_step)
+    unsigned int* d_pq = nullptr;       // [PANEL4_MAX_OUTER] role counters of chol_panel4 + [16] its hand-off flags
     int sol_memset = 0;                 // env SFFT_SOL_MEMSET=1: zero the solution with hipMemsetAsync (a memset node in the solver graph) instead of a kernel
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
@@ -1086,6 +1088,9 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
         if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
         if (const char* ev = getenv("SFFT_SOL_MEMSET")) p->sol_memset = atoi(ev);
+        if (const char* ev = getenv("SFFT_PANEL4")) p->panel4 = atoi(ev);
+        PLAN_TRY(dev_alloc(p, &p->d_pq, (size_t)PANEL4_MAX_OUTER + 16));
+        PLAN_HIP(hipMemset(p->d_pq, 0, ((size_t)PANEL4_MAX_OUTER + 16) * sizeof(unsigned int)));
         // SFFT_CHOL_LA=1 (default off): look-ahead of the outer-blocked factorisation -- measured at n = 7207: 8.56 -> 8.25 ms as a graph,
         // 8.5 -> 8.2 ms eager, 14.9 ms with the side stream at low priority: a rank-256 update workgroup lives ~145 us and holds its CU's
         // registers, so the dependent panel launches beside it wait for slots and lose what the overlap gains
@@ -1099,6 +1104,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
         int ncu = 0;
         PLAN_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        p->ncu = ncu;
         if (nblk_b > ncu) p->back_variant = 0;      // the one-launch version needs every block's workgroup resident at once
     }
     PLAN_TRY(dev_alloc(p, &p->d_counter, (size_t)1));
@@ -1252,7 +1258,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_edge, p->d_strip, p->d_cyp, p->d_rowmomI, p->d_gamR};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_edge, p->d_strip, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1740,7 +1746,7 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
     const int n = p->NEQfs;
     const int nbc = (n + CB - 1) / CB;
     unsigned int* d_queue = p->d_tflags + (size_t)nbc * (nbc + 1);
-    hipLaunchKernelGGL(chol_begin, dim3(1), dim3(1), 0, s, p->d_epoch, d_queue);
+    hipLaunchKernelGGL(chol_begin, dim3(1), dim3(PANEL4_MAX_OUTER), 0, s, p->d_epoch, d_queue, p->d_pq);
     const bool dataflow = p->dataflow && n < p->chol_outer_min;
     if (dataflow) {
         // the whole factorisation as one launch of persistent workgroups (see chol_dataflow)
@@ -1755,7 +1761,14 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
         // outer blocks of 256 columns (see chol_syrk): the inner steps stay inside the block, one rank-256 update per block
         const int OB = 4 * CB;
         bool side_pending = false;
+        int outer = 0;
         while (n - kb >= OB + CB) {
+            const int ntile4 = (n + 1 - kb + CB - 1) / CB;       // 64-row tiles of this block column (border row included)
+            if (p->panel4 && p->d_pq && ntile4 <= p->ncu && outer < PANEL4_MAX_OUTER) {
+                // the four panel steps as one launch of co-resident workgroups (chol_panel4)
+                hipLaunchKernelGGL(chol_panel4, dim3(ntile4), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_pq + PANEL4_MAX_OUTER, p->d_pq, p->d_epoch,
+                                   (unsigned)outer, p->d_status, p->d_rd, p->d_w16, nbc);
+            } else {
             hipLaunchKernelGGL(chol_panel, dim3(1 + (n + 1 - kb - CB + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
             for (int st = 1; st < 4; ++st) {
                 const int k = kb + st * CB;
@@ -1763,6 +1776,8 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
                 hipLaunchKernelGGL(chol_step, dim3(4 - st, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
                                    p->d_bflags + p->n_bflags - 1, p->d_epoch, (unsigned)((k / CB) % 255), p->d_status, p->d_rd);
             }
+            }
+            ++outer;
             const int r0 = kb + OB;
             const int nt = (n + 1 - r0 + SYRK_T - 1) / SYRK_T;
             const int NA = OB / SYRK_T;         // tile columns of the NEXT outer block

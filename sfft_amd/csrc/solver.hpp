@@ -40,8 +40,12 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 }
 
 // first node of a solve: a new stamp for this solve's flag hand-offs (never 0 in its upper 24 bits)
-__global__ void chol_begin(unsigned int* epoch_ctr, unsigned int* queue)
+// (256 threads: thread t also clears role counter t of chol_panel4, one per outer block)
+#define PANEL4_MAX_OUTER 256
+__global__ void chol_begin(unsigned int* epoch_ctr, unsigned int* queue, unsigned int* panel_roles)
 {
+    if (panel_roles && threadIdx.x < PANEL4_MAX_OUTER) panel_roles[threadIdx.x] = 0u;
+    if (threadIdx.x != 0) return;
     unsigned int v = (*epoch_ctr + 1u) & 0xFFFFFFu;
     *epoch_ctr = v ? v : 1u;
     *queue = 0u;                            // task counter of chol_dataflow
@@ -969,6 +973,144 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
         }
     }
 #undef DF_TRACE
+}
+
+// ---- the four panel steps of one 256-column outer block as ONE launch ------------------------------------------------------
+// (outer-blocked factorisation of large systems, below).  One workgroup per 64-row tile of the block column, rows kb .. n (the border
+// row rides in the last tile).  Roles are handed out by an atomic counter in start order, so a workgroup only ever waits for workgroups
+// that are already running: role r owns row tile r.  It keeps its four 64 x 64 tiles (columns kb + 64 st, st = 0 .. 3) in the matrix
+// accumulators and walks the steps:
+//   r == st: factor the diagonal tile, publish the factor and the inverses of its 16 x 16 diagonal sub-blocks (flag st), done;
+//   r  > st: wait for that flag, X = T_st L^-T on the matrix cores (df_trsm_mfma), store X (final values of the factor; roles 1 .. 3
+//            also publish it: flag 4 + 4 st + r), then T_sp -= X X_sp^T for the later tiles sp = st + 1 .. min(3, r) of its row, with
+//            X_sp = role sp's X tile of this step (its own when sp == r).
+// Critical path per step: flag -> load factor -> solve -> update the next diagonal tile -> factor (13 us) -> publish: ~18 - 20 us
+// against the 35 - 40 us of a chol_step launch (whose every column-0 workgroup factors the diagonal block redundantly, behind a
+// launch boundary).  Hand-offs follow chol_dataflow's recipe (write-through payload, drained, one relaxed flag store; one poller,
+// one agent-scope acquire).  The stamp carries the solve counter and the outer block, so the 16 flags are reused without a reset.
+__global__ void __launch_bounds__(256) chol_panel4(double* __restrict__ A, int ld, int n, int kb, unsigned int* __restrict__ pflags,
+                                                   unsigned int* __restrict__ role_ctr, const unsigned int* __restrict__ epoch_ctr,
+                                                   unsigned int outer_id, int* __restrict__ status, double* __restrict__ rd,
+                                                   double* __restrict__ w16, int nbc)
+{
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
+    __shared__ int s_role;
+    double (*T)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                        // this step's tile / X
+    double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // another role's X tile / start of the PanelLds
+    PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
+    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
+    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD);
+    const unsigned int epoch = (*epoch_ctr << 8) | (outer_id & 0xFFu);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
+    const int ti = 16 * wv + ln, cg = lk;                    // element ownership of chol_factor_diag<true>
+    if (tid == 0) s_role = (int)atomicAdd(role_ctr + outer_id, 1u);
+    __syncthreads();
+    const int r = s_role;
+    const int R0 = kb + CB * r, nr = min(CB, n + 1 - R0);
+    if (nr <= 0) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((size_t)(n + 1) * ld * sizeof(double)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)w16, 0, (int)((size_t)nbc * 1024 * sizeof(double)), 0x00020000);
+    // my four tiles, in the accumulator layout C[16 wv + lk + 4 q][16 jt + ln] (tiles right of the diagonal of rows < 256 are never used)
+    d4s cT[4][4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * wv + lk + 4 * q, jc = 16 * jt + ln;
+                const double v = A[(size_t)(R0 + min(i, nr - 1)) * ld + kb + CB * st + jc];
+                cT[st][jt][q] = (i < nr && (st != r || jc <= i)) ? v : 0.0;
+            }
+    auto step = [&](auto ST) -> bool {                       // returns true when this role is finished
+        constexpr int st = decltype(ST)::value;
+        if (r < st) return true;
+        __syncthreads();                                     // (T / Lj of the previous step are no longer read)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[16 * wv + lk + 4 * q][16 * jt + ln] = cT[st][jt][q];
+        if (r == st) {
+            // ---- factor the diagonal tile (a full 64 x 64 block: the host only sends outer blocks with >= 320 columns left) ----
+            __syncthreads();
+            double a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cc = cg + 4 * q;
+                a[q] = (cc <= ti) ? T[ti][cc] : 0.0;
+            }
+            __syncthreads();                                 // T has been read; the PanelLds region may be overwritten
+            chol_factor_diag<true>(a, L, tid, CB, true, status, Vd);
+            chol_inv16_mfma(L.Dl, Vd, reinterpret_cast<double (*)[16][W16_LD]>(&T[0][0]) + 3 * wv, W16t, wv, ln, lk);
+            const int jb = kb / CB + st;                     // block index of this diagonal tile (w16 slot)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double v0 = W16t[wv][lane >> 2][4 * (lane & 3) + 2 * h], v1 = W16t[wv][lane >> 2][4 * (lane & 3) + 2 * h + 1];
+                df_u4 pk;
+                pk.x = (unsigned int)__double2loint(v0); pk.y = (unsigned int)__double2hiint(v0);
+                pk.z = (unsigned int)__double2loint(v1); pk.w = (unsigned int)__double2hiint(v1);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_w, (int)(((size_t)jb * 1024 + (size_t)wv * 256 + (size_t)lane * 4 + 2 * h) * sizeof(double)), 0, /*aux: sc1*/ 16);
+            }
+            df_store_tile(rsrc, ld, R0, CB, kb + CB * st, L.Dl, tid);          // (Dl is zero above the diagonal)
+            if (tid < CB) __hip_atomic_store(&rd[R0 + tid], L.rdiag[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            df_publish(pflags, st, epoch, tid);
+            return true;
+        }
+        // ---- r > st: X = T L(st,st)^-T ----
+        if (tid == 0) { df_poll(pflags, st, epoch, status); df_acquire(); }
+        __syncthreads();
+        {
+            const int c0 = kb + CB * st, jb = kb / CB + st;
+            double dv[16], wvv[4];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int e = tid + 256 * it, i = e >> 6, q = e & 63;
+                dv[it] = A[(size_t)(c0 + i) * ld + c0 + q];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) wvv[it] = w16[(size_t)jb * 1024 + tid + 256 * it];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int e = tid + 256 * it, i = e >> 6, q = e & 63;
+                L.Dl[i][q] = (q <= i) ? dv[it] : 0.0;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { const int e = tid + 256 * it; W16t[e >> 8][(e >> 4) & 15][e & 15] = wvv[it]; }
+        }
+        __syncthreads();
+        df_trsm_mfma(T, L.Dl, W16t, wv, ln, lk);
+        __syncthreads();
+        df_store_tile(rsrc, ld, R0, nr, kb + CB * st, T, tid);
+        if (r <= 3) df_publish(pflags, 4 + 4 * st + r, epoch, tid);
+        // ---- updates of my later tiles ----
+        auto upd = [&](auto SP) {
+            constexpr int sp = decltype(SP)::value;
+            if constexpr (sp > st && sp <= 3) {
+                if (sp > r) return;
+                const double (*B)[CB + 1] = T;
+                if (sp != r) {
+                    __syncthreads();                         // (the trsm's L.Dl / the previous sp's tile in Lj have been read)
+                    if (tid == 0) { df_poll(pflags, 4 + 4 * st + sp, epoch, status); df_acquire(); }
+                    __syncthreads();
+                    df_load_tile(A, ld, kb + CB * sp, CB, kb + CB * st, Lj, tid);
+                    __syncthreads();
+                    B = Lj;
+                }
+#pragma unroll 4
+                for (int ks = 0; ks < CB / 4; ++ks) {
+                    const double av = -T[16 * wv + ln][4 * ks + lk];
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) cT[sp][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[16 * jt + ln][4 * ks + lk], cT[sp][jt], 0, 0, 0);
+                }
+            }
+        };
+        upd(std::integral_constant<int, 1>{}); upd(std::integral_constant<int, 2>{}); upd(std::integral_constant<int, 3>{});
+        return false;
+    };
+    if (step(std::integral_constant<int, 0>{})) return;
+    if (step(std::integral_constant<int, 1>{})) return;
+    if (step(std::integral_constant<int, 2>{})) return;
+    step(std::integral_constant<int, 3>{});
 }
 
 // ---- outer blocking for large systems ----------------------------------------------------------------------------
