@@ -214,6 +214,7 @@ struct sfft_plan {
     unsigned int* d_pq = nullptr;       // [PANEL4_MAX_OUTER] role counters of chol_panel4 + [16] its hand-off flags
     int sol_memset = 0;                 // env SFFT_SOL_MEMSET=1: zero the solution with hipMemsetAsync (a memset node in the solver graph) instead of a kernel
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
+    int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
@@ -1016,9 +1017,14 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                         owner[g.plane[0]] = (int)gi; owner[g.plane[1]] = (int)gi;
                     }
                 }
-                for (int a = 0; a < p->Fij && ok; ++a) ok = owner[a] >= 0;
+                // (odd Fij: the last plane has no dual partner, hence no such group; its Theta pass stays in a vector launch of its own)
+                int nf = 0;
+                while (nf < p->Fij && owner[nf] >= 0) ++nf;
+                for (int a = nf; a < p->Fij && ok; ++a) ok = owner[a] < 0;
+                ok = ok && nf > 0;
                 if (ok) {
-                    for (int a = 0; a < p->Fij; ++a) {
+                    p->n_the_fused = nf;
+                    for (int a = 0; a < nf; ++a) {
                         G1Group& g = groups[owner[a]];
                         g.tpass[g.plane[0] == a ? 0 : 1] = the_pass[a];
                         g.plane[2] = JP; g.ht = hG;
@@ -2020,7 +2026,10 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
-        if (!theta_with_omega && !(p->theta_in_groups && p->g1_mfma >= 3) && (rc = greek_g1_group(p, p->n_omg, p->n_dense_w, p->w, s))) return rc;
+        if (!theta_with_omega) {
+            const int fused = (p->theta_in_groups && p->g1_mfma >= 3) ? p->n_the_fused : 0;      // (the rest: a vector launch of their own)
+            if (fused < p->n_dense_w && (rc = greek_g1_group(p, p->n_omg + fused, p->n_dense_w - fused, p->w, s))) return rc;
+        }
         if (p->gamma_analytic && !gamma_aside) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
 #define ROWMOM_I(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
