@@ -64,6 +64,41 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) strided_dft(const cplx* 
     }
 }
 
+// First pass of a four-step COLUMN transform whose first factor is 16 (9232 = 16 x 577): a 16-point transform per (column, j) entirely in
+// registers -- lanes are 64 consecutive columns (1 KB contiguous per row and instruction), the 16 inputs of a thread are the rows
+// j + B e, the four-step twiddle rootN[(j k) mod N] is wave-uniform (scalar loads).  No LDS, no barriers; replaces strided_dft's
+// LDS round trip for this pass (0.55 -> see DESIGN ms per 9232 x 4609 plane).  d as for strided_dft (mode 2, len 16, twiddle 1).
+__global__ void __launch_bounds__(256) strided_dft16_cols(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, const cplx* __restrict__ rootN)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);          // wave-uniform
+    const int line = (int)blockIdx.x * 64 + lane;
+    if (j >= d.J) return;
+    const bool ok = line < d.nlines;
+    const long long li = (long long)(ok ? line : d.nlines - 1) * d.lst_in + (long long)j * d.js_in;
+    cplx u[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) u[e] = in[li + (long long)e * d.es_in];
+    if (d.w) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const double f = d.w[j * d.w_js + e * d.w_es]; u[e].x *= f; u[e].y *= f; }
+    }
+    if (d.conj_in) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[e].y = -u[e].y;
+    }
+    dft16(u);
+    if (!ok) return;
+    const long long lo = (long long)line * d.lst_out + (long long)j * d.js_out;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cplx z = u[R16_OUT(k)];
+        if (d.twiddle) z = cmul(z, rootN[(int)(((long long)j * k) % d.N)]);
+        if (d.conj_out) z.y = -z.y;
+        out[lo + (long long)k * d.es_out] = make_double2(z.x * d.scale, z.y * d.scale);
+    }
+}
+
 // The same pass for a Rader sub-axis (N = 577, config 5's 9232 = 16 x 577 column axis), lines fastest (mode 2): a kernel of its own so that
 // the compiler sees one transform, not every path of lds_dft (strided_dft is 52 k instructions and sits at its register cap).
 // RADER_TC lines (columns) x 577 elements per workgroup: each row of the tile is RADER_TC x 16 contiguous bytes.

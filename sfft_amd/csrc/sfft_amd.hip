@@ -1350,6 +1350,10 @@ static bool fast_axis(const AxisHost& a) { return !a.big && !a.blue && a.M == 40
 // one pass of batched strided sub-transforms
 static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, const AxisHost& sub, const cplx* rootN, hipStream_t s)
 {
+    if (d.mode == 2 && d.len == 16 && sub.M == 16 && !sub.blue && !getenv("SFFT_NO_DFT16_REGS")) {        // 16-point first pass of a column transform: registers only
+        hipLaunchKernelGGL(strided_dft16_cols, dim3((d.nlines + 63) / 64, (d.J + 3) / 4), dim3(256), 0, s, in, out, d, rootN);
+        return;
+    }
     int TC, MS;
     // Bluestein sub-transforms run two passes over the tile with barriers throughout: two workgroups per CU (half the LDS each)
     // hide more than a wider tile gains (9232-point columns: 22.4 -> 20.1 ms for 11 planes)
