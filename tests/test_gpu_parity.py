@@ -553,14 +553,17 @@ def test_config3_bspline_6144(dev):
     clear_plan_cache()
 
 
-def test_config3_bspline_strip_matches_oracle(dev):
+@pytest.mark.parametrize("shape", [(6144, 96), (96, 6144)], ids=["cols6144", "rows6144"])
+def test_config3_bspline_strip_matches_oracle(dev, shape):
     """6144 x 96 strip with config 3's basis: the same 7231-unknown system as the full frame (outer-blocked Cholesky, 325 Omega
-    passes, tied scaling), small enough for the oracle: LHMAT / RHb <= 1e-11, apply-only DIFF <= 1e-10 RMS(J), end to end <= 1e-6."""
+    passes, tied scaling), small enough for the oracle: LHMAT / RHb <= 1e-11, apply-only DIFF <= 1e-10 RMS(J), end to end <= 1e-6.
+    The transposed strip (96 x 6144) runs the full-width 6144-point ROW passes (forward r2c of the B-spline stage planes, inverse c2r
+    with the DIFF epilogue) with the config's own basis tables."""
     from oracle import bspline_oracle as BO
     from sfft_amd.plan import clear_plan_cache
     from sfft_amd.BSplineSFFT import GeneralSFFTSubtract as BGSS, ElementalSFFTSubtract as BESS
     clear_plan_cache()
-    N0, N1 = 6144, 96
+    N0, N1 = shape
     cfg, kx, ky = _config3(N0, N1, dev)
     plan = cfg[1]["plan"]
     REF, SCI, mREF, mSCI = _blob_pair(N0, N1, 4)
@@ -615,14 +618,23 @@ def test_config2_full_size_matches_oracle(dev, big):
     assert rel_rms_err(diff.cpu().numpy(), D_o) <= 1e-6
 
 
-def test_config5_strip_matches_oracle(dev):
-    """BASELINE config 5's geometry on a 9232 x 128 strip: the four-step 9232-point axis (16 x 577), KerHW 12 (49 x 49 Omega lag patches: the
+@pytest.mark.parametrize("shape", [(9232, 128), (128, 9216)], ids=["cols9232", "rows9216"])
+def test_config5_strip_matches_oracle(dev, shape):
+    """(The 128 x 9216 strip: config 5's full-width 9216-point ROW passes with KerHW 12 and orders 3 / 3.)
+    BASELINE config 5's geometry on a 9232 x 128 strip: the four-step 9232-point axis (16 x 577), KerHW 12 (49 x 49 Omega lag patches: the
     decimated vector kernel in two lag bands), orders 3 / 3 (NEQ 6260: the outer-blocked Cholesky), vconv_mixed<3,12> -- against the oracle:
     LHMAT / RHb <= 1e-11 block by block, apply-only DIFF <= 1e-10 RMS(J), end to end <= 1e-6."""
     from oracle import sfft_oracle as O
     from sfft_amd.plan import Plan
-    N0, N1, w = 9232, 128, 12
-    REF, SCI, mREF, mSCI = _blob_pair(N0, N1, 5)
+    (N0, N1), w = shape, 12
+    if N0 < N1:
+        # (the sin x cos y blob field is numerically rank deficient on a wide strip: cond(LHMAT) = 8e17 at 128 x 9216, where LU and Cholesky on
+        #  the ORACLE's own matrix already differ by 4e-6 in DIFF; a seeded star field is not)
+        from sfft_amd.utils.synthetic import make_pair
+        pr = make_pair(N0, N1, seed=11, mask=True, density=400.0)
+        REF, SCI, mREF, mSCI = pr["REF"], pr["SCI"], pr["mREF"], pr["mSCI"]
+    else:
+        REF, SCI, mREF, mSCI = _blob_pair(N0, N1, 5)
     plan = Plan(N0, N1, w, 3, 3, True, device=dev.index)
     assert plan.NEQ == 6260
     ncpu = min(64, os.cpu_count() or 1)
