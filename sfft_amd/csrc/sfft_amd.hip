@@ -210,6 +210,7 @@ struct sfft_plan {
     int n_groups = 0;
     int omg_reduce = 0;                 // env SFFT_OMG_REDUCE=1: one Omega pass per moment class is transformed, the others are derived (measured: no net gain, off)
     OmgReduce omgr; double* d_edge = nullptr; double* d_strip = nullptr; hipEvent_t ev_strip = nullptr;
+    int syrk4 = 0;                      // rank-256 update of the outer-blocked factorisation on v_mfma_f64_4x4x4_4b_f64 (SFFT_SYRK4=0: 16 x 16 x 4)
     int panel4 = 1, ncu = 0;            // env SFFT_PANEL4=0: the panel steps of the outer-blocked factorisation as four launches (chol_panel + 3 chol_step)
     unsigned int* d_pq = nullptr;       // [PANEL4_MAX_OUTER] role counters of chol_panel4 + [16] its hand-off flags
     int sol_memset = 0;                 // env SFFT_SOL_MEMSET=1: zero the solution with hipMemsetAsync (a memset node in the solver graph) instead of a kernel
@@ -1095,6 +1096,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
         if (const char* ev = getenv("SFFT_SOL_MEMSET")) p->sol_memset = atoi(ev);
         if (const char* ev = getenv("SFFT_PANEL4")) p->panel4 = atoi(ev);
+        if (const char* ev = getenv("SFFT_SYRK4")) p->syrk4 = atoi(ev);
         PLAN_TRY(dev_alloc(p, &p->d_pq, (size_t)PANEL4_MAX_OUTER + 16));
         PLAN_HIP(hipMemset(p->d_pq, 0, ((size_t)PANEL4_MAX_OUTER + 16) * sizeof(unsigned int)));
         // SFFT_CHOL_LA=1 (default off): look-ahead of the outer-blocked factorisation -- measured at n = 7207: 8.56 -> 8.25 ms as a graph,
@@ -1771,6 +1773,7 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
         // outer blocks of 256 columns (see chol_syrk): the inner steps stay inside the block, one rank-256 update per block
         const int OB = 4 * CB;
         bool side_pending = false;
+        auto SYRK_K = p->syrk4 ? chol_syrk<true> : chol_syrk<false>;       // (SFFT_SYRK4=0: the 16 x 16 x 4 matrix instruction)
         int outer = 0;
         while (n - kb >= OB + CB) {
             const int ntile4 = (n + 1 - kb + CB - 1) / CB;       // 64-row tiles of this block column (border row included)
@@ -1797,14 +1800,14 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
                 // Dependencies: the side update needs this block's panel; the next near update needs the previous side update.
                 HIPCHK(hipEventRecord(p->ev_la_panel, s));
                 if (side_pending) HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0));
-                hipLaunchKernelGGL(chol_syrk, dim3(NA, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
+                hipLaunchKernelGGL(SYRK_K, dim3(NA, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
                 HIPCHK(hipStreamWaitEvent(p->s3, p->ev_la_panel, 0));
-                hipLaunchKernelGGL(chol_syrk, dim3(nt - NA, nt), dim3(256), 0, p->s3, p->d_A, p->ld, n, kb, OB, r0, NA);
+                hipLaunchKernelGGL(SYRK_K, dim3(nt - NA, nt), dim3(256), 0, p->s3, p->d_A, p->ld, n, kb, OB, r0, NA);
                 HIPCHK(hipEventRecord(p->ev_la_side, p->s3));
                 side_pending = true;
             } else {
                 if (side_pending) { HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0)); side_pending = false; }
-                hipLaunchKernelGGL(chol_syrk, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
+                hipLaunchKernelGGL(SYRK_K, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
             }
             kb = r0;
             hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A + (size_t)kb * p->ld + kb, p->ld, std::min(CB, n - kb), p->d_dbuf);

@@ -1123,6 +1123,12 @@ __global__ void __launch_bounds__(256) chol_panel4(double* __restrict__ A, int l
 #define SYRK_KC 16
 #define SYRK_S (SYRK_KC + 4)
 // tj0: first tile column of this launch (the look-ahead splits the update into the next panel's two tile columns and the rest)
+// M4 = true: the products run on v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction; a loop of nothing else
+// sustains 74 TFLOP/s against 47 for the 16 x 16 x 4 form, profiles/r02_mfma_f64_peak.txt).  A 16 x 16 x 4 tile product is four of
+// them: instruction bi takes A rows 4 bi .. 4 bi + 3 (the same in all four blocks: lane 16 k + 4 blk + i holds A[4 bi + i][k]) and
+// the B operand of the 16 x 16 x 4 form unchanged (lane 16 k + n holds B[k][n], block blk = columns 4 blk .. 4 blk + 3); lane
+// 16 i + n of the result holds C[4 bi + i][n].  Same accumulator count, 20 instead of 8 LDS reads per 64 k-products.
+template <bool M4>
 __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int ld, int n, int K0, int KB, int r0, int tj0)
 {
     const int ti = blockIdx.y, tj = blockIdx.x + tj0;
@@ -1168,10 +1174,21 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
                 a[t] = Li[64 * wr + 16 * t + ln][4 * ks + lk];
                 b[t] = Lj[64 * wc + 16 * t + ln][4 * ks + lk];
             }
+            if constexpr (M4) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int bi = 0; bi < 4; ++bi) {
+                        const double a4 = Li[64 * wr + 16 * it + 4 * bi + (lane & 3)][4 * ks + lk];
+#pragma unroll
+                        for (int jt = 0; jt < 4; ++jt) c[it][jt][bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, b[jt], c[it][jt][bi], 0, 0, 0);
+                    }
+            } else {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) c[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], c[it][jt], 0, 0, 0);
+            }
         }
     }
     // read-modify-write of the tile, 16 elements at a time: all 16 loads first (written as `A[..] -= c` the compiler orders
@@ -1183,14 +1200,14 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + 64 * wr + 16 * it + lk + 4 * q, j = j0 + 64 * wc + 16 * jt + ln;
+                const int i = i0 + 64 * wr + 16 * it + (M4 ? 4 * q + lk : lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
                 oldv[jt][q] = (i <= n && j < n && j <= i) ? A[(size_t)i * ld + j] : 0.0;
             }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + 64 * wr + 16 * it + lk + 4 * q, j = j0 + 64 * wc + 16 * jt + ln;
+                const int i = i0 + 64 * wr + 16 * it + (M4 ? 4 * q + lk : lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
                 if (i <= n && j < n && j <= i) A[(size_t)i * ld + j] = oldv[jt][q] - c[it][jt][q];
             }
     }
