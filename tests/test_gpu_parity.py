@@ -1197,6 +1197,24 @@ def test_generic_fft_variants_agree(dev, shape, w):
     assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
 
 
+@pytest.mark.parametrize("env", [{"SFFT_NO_RADER": "1"}, {"SFFT_NO_DFT16_REGS": "1"}, {"SFFT_NO_STAGED": "1"}, {"SFFT_NO_VCONV": "1"},
+                                 {"SFFT_NO_VCONV": "1", "SFFT_NO_RADER": "1", "SFFT_NO_DFT16_REGS": "1"}],
+                         ids=["bluestein577", "lds16", "unstaged", "fourier_apply", "fourier_apply_round2_kernels"])
+def test_four_step_column_axis_variants_agree(dev, env):
+    """9232 = 16 x 577 rows (config 5's column axis): Rader's 576-point sub-transform against Bluestein on 2048 points, the
+    register-only 16-point first pass against the LDS one, staged against per-plane forward transforms, and the Fourier-domain
+    apply -- whose INVERSE column transform runs the same two kernels with the conjugation flags -- against the mixed-domain one.
+    Same linear system to rounding, same DIFF."""
+    from sfft_amd.utils.synthetic import make_pair
+    shape, w = (9232, 80), 3
+    pair = make_pair(*shape, seed=77, mask=True, density=400.0)
+    new = _subtract_with_env(dev, {}, shape, w, 2, 1, pair)
+    old = _subtract_with_env(dev, env, shape, w, 2, 1, pair)
+    assert np.max(np.abs(new[2] - old[2])) <= 1e-11 * np.max(np.abs(old[2]))
+    assert np.max(np.abs(new[3] - old[3])) <= 1e-11 * np.max(np.abs(old[3]))
+    assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
+
+
 @pytest.mark.parametrize("shape,w,DK", [((320, 288), 8, 2), ((4096, 4096), 8, 2), ((512, 384), 5, 3)])
 def test_derived_omega_patches_equal_transformed_ones(dev, shape, w, DK):
     """SFFT_OMG_REDUCE=1 (off by default: no net gain measured): Omega products I_a conj(I_b) whose polynomial degrees add up to
