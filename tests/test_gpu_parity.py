@@ -183,6 +183,11 @@ ORACLE_CASES = [
     (80, 9232, 2, 1, 0, True, "SCI", True),     # axis 1 needs it (9232 = 16 x 577, Bluestein inside)
     (160, 144, 2, 3, 2, False, "REF", False),   # NEQ = 256 = 4 x 64: the fused Cholesky steps end exactly at the matrix edge
     (160, 144, 2, 1, 0, True, "REF", False),    # NEQ_FSfree = 74: one fused step would not fit (n < 128), two-kernel path only
+    # KerHW > 8: Omega lag half-width 2 w > 16 on the matrix cores, 16 lags per launch (lag0 = 0, 16)
+    (208, 160, 10, 1, 1, True, "REF", True),    # h = 20, N0 a multiple of 16: decimated launches, the second one needs 4 of its 16 lags
+    (192, 176, 12, 1, 1, True, "SCI", True),    # h = 24 (config 5's KerHW): decimated, second launch at half the matrix instructions
+    (130, 140, 16, 1, 0, False, "REF", True),   # h = 32, N0 not a multiple of 16: undecimated launches with the row mask, both full
+    (256, 96, 14, 0, 1, True, "REF", False),    # h = 28, a single kernel plane: one diagonal pass, no groups of three
 ]
 
 
