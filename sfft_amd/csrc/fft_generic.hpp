@@ -122,6 +122,7 @@ struct ColOuts {
     int stage_plane[COLG_MAX_OUT];                // source plane in the stage buffer
     int out_plane[COLG_MAX_OUT];                  // destination plane
     const double* wx[COLG_MAX_OUT];               // [N0] row factor
+    int lo[COLG_MAX_OUT], hi[COLG_MAX_OUT];       // rows outside [lo, hi) have a zero row factor: not read (generic pass only)
 };
 
 __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_fwd_weighted(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int N0, int ncols,
@@ -147,10 +148,11 @@ __global__ void __launch_bounds__(SFFT_FFT_MAX_THREADS) cols_fwd_weighted(const 
     {
         cplx zz[16];
         double ff[16];
+        const int lo = g.lo[o], hi = g.hi[o];
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int l = (tid >> LT) + it * lstep;
-            const bool ok = l < N0 && cok;
+            const bool ok = l >= lo && l < hi && cok;
             zz[it] = ok ? gp[(size_t)(l * rs)] : make_double2(0.0, 0.0);
             ff[it] = ok ? wx[l] : 0.0;
         }

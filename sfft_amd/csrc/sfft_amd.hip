@@ -217,6 +217,8 @@ struct sfft_plan {
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
+    int no_wx_support = 0;              // env SFFT_NO_WX_SUPPORT=1: the generic weighted column pass reads rows whose row factor is zero too (A/B)
+    std::vector<int> kbx_lo, kbx_hi;    // [nkx] first row / one past the last row where the kernel row factor is nonzero
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     int timing = 0;
@@ -577,6 +579,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     p->dev = device;
     if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
+    if (const char* ev = getenv("SFFT_NO_WX_SUPPORT")) p->no_wx_support = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
     if (const char* ev = getenv("SFFT_THETA_MFMA")) p->theta_mfma = atoi(ev);
@@ -647,6 +650,15 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_tbx, (size_t)BS.nbx * N0));
         PLAN_TRY(dev_alloc(p, &p->d_tby, (size_t)BS.nby * N1));
         PLAN_HIP(hipMemcpy(p->d_kbx, BS.kbx.data(), (size_t)BS.nkx * N0 * sizeof(double), hipMemcpyHostToDevice));
+        // support of every kernel row factor (B-spline factors vanish outside a few knot spans): the weighted column pass skips the rest
+        p->kbx_lo.assign(BS.nkx, 0); p->kbx_hi.assign(BS.nkx, N0);
+        for (int i = 0; i < BS.nkx; ++i) {
+            const double* t = BS.kbx.data() + (size_t)i * N0;
+            int lo = 0, hi = N0;
+            while (lo < N0 && t[lo] == 0.0) ++lo;
+            while (hi > lo && t[hi - 1] == 0.0) --hi;
+            p->kbx_lo[i] = lo; p->kbx_hi[i] = hi;
+        }
         PLAN_HIP(hipMemcpy(p->d_kby, BS.kby.data(), (size_t)BS.nky * N1 * sizeof(double), hipMemcpyHostToDevice));
         PLAN_HIP(hipMemcpy(p->d_tbx, BS.tbx.data(), (size_t)BS.nbx * N0 * sizeof(double), hipMemcpyHostToDevice));
         PLAN_HIP(hipMemcpy(p->d_tby, BS.tby.data(), (size_t)BS.nby * N1 * sizeof(double), hipMemcpyHostToDevice));
@@ -1517,7 +1529,15 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
         while (k < nst) {
             ColOuts g; memset(&g, 0, sizeof(g));
             while (k < nst && g.nout + (int)stages[k].outs.size() <= COLG_MAX_OUT) {
-                for (const Out& o : stages[k].outs) { g.stage_plane[g.nout] = k; g.out_plane[g.nout] = o.plane; g.wx[g.nout] = o.wx; ++g.nout; }
+                for (const Out& o : stages[k].outs) {
+                    g.stage_plane[g.nout] = k; g.out_plane[g.nout] = o.plane; g.wx[g.nout] = o.wx;
+                    g.lo[g.nout] = 0; g.hi[g.nout] = p->N0;
+                    const ptrdiff_t off = o.wx - p->d_kbx;
+                    if (!p->no_wx_support && off >= 0 && off < (ptrdiff_t)p->kbx_lo.size() * p->N0) {
+                        g.lo[g.nout] = p->kbx_lo[off / p->N0]; g.hi[g.nout] = p->kbx_hi[off / p->N0];
+                    }
+                    ++g.nout;
+                }
                 ++k;
             }
             if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
