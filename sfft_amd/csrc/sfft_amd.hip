@@ -76,6 +76,7 @@ extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 #include "fft_generic.hpp"
 #include "fft_fourstep.hpp"
 #include "fft_r16_4096.hpp"
+#include "fft_r24_6144.hpp"
 #include "greek.hpp"
 #include "fill.hpp"
 #include "solver.hpp"
@@ -217,6 +218,7 @@ struct sfft_plan {
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
+    int cols6k = 0;                     // 6144-point column axis on the register-resident kernel (env SFFT_NO_COLS6K=1: the generic pass, A/B)
     int no_wx_support = 0;              // env SFFT_NO_WX_SUPPORT=1: the generic weighted column pass reads rows whose row factor is zero too (A/B)
     std::vector<int> kbx_lo, kbx_hi;    // [nkx] first row / one past the last row where the kernel row factor is nonzero
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
@@ -716,6 +718,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->nt_rows = fft_threads(p->ax1.M);
         p->lds_rows = (size_t)axis_lds_len(p->ax1) * sizeof(cplx);
     }
+    p->cols6k = !p->ax0.big && !p->ax0.blue && p->ax0.M == 6144 && !p->no_fast_fft && !getenv("SFFT_NO_COLS6K");
     if (!p->ax0.big) {
         pick_col_tile(p->ax0, &p->TC, &p->MS);
         p->nt_cols = fft_threads(p->TC * p->ax0.M);
@@ -1541,6 +1544,11 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                 ++k;
             }
             if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
+            if (p->cols6k) {       // register-resident 6144-point columns, one per workgroup, 64 columns per (XCD-interleaved) column group
+                hipLaunchKernelGGL(cols_fwd_weighted_6144, dim3(64 * g.nout * ((p->Nh + 63) / 64)), dim3(384), F6K_LDS * sizeof(double), s,
+                                   p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
+                continue;
+            }
             hipLaunchKernelGGL(cols_fwd_weighted, dim3(8 * G * g.nout * ntg), dim3(p->nt_cols), p->lds_cols, s, p->d_stage, dst, g, p->N0, p->Nh,
                                p->Nhp, p->TC, ilog2(p->TC), p->MS, p->lay, axis_dev(p->ax0));
         }
