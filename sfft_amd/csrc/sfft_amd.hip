@@ -218,6 +218,7 @@ struct sfft_plan {
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
+    int rows6k = 0;                     // 6144-point row axis on the register-resident kernel (env SFFT_NO_ROWS6K=1: the generic pass, A/B)
     int cols6k = 0;                     // 6144-point column axis on the register-resident kernel (env SFFT_NO_COLS6K=1: the generic pass, A/B)
     int no_wx_support = 0;              // env SFFT_NO_WX_SUPPORT=1: the generic weighted column pass reads rows whose row factor is zero too (A/B)
     std::vector<int> kbx_lo, kbx_hi;    // [nkx] first row / one past the last row where the kernel row factor is nonzero
@@ -718,6 +719,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->nt_rows = fft_threads(p->ax1.M);
         p->lds_rows = (size_t)axis_lds_len(p->ax1) * sizeof(cplx);
     }
+    p->rows6k = !p->ax1.big && !p->ax1.blue && p->ax1.M == 6144 && !p->no_fast_fft && !getenv("SFFT_NO_ROWS6K");
     p->cols6k = !p->ax0.big && !p->ax0.blue && p->ax0.M == 6144 && !p->no_fast_fft && !getenv("SFFT_NO_COLS6K");
     if (!p->ax0.big) {
         pick_col_tile(p->ax0, &p->TC, &p->MS);
@@ -1457,6 +1459,19 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
         }
         const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
         hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, rw, grp, dst,
+                           p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
+    }
+    else if (p->rows6k) {
+        RowsArgs rw = ra;
+        for (int k = 0; k < nplanes; ++k) { if (!rw.wx[k]) rw.wx[k] = p->d_ones; if (!rw.wy[k]) rw.wy[k] = p->d_ones; }
+        RowGroups grp; grp.ngroups = 0;
+        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { grp.mom_out[u] = nullptr; grp.mom_nq[u] = 0; }
+        for (int k = 0; k < nplanes; ++k) {
+            if (k > 0 && ra.src[k] == ra.src[k - 1]) ++grp.count[grp.ngroups - 1];
+            else { grp.first[grp.ngroups] = k; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
+        }
+        const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
+        hipLaunchKernelGGL(rows_r2c_6144, dim3(8 * rp_per, grp.ngroups), dim3(384), F6K_LDS * sizeof(double), s, rw, grp, dst,
                            p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     else
