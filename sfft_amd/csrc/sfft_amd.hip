@@ -76,7 +76,7 @@ extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 #include "fft_generic.hpp"
 #include "fft_fourstep.hpp"
 #include "fft_r16_4096.hpp"
-#include "fft_r24_6144.hpp"
+#include "fft_r24.hpp"
 #include "greek.hpp"
 #include "fill.hpp"
 #include "solver.hpp"
@@ -218,8 +218,8 @@ struct sfft_plan {
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
-    int rows6k = 0;                     // 6144-point row axis on the register-resident kernel (env SFFT_NO_ROWS6K=1: the generic pass, A/B)
-    int cols6k = 0;                     // 6144-point column axis on the register-resident kernel (env SFFT_NO_COLS6K=1: the generic pass, A/B)
+    int rows_r24 = 0;                   // 16 / 24: 6144- / 9216-point row axis on the register-resident kernels of fft_r24.hpp (env SFFT_NO_ROWS_R24=1: the generic pass, A/B)
+    int cols_r24 = 0;                   // the same for the column axis (env SFFT_NO_COLS_R24=1)
     int no_wx_support = 0;              // env SFFT_NO_WX_SUPPORT=1: the generic weighted column pass reads rows whose row factor is zero too (A/B)
     std::vector<int> kbx_lo, kbx_hi;    // [nkx] first row / one past the last row where the kernel row factor is nonzero
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
@@ -719,8 +719,11 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->nt_rows = fft_threads(p->ax1.M);
         p->lds_rows = (size_t)axis_lds_len(p->ax1) * sizeof(cplx);
     }
-    p->rows6k = !p->ax1.big && !p->ax1.blue && p->ax1.M == 6144 && !p->no_fast_fft && !getenv("SFFT_NO_ROWS6K");
-    p->cols6k = !p->ax0.big && !p->ax0.blue && p->ax0.M == 6144 && !p->no_fast_fft && !getenv("SFFT_NO_COLS6K");
+    auto r24_q = [](const AxisHost& ax) { return (ax.big || ax.blue) ? 0 : ax.M == 6144 ? 16 : ax.M == 9216 ? 24 : 0; };
+    p->rows_r24 = (p->no_fast_fft || getenv("SFFT_NO_ROWS_R24")) ? 0 : r24_q(p->ax1);
+    p->cols_r24 = (p->no_fast_fft || getenv("SFFT_NO_COLS_R24")) ? 0 : r24_q(p->ax0);
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!p->ax0.big) {
         pick_col_tile(p->ax0, &p->TC, &p->MS);
         p->nt_cols = fft_threads(p->TC * p->ax0.M);
@@ -1461,18 +1464,16 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
         hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, rw, grp, dst,
                            p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
-    else if (p->rows6k) {
+    else if (p->rows_r24) {
         RowsArgs rw = ra;
         for (int k = 0; k < nplanes; ++k) { if (!rw.wx[k]) rw.wx[k] = p->d_ones; if (!rw.wy[k]) rw.wy[k] = p->d_ones; }
-        RowGroups grp; grp.ngroups = 0;
-        for (int u = 0; u < SFFT_MAX_PLANES; ++u) { grp.mom_out[u] = nullptr; grp.mom_nq[u] = 0; }
-        for (int k = 0; k < nplanes; ++k) {
-            if (k > 0 && ra.src[k] == ra.src[k - 1]) ++grp.count[grp.ngroups - 1];
-            else { grp.first[grp.ngroups] = k; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
-        }
         const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
-        hipLaunchKernelGGL(rows_r2c_6144, dim3(8 * rp_per, grp.ngroups), dim3(384), F6K_LDS * sizeof(double), s, rw, grp, dst,
-                           p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
+        if (p->rows_r24 == 16)
+            hipLaunchKernelGGL(rows_r2c_r24<16>, dim3(8 * rp_per * nplanes), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, rw, nplanes, dst,
+                               p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
+        else
+            hipLaunchKernelGGL(rows_r2c_r24<24>, dim3(8 * rp_per * nplanes), dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s, rw, nplanes, dst,
+                               p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     else
         hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
@@ -1559,9 +1560,14 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                 ++k;
             }
             if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
-            if (p->cols6k) {       // register-resident 6144-point columns, one per workgroup, 64 columns per (XCD-interleaved) column group
-                hipLaunchKernelGGL(cols_fwd_weighted_6144, dim3(64 * g.nout * ((p->Nh + 63) / 64)), dim3(384), F6K_LDS * sizeof(double), s,
-                                   p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
+            if (p->cols_r24) {     // register-resident 6144- / 9216-point columns, one per workgroup, 64 columns per (XCD-interleaved) column group
+                const dim3 grid(64 * g.nout * ((p->Nh + 63) / 64));
+                if (p->cols_r24 == 16)
+                    hipLaunchKernelGGL(cols_fwd_weighted_r24<16>, grid, dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s,
+                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
+                else
+                    hipLaunchKernelGGL(cols_fwd_weighted_r24<24>, grid, dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s,
+                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
                 continue;
             }
             hipLaunchKernelGGL(cols_fwd_weighted, dim3(8 * G * g.nout * ntg), dim3(p->nt_cols), p->lds_cols, s, p->d_stage, dst, g, p->N0, p->Nh,

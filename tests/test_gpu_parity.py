@@ -46,7 +46,7 @@ NAMES = golden_names()
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(8, 8), (64, 64), (128, 32), (48, 40), (45, 35), (100, 96), (512, 256), (300, 500),
                                    (1024, 2048), (4096, 64), (64, 4096), (4096, 4096), (4095, 4096), (8192, 16),
-                                   (6144, 40), (40, 6144), (9232, 64), (64, 9216), (4100, 5000), (4097, 24), (16, 12261), (4513, 32), (40, 4603),     # big axes (12261 = 3 * 61 * 67); primes up to 4608 through Bluestein on 9216 points
+                                   (6144, 40), (40, 6144), (6144, 6144), (9232, 64), (64, 9216), (4100, 5000), (4097, 24), (16, 12261), (4513, 32), (40, 4603),     # big axes (12261 = 3 * 61 * 67); primes up to 4608 through Bluestein on 9216 points
                                    (12, 24), (9, 18), (27, 24), (81, 162), (96, 1536), (1536, 96), (8748, 16), (16, 8748),
                                    (9216, 24), (2304, 3072)])   # last rows: 2^a*3^b axes (mixed-radix on-chip transform)
 @pytest.mark.parametrize("ij", [(0, 0), (2, 1)])
@@ -1215,6 +1215,20 @@ def test_four_step_column_axis_variants_agree(dev, env):
     pair = make_pair(*shape, seed=77, mask=True, density=400.0)
     new = _subtract_with_env(dev, {}, shape, w, 2, 1, pair)
     old = _subtract_with_env(dev, env, shape, w, 2, 1, pair)
+    assert np.max(np.abs(new[2] - old[2])) <= 1e-11 * np.max(np.abs(old[2]))
+    assert np.max(np.abs(new[3] - old[3])) <= 1e-11 * np.max(np.abs(old[3]))
+    assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
+
+
+@pytest.mark.parametrize("shape", [(6144, 96), (96, 6144), (9216, 80), (80, 9216)])
+def test_r24_axis_kernels_agree_with_generic_passes(dev, shape):
+    """6144- and 9216-point axes (configs 3 and 5): the register-resident 16 x 16 x 24 / 16 x 24 x 24 column and row kernels
+    (fft_r24.hpp) against the generic LDS-resident passes they replace.  Same linear system to rounding, same DIFF."""
+    from sfft_amd.utils.synthetic import make_pair
+    w = 3
+    pair = make_pair(*shape, seed=61, mask=True, density=400.0)
+    new = _subtract_with_env(dev, {}, shape, w, 2, 1, pair)
+    old = _subtract_with_env(dev, {"SFFT_NO_COLS_R24": "1", "SFFT_NO_ROWS_R24": "1"}, shape, w, 2, 1, pair)
     assert np.max(np.abs(new[2] - old[2])) <= 1e-11 * np.max(np.abs(old[2]))
     assert np.max(np.abs(new[3] - old[3])) <= 1e-11 * np.max(np.abs(old[3]))
     assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
