@@ -318,4 +318,96 @@ __global__ void __launch_bounds__(24 * Q, 3) rows_r2c_r24(RowsArgs a, int nplane
     }
 }
 
+// ================================================================================================
+// The 577-point sub-transform of a four-step column axis (9232 = 16 x 577, config 5) by Rader's algorithm, in registers:
+// the two 576-point transforms of the cyclic convolution are 24 x 24, 24 threads per sequence with 24 points each, and every stage is
+// a dft24 on a thread's own registers -- LDS carries one exchange per transform (real and imaginary parts one after the other) where
+// strided_rader577 makes six passes of three stages each over an LDS-resident tile.  Eight sequences (adjacent columns) per workgroup
+// of 192 threads, thread = 8 i + sequence: every load and store instruction moves whole 128-byte rows of the eight columns, gathered /
+// scattered in Rader order straight from / to global memory (gin[r] = g^r, gout[q] = g^-q behind rin / rout).
+//   a[r] = x[g^r];  A = FFT576(a);  c = conj(A .* bf);  c[0] += conj(x[0]);  C = FFT576(c);  X[g^-q] = conj(C[q]);  X[0] = x[0] + A[0]
+// (bf = FFT576(b) / 576, b[q] = W577^(g^-q), bf[0] = -1 / 576: see lds_rader577).  Same PassDesc as strided_rader577 (mode 2, no weights).
+// ================================================================================================
+#define RDR_SEQ 8
+#define RDR_NT (24 * RDR_SEQ)
+#define RDR_SS 616                                   // doubles per sequence: 24 rows of 25 (padded), = 8 mod 32 so that the eight sequences spread over the banks
+
+// one 576-point transform step: t[s] (this thread's stage-1 outputs, s < 24, already twiddled) -> z[r] = the value of thread r, slot of this thread
+__device__ __forceinline__ void rdr_exchange(const cplx (&t)[24], cplx (&z)[24], double* sb, int i)
+{
+    double zr[24];
+#pragma unroll
+    for (int sx = 0; sx < 24; ++sx) sb[25 * sx + i] = t[sx].x;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 24; ++r) zr[r] = sb[25 * i + r];
+    __syncthreads();
+#pragma unroll
+    for (int sx = 0; sx < 24; ++sx) sb[25 * sx + i] = t[sx].y;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 24; ++r) z[r] = make_double2(zr[r], sb[25 * i + r]);
+    __syncthreads();
+}
+
+// in: y[r] = x[i + 24 r] of a 576-point sequence (thread i of its 24).  out: F[r] = X[i + 24 r].
+__device__ __forceinline__ void rdr_fft576(cplx (&y)[24], cplx (&F)[24], double* sb, int i, const cplx* __restrict__ tw)
+{
+    cplx G[3][8], t[24], z[24];
+    dft24_g(y, G);
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[d + 8 * c] = dft24_x(G, d, c);
+    twiddle24(t, tw, i);                             // W576^(i s)
+    rdr_exchange(t, z, sb, i);
+    dft24_g(z, G);
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) F[d + 8 * c] = dft24_x(G, d, c);
+}
+
+__global__ void __launch_bounds__(RDR_NT, 3) strided_rader577_r24(const cplx* __restrict__ in, cplx* __restrict__ out, PassDesc d, AxisDev ax)
+{
+    __shared__ double lds[RDR_SEQ * RDR_SS];
+    constexpr int N = 577;
+    const int tid = threadIdx.x, seq = tid & (RDR_SEQ - 1), i = tid >> 3;
+    const int j = (int)blockIdx.y;
+    const int line = (int)blockIdx.x * RDR_SEQ + seq;
+    const bool lok = line < d.nlines;
+    const int* __restrict__ gin = ax.rin + N;
+    const int* __restrict__ gout = ax.rout + N;
+    // (uniform base + 32-bit lane offset, see at_byte: a plane is < 4 GB)
+    const cplx* __restrict__ pin = in + (long long)blockIdx.x * RDR_SEQ * d.lst_in + (long long)j * d.js_in;
+    const unsigned lin = (unsigned)((lok ? seq : d.nlines - 1 - (int)blockIdx.x * RDR_SEQ) * (int)d.lst_in) * (unsigned)sizeof(cplx);
+    const unsigned ein = (unsigned)d.es_in * (unsigned)sizeof(cplx);
+    double* sb = lds + seq * RDR_SS;
+    cplx y[24], F[24];
+#pragma unroll
+    for (int r = 0; r < 24; ++r) y[r] = *at_byte(pin, lin + (unsigned)gin[i + 24 * r] * ein);
+    cplx x0 = *at_byte(pin, lin);
+    if (d.conj_in) {
+#pragma unroll
+        for (int r = 0; r < 24; ++r) y[r].y = -y[r].y;
+        x0.y = -x0.y;
+    }
+    rdr_fft576(y, F, sb, i, ax.tw);                  // F[k] = A[i + 24 k]
+    const cplx A0 = F[0];                            // (thread i = 0: A[0] = sum of a)
+#pragma unroll
+    for (int k = 0; k < 24; ++k) y[k] = cconj(cmul(F[k], ax.bf[i + 24 * k]));
+    if (i == 0) { y[0].x += x0.x; y[0].y -= x0.y; }
+    rdr_fft576(y, F, sb, i, ax.tw);                  // conj(F[k]) = x[0] + (a (*) b)[i + 24 k] = X[g^-(i + 24 k)]
+    if (!lok) return;
+    cplx* __restrict__ pout = out + (long long)blockIdx.x * RDR_SEQ * d.lst_out + (long long)j * d.js_out;
+    const unsigned lout = (unsigned)(seq * (int)d.lst_out) * (unsigned)sizeof(cplx), eout = (unsigned)d.es_out * (unsigned)sizeof(cplx);
+    const double sy = d.conj_out ? d.scale : -d.scale;          // (the conjugation of the second transform, and the caller's)
+#pragma unroll
+    for (int k = 0; k < 24; ++k) *at_byte(pout, lout + (unsigned)gout[i + 24 * k] * eout) = make_double2(F[k].x * d.scale, F[k].y * sy);
+    if (i == 0) {
+        const cplx X0 = cadd(x0, A0);
+        *at_byte(pout, lout) = make_double2(X0.x * d.scale, d.conj_out ? -X0.y * d.scale : X0.y * d.scale);
+    }
+}
+
 #endif

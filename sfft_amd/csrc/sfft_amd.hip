@@ -426,13 +426,14 @@ static int build_rader_axis(sfft_plan* p, AxisHost& ax, int N)
     }
     if (!g) return set_err(SFFT_ERR_INVALID_ARG, "Rader: length is not prime");
     const long long ginv = powmod(g, N - 2);
-    std::vector<int> rin(N, 0), rout(N, 0);         // LDS slots of input / output element n (strided_rader577)
+    std::vector<int> rin(2 * N, 0), rout(2 * N, 0); // [0, N): LDS slots of input / output element n (strided_rader577); [N, 2N - 1): the inverse
+                                                    // maps, element of slot r: g^r, g^-q (strided_rader577_r24)
     std::vector<long double> br(M), bi(M);
-    for (int r = 0; r < M; ++r) rin[(int)powmod(g, r)] = r;
+    for (int r = 0; r < M; ++r) { rin[(int)powmod(g, r)] = r; rin[N + r] = (int)powmod(g, r); }
     rin[0] = RADER_XS; rout[0] = RADER_XS;
     for (int q = 0; q < M; ++q) {
         const int n = (int)powmod(ginv, q);
-        rout[n] = q;
+        rout[n] = q; rout[N + q] = n;
         const long double ang = -2.0L * PI * n / N;   // b[q] = W_N^(g^-q)
         br[q] = cosl(ang); bi[q] = sinl(ang);
     }
@@ -447,12 +448,12 @@ static int build_rader_axis(sfft_plan* p, AxisHost& ax, int N)
     for (int k = 0; k < N; ++k) { const long double ang = -2.0L * PI * k / N; root[k] = make_double2((double)cosl(ang), (double)sinl(ang)); }
     int rc;
     if ((rc = dev_alloc(p, &ax.tw, M)) || (rc = dev_alloc(p, &ax.bf, M)) || (rc = dev_alloc(p, &ax.root, N)) ||
-        (rc = dev_alloc(p, &ax.rin, N)) || (rc = dev_alloc(p, &ax.rout, N))) return rc;
+        (rc = dev_alloc(p, &ax.rin, 2 * N)) || (rc = dev_alloc(p, &ax.rout, 2 * N))) return rc;
     HIPCHK(hipMemcpy(ax.tw, tw.data(), M * sizeof(cplx), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ax.bf, bf.data(), M * sizeof(cplx), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ax.root, root.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ax.rin, rin.data(), N * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ax.rout, rout.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ax.rin, rin.data(), 2 * N * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ax.rout, rout.data(), 2 * N * sizeof(int), hipMemcpyHostToDevice));
     return SFFT_OK;
 }
 
@@ -1382,6 +1383,10 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
     pick_col_tile(sub, &TC, &MS, sub.blue ? std::min((size_t)4800, (size_t)LDS_COL_ELEMS) : 0);
     if (sub.rader) {                                // RADER_TC sequences of RADER_XS + 1 elements (fft_fourstep.hpp)
         TC = RADER_TC; MS = (RADER_XS + 1 + 15) / 16 * 16 + 16 / TC;
+        if (d.mode == 2 && !d.twiddle && !d.w && sub.N == 577 && !getenv("SFFT_NO_RADER_R24")) {       // ... in registers, 24 x 24
+            hipLaunchKernelGGL(strided_rader577_r24, dim3((d.nlines + RDR_SEQ - 1) / RDR_SEQ, d.J), dim3(RDR_NT), 0, s, in, out, d, axis_dev(sub));
+            return;
+        }
         if (d.mode == 2 && !d.twiddle) {            // (the second pass of a column transform: its own kernel)
             hipLaunchKernelGGL(strided_rader577, dim3((d.nlines + TC - 1) / TC, d.J), dim3(RADER_NT), (size_t)TC * MS * sizeof(cplx), s, in, out, d,
                                axis_dev(sub), MS);

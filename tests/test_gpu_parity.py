@@ -1202,9 +1202,9 @@ def test_generic_fft_variants_agree(dev, shape, w):
     assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
 
 
-@pytest.mark.parametrize("env", [{"SFFT_NO_RADER": "1"}, {"SFFT_NO_DFT16_REGS": "1"}, {"SFFT_NO_STAGED": "1"}, {"SFFT_NO_VCONV": "1"},
+@pytest.mark.parametrize("env", [{"SFFT_NO_RADER_R24": "1"}, {"SFFT_NO_RADER": "1"}, {"SFFT_NO_DFT16_REGS": "1"}, {"SFFT_NO_STAGED": "1"}, {"SFFT_NO_VCONV": "1"},
                                  {"SFFT_NO_VCONV": "1", "SFFT_NO_RADER": "1", "SFFT_NO_DFT16_REGS": "1"}],
-                         ids=["bluestein577", "lds16", "unstaged", "fourier_apply", "fourier_apply_round2_kernels"])
+                         ids=["rader577_lds", "bluestein577", "lds16", "unstaged", "fourier_apply", "fourier_apply_round2_kernels"])
 def test_four_step_column_axis_variants_agree(dev, env):
     """9232 = 16 x 577 rows (config 5's column axis): Rader's 576-point sub-transform against Bluestein on 2048 points, the
     register-only 16-point first pass against the LDS one, staged against per-plane forward transforms, and the Fourier-domain
