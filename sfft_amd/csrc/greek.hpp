@@ -1010,6 +1010,7 @@ __global__ void __launch_bounds__(256) greek_g1_row0(const cplx* __restrict__ sp
 // Greek stage 2: patch[r][e] = scale * sum_{m < Nh} wgt[m] * Re( W1^(m e) * y[m] * sum_chunks G[r][m] ),  |e| <= h.
 // wgt = 1 for the self-conjugate columns (m = 0, and m = N1/2 when N1 is even), 2 otherwise;
 // y[m] = conj(tscale * Yq[q][m]) for Gamma jobs, 1 otherwise.
+template <int CB8>      // chunk partials per batch of loads (4 when the launch has at most four chunks, else 8)
 __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, const G1Pass* __restrict__ passes,
                                                 const PatchJob* __restrict__ jobs, int job0,
                                                 double* __restrict__ patches, int Nh, int Nhp, int N1, int S,
@@ -1033,12 +1034,12 @@ __global__ void __launch_bounds__(256) greek_g2(const cplx* __restrict__ Gp, con
         const int ne = min(16, h - e0);   // lags e0+1 .. e0+ne, plus lag 0 when e0 == 0
         for (int m = tid; m < Nh; m += 256) {
             double gx = 0.0, gy = 0.0;
-            for (int c0 = 0; c0 < S; c0 += 8) {         // eight chunk partials per batch: the loads are independent and issue together
-                cplx v[8];
+            for (int c0 = 0; c0 < S; c0 += CB8) {       // a batch of chunk partials: the loads are independent and issue together
+                cplx v[CB8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = g[(size_t)min(c0 + c, S - 1) * PH * Nhp + m];
+                for (int c = 0; c < CB8; ++c) v[c] = g[(size_t)min(c0 + c, S - 1) * PH * Nhp + m];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
+                for (int c = 0; c < CB8; ++c) {
                     const double f = (c0 + c < S) ? 1.0 : 0.0;
                     gx = fma(v[c].x, f, gx); gy = fma(v[c].y, f, gy);
                 }

@@ -961,8 +961,6 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->fa.reg_coef = 0.0; p->fa.ireg = nullptr; p->fa.sst = p->fa.csst = p->fa.dsst = nullptr;
         p->n_patches = poff;
         (void)PHo; (void)PHg;
-        PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
-        PLAN_HIP(hipMemcpy(p->d_passes, p->passes.data(), p->passes.size() * sizeof(G1Pass), hipMemcpyHostToDevice));
         if (p->g1_mfma >= 3 && hO >= 9 && hO <= 32) {
             // Pass groups of the Omega launch (greek_g1_mfma4g): an edge (x, y) with the dual-diagonal pass of the same two planes;
             // then triangles (x,y), (y,z), (x,z) among the remaining ordinary passes, greedily; then pairs of passes that share a
@@ -1056,9 +1054,27 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             }
             if (getenv("SFFT_G1_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_g1trace, (size_t)3 * 65536)); PLAN_HIP(hipMemset(p->d_g1trace, 0, (size_t)3 * 65536 * 8)); }
             p->n_groups = (int)groups.size();
+            // (Uneven row chunks -- S - 1 long ones and a short last one, so that the long layers hold most wave slots for the whole launch
+            //  and the short waves cycle through the rest: 912 + 912 + 224 row pairs instead of 4 x 512 at 4096^2, which a slot model
+            //  prices at 0.89 of the launch -- were measured and are SLOWER: 0.44 - 0.45 ms against 0.34; config 5: 22 ms against 7.7.  Equal
+            //  chunks of 2 / 3 / 4 / 8 all take 0.34 - 0.35 ms: the launch is bound by instruction issue per SIMD,
+            //  not by how its waves fill the slots.  SFFT_G1_RPC=<rows per chunk> keeps the experiment reproducible.)
+            if (const char* ev = getenv("SFFT_G1_RPC")) {
+                const int v = atoi(ev);
+                if (p->g1_dit && N0 % 16 == 0 && v >= 16 * DF_BURST && v % (16 * DF_BURST) == 0 && v <= N0) {
+                    const int S2 = (N0 + v - 1) / v;
+                    if (S2 >= 1 && S2 <= 16) {       // the partial-sum offsets of the passes are linear in the number of chunks
+                        for (G1Pass& d : p->passes) { d.gp_off = d.gp_off / S * S2; d.gp_off2 = d.gp_off2 / S * S2; }
+                        goff = goff / S * S2;
+                        S = S2; p->S = S2; p->rows_per_chunk = v;
+                    }
+                }
+            }
             PLAN_TRY(dev_alloc(p, &p->d_groups, groups.size()));
             PLAN_HIP(hipMemcpy(p->d_groups, groups.data(), groups.size() * sizeof(G1Group), hipMemcpyHostToDevice));
         }
+        PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
+        PLAN_HIP(hipMemcpy(p->d_passes, p->passes.data(), p->passes.size() * sizeof(G1Pass), hipMemcpyHostToDevice));
         PLAN_TRY(dev_alloc(p, &p->d_jobs, p->jobs.size()));
         PLAN_HIP(hipMemcpy(p->d_jobs, p->jobs.data(), p->jobs.size() * sizeof(PatchJob), hipMemcpyHostToDevice));
         PLAN_TRY(dev_alloc(p, &p->d_gp, (size_t)goff));
@@ -2114,10 +2130,14 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G2, s);
-        hipLaunchKernelGGL(greek_g2, dim3(4 * p->w + 1, p->n_omg), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
-                           p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
-        hipLaunchKernelGGL(greek_g2, dim3(2 * p->w + 1, (int)p->jobs.size() - p->n_omg), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs,
-                           p->n_omg, p->d_patches, p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
+        // one launch for all patch jobs: the grid is as tall as the widest patch (4 w + 1 rows), the workgroups past a narrower
+        // job's 2 w + 1 rows return at once (two launches ran one after the other, each far from filling the chip)
+        if (p->S <= 4)
+            hipLaunchKernelGGL(greek_g2<4>, dim3(4 * p->w + 1, (int)p->jobs.size()), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
+                               p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
+        else
+            hipLaunchKernelGGL(greek_g2<8>, dim3(4 * p->w + 1, (int)p->jobs.size()), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
+                               p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
         if (p->omg_reduce) {
             if (p->s2 && !p->no_overlap && s != nullptr) HIPCHK(hipStreamWaitEvent(s, p->ev_strip, 0));
             const int PHo = 2 * p->omgr.h + 1;
