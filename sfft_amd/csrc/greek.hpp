@@ -649,8 +649,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         wx[0] = SFFT_SWZ(wx0, 0); wx[1] = SFFT_SWZ(wx0, 1); wx[2] = SFFT_SWZ(wx0, 2); wx[3] = SFFT_SWZ(wx0, 3);
         wy[0] = SFFT_SWZ(wy0, 0); wy[1] = SFFT_SWZ(wy0, 1); wy[2] = SFFT_SWZ(wy0, 2); wy[3] = SFFT_SWZ(wy0, 3);
 #undef SFFT_SWZ
-        auto slot = [&](auto SL, bool dual) {
+        // DU: 0 = an ordinary pass, 1 = a dual pass, 2 = decided at run time (d0).  Only a group of one pass on two planes (mode 0) needs
+        // the run-time form; written with a run-time flag everywhere, every slot-0 step computed BOTH products and selected between them
+        // (8 more fp64 instructions and 8 v_cndmask per step: this launch is bound by vector / matrix instruction issue, see DESIGN).
+        auto slot = [&](auto SL, auto DU) {
             constexpr int sl = decltype(SL)::value;
+            constexpr int du = decltype(DU)::value;
+            const bool dual = du == 2 ? d0 : (du == 1);
             const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode >= 2) ? 1 : 2];
             // dual: H.x = |a|^2, H.y = |b|^2 (two real products side by side)
             const cplx H = dual ? make_double2(fma(va.x, va.x, va.y * va.y), fma(vb.x, vb.x, vb.y * vb.y)) : cmulc(va, vb);
@@ -681,12 +686,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
                 Sx[sl][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], H.y, Sx[sl][3][gq], 0, 0, 0);      // S4   (dual: S1 of |B|^2)
             }
         };
-        if (use0) slot(std::integral_constant<int, 0>{}, d0);
+        using DU0 = std::integral_constant<int, 0>; using DU1 = std::integral_constant<int, 1>; using DU2 = std::integral_constant<int, 2>;
+        if (mode == 0) { if (use0) slot(std::integral_constant<int, 0>{}, DU2{}); }
         if (mode == 1) {
-            if (use1) slot(std::integral_constant<int, 1>{}, false);
-            if (use2) slot(std::integral_constant<int, 2>{}, false);
+            if (use0) slot(std::integral_constant<int, 0>{}, DU0{});
+            if (use1) slot(std::integral_constant<int, 1>{}, DU0{});
+            if (use2) slot(std::integral_constant<int, 2>{}, DU0{});
         }
-        if (mode >= 2) slot(std::integral_constant<int, 2>{}, false);
+        if (mode >= 2) { slot(std::integral_constant<int, 0>{}, DU1{}); slot(std::integral_constant<int, 2>{}, DU0{}); }
         if (mode == 3) {
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts) {
@@ -798,6 +805,348 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAV
         }
     }
     if (trace && lane == 0) { trace[3 * (size_t)blockIdx.x] = t_start; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)logical; }
+}
+
+// ---- the grouped Omega launch with a tile's planes shared through LDS (round 3) ------------------------------------------------------
+// greek_g1_mfma4g is bound by the memory side: every wave loads its three planes itself, so a tile's planes pass the CU's L1 three
+// times, and the sibling waves of a tile run at their own pace (and, with many groups per tile, start a good part of a wave's life
+// apart), so the XCD's L2 does not hold the rows between the first and the last reader: 1.4x (Fij = 6) to 7.5x (Fij = 25) the plane
+// bytes come from HBM.  Neither fewer vector instructions (compile-time dual flag), nor one wave per SIMD with loads two steps ahead,
+// nor other chunk counts moved it (0.33 - 0.35 ms at 4096^2 in every case).
+// Here a WORKGROUP of eight waves owns a "block" of up to eight pass groups of one tile whose planes (at most G1W_NP) are loaded ONCE
+// per step -- wave w loads plane w (and w + 8) of the block's list for the step's 4 + 4 rows, 2 KB -- into a two-stage LDS ring
+// together with the step's twiddles; after one barrier per step every wave takes the operands of its three slots from LDS.  The waves
+// of a workgroup are in lockstep by construction.  With more than one block per tile (Fij = 25: 113 groups = 15 blocks) the launch is
+// PERSISTENT: one workgroup per CU, the workgroups of an XCD form `tpr` teams of `nblk` that start their tiles together and walk them in
+// step (equal work per block), so a tile's planes are in flight for all its blocks at the same time.  Global loads run two steps
+// ahead of their use (a wave holds 2 x 2 complex values per step in flight instead of 2 x 7).
+// DIT, whole 8-row steps only (g1_decimated); HALF / lag0 as in greek_g1_mfma4g.
+// MEASURED (profiles/r03_d_*): slower than greek_g1_mfma4g everywhere -- 0.505 vs 0.339 ms at 4096^2 (Fij = 6, one block per tile), 14.9 vs
+// 10.3 ms at config 3 (15 blocks, persistent), 10.7 vs 7.8 ms at config 5.  A step is 4140 cycles here against 2690: the barrier puts all
+// eight waves into the same phase, the 56 KB of operands a step reads from LDS (440 cycles of its bandwidth) and the barrier skew are
+// exposed in front of every step's matrix instructions, and the one-block case leaves an eighth of the wave slots without matrix
+// work.  The launch needs its memory side (~0.30 ms alone) AND its instruction issue (~0.23 ms alone) to overlap, which independent
+// waves do better than lockstep ones.  Kept behind SFFT_G1_WG=1 with its parity test; not the default.
+#define G1W_NP 15
+struct G1Blk { int g0, ng, np; int plane[G1W_NP]; };
+
+// TWO: blocks have more than eight LDS items (planes + twiddles), a wave loads two of them per step.  (The loads of a step are
+// unconditional -- a wave without an item re-reads a valid address and does not store it: register values that are only
+// conditionally written go to scratch.)
+template <bool HALF, bool TWO>
+__global__ void __launch_bounds__(512) greek_g1_mfma4w(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, const G1Group* __restrict__ groups,
+                                                        const G1Blk* __restrict__ blks, int nblk, cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
+                                                        int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S, int lag0, int tpr, int rounds, int ni)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = ncb * S;
+    int tile_first, tile_step, tile_end, blk;
+    if (rounds > 0) {          // persistent: the XCD's workgroups in teams of nblk, contiguous tile ranges per XCD
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int tx = (ntiles + 7) >> 3;
+        const int t_in = slot / nblk;
+        blk = slot - t_in * nblk;
+        tile_first = xcd * tx + t_in; tile_step = tpr; tile_end = min(ntiles, (xcd + 1) * tx);
+    } else {                   // one workgroup per (tile, block), the blocks of a tile back to back on one XCD
+        const int total = ntiles * nblk, per = (total + 7) >> 3;
+        const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (logical >= total) return;
+        const int t = logical / nblk;
+        blk = logical - t * nblk;
+        tile_first = t; tile_step = 1; tile_end = t + 1;
+    }
+    const G1Blk* __restrict__ bk = blks + blk;
+    const int np = bk->np, ng = bk->ng;
+    const bool has = wv < ng;
+    const G1Group gr = groups[bk->g0 + (has ? wv : 0)];
+    int it0 = 0, it1 = 0, it2 = 0;                      // LDS items of the group's three planes
+    for (int j = 0; j < np; ++j) { const int pl = bk->plane[j]; if (pl == gr.plane[0]) it0 = j; if (pl == gr.plane[1]) it1 = j; if (pl == gr.plane[2]) it2 = j; }
+    const bool use0 = (gr.mask & 1) != 0, use1 = (gr.mask & 2) != 0, use2 = (gr.mask & 4) != 0;
+    const int k0 = use0 ? gr.pass[0] : (use1 ? gr.pass[1] : gr.pass[2]), k1 = use1 ? gr.pass[1] : k0, k2 = use2 ? gr.pass[2] : k0;
+    const long long go0 = passes[k0].gp_off, go1 = passes[k1].gp_off, go2 = passes[k2].gp_off;
+    const long long gd0 = passes[k0].gp_off2;
+    const bool d0 = use0 && passes[k0].dual != 0;
+    const int h = passes[k0].h, PH = 2 * h + 1;
+    const bool theta = gr.tpass[0] >= 0;
+    const bool three = gr.plane[2] != gr.plane[0];
+    const long long gt0 = theta ? passes[gr.tpass[0]].gp_off : 0, gt1 = theta ? passes[gr.tpass[1]].gp_off : 0;
+    const int ht = gr.ht, PHt = 2 * ht + 1;
+    const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
+    const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
+    const unsigned halfb = (unsigned)(N0 / 2) * rsb;
+    const int dlag = (n < 8) ? 8 * (n >> 2) + 2 * ((n & 3) + 1) : 8 * ((n >> 2) - 2) + 2 * (n & 3) + 1;
+    const unsigned tcolb = (unsigned)min(lag0 + dlag, HM - 1) * (unsigned)sizeof(cplx);
+    // the (at most two) items this wave loads: item j < np = plane j of the block, item np = the twiddles
+    const int itA = wv, itB = wv + 8;
+    const bool onA = itA <= np, onB = TWO && itB <= np, twA = itA == np, twB = TWO && itB == np;
+    const unsigned hoffA = twA ? 0u : halfb, hoffB = twB ? 0u : halfb;
+    const char* __restrict__ baseA = twA ? reinterpret_cast<const char*>(W0tab) : reinterpret_cast<const char*>(spec + (size_t)bk->plane[min(itA, np - 1)] * plane_sz);
+    const char* __restrict__ baseB = twB ? reinterpret_cast<const char*>(W0tab) : reinterpret_cast<const char*>(spec + (size_t)bk->plane[min(itB, np - 1)] * plane_sz);
+    const unsigned sstride = (unsigned)ni * 2048u;
+    // LDS slots of the two values an item loads per step: a plane's rows x' and x' + N0 / 2; the twiddles and, in the unused second half of
+    // the twiddle item, a dump for the second twiddle load and for waves without an item (their stores are unconditional too: a
+    // conditional LDS store sends the loaded values through scratch)
+    const unsigned dump = (unsigned)np * 2048u + 1024u;
+    char* const ldsA0 = smem_raw + (onA ? (unsigned)itA * 2048u : dump) + (unsigned)lane * 16u;
+    char* const ldsA1 = smem_raw + ((onA && !twA) ? (unsigned)itA * 2048u + 1024u : dump) + (unsigned)lane * 16u;
+    char* const ldsB0 = smem_raw + (onB ? (unsigned)itB * 2048u : dump) + (unsigned)lane * 16u;
+    char* const ldsB1 = smem_raw + ((onB && !twB) ? (unsigned)itB * 2048u + 1024u : dump) + (unsigned)lane * 16u;
+    const char* const rd0 = smem_raw + (unsigned)it0 * 2048u + (unsigned)lane * 16u;
+    const char* const rd1 = smem_raw + (unsigned)it1 * 2048u + (unsigned)lane * 16u;
+    const char* const rd2 = smem_raw + (unsigned)it2 * 2048u + (unsigned)lane * 16u;
+    const char* const rdw = smem_raw + (unsigned)np * 2048u + (unsigned)lane * 16u;
+
+    struct LoadSet { cplx tw, v[3], u[3]; };
+    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
+    const int chunk = tile / ncb;
+    const int m0 = (tile - chunk * ncb) * 16;
+    const int lb = chunk * (rows_per_chunk / 2);
+    const int le = min(N0 / 2, lb + rows_per_chunk / 2);
+    const int m = m0 + n;
+    const bool act = m < Nh;
+    const unsigned cob = (unsigned)(lay.col(act ? m : Nh - 1) * sizeof(cplx));
+    const unsigned r0 = (unsigned)(lb + kq);
+    const unsigned prow_max = cob + (unsigned)(N0 / 2 - 1) * rsb, trow_max = tcolb + (unsigned)(N0 - 1) * hmb;
+    unsigned offA = twA ? tcolb + r0 * hmb : cob + r0 * rsb, offB = twB ? tcolb + r0 * hmb : cob + r0 * rsb;
+    const unsigned incA = twA ? 4u * hmb : 4u * rsb, incB = twB ? 4u * hmb : 4u * rsb;
+    const unsigned maxA = twA ? trow_max : prow_max, maxB = twB ? trow_max : prow_max;
+    d4v Sx[3][4];
+    double g0x[3], g0y[3];
+    double St[2][4][2], t0x[2] = {0.0, 0.0}, t0y[2] = {0.0, 0.0};
+#pragma unroll
+    for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) St[ts][q][0] = St[ts][q][1] = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Sx[sl][q] = (d4v){0.0, 0.0, 0.0, 0.0};
+        g0x[sl] = g0y[sl] = 0.0;
+    }
+    auto run = [&](auto MODE) {
+    constexpr int mode = decltype(MODE)::value;      // -1: no group (loads and barriers only); 0 .. 3 as in greek_g1_mfma4g
+    constexpr bool three_c = mode == 1 || mode == 3;
+    // (macros on plain values, not lambdas on a struct: with the barriers of this loop between them the struct stayed in scratch)
+#define G1W_ISSUE(A0, A1, B0, B1) do { \
+        A0 = *reinterpret_cast<const cplx*>(baseA + offA); \
+        A1 = *reinterpret_cast<const cplx*>(baseA + (offA + hoffA)); \
+        offA = min(offA + incA, maxA); \
+        if (TWO) { \
+            B0 = *reinterpret_cast<const cplx*>(baseB + offB); \
+            B1 = *reinterpret_cast<const cplx*>(baseB + (offB + hoffB)); \
+            offB = min(offB + incB, maxB); \
+        } } while (0)
+#define G1W_STASH(A0, A1, B0, B1, STAGE) do { \
+        *reinterpret_cast<cplx*>(ldsA0 + (STAGE) * sstride) = A0; \
+        *reinterpret_cast<cplx*>(ldsA1 + (STAGE) * sstride) = A1; \
+        if (TWO) { \
+            *reinterpret_cast<cplx*>(ldsB0 + (STAGE) * sstride) = B0; \
+            *reinterpret_cast<cplx*>(ldsB1 + (STAGE) * sstride) = B1; \
+        } } while (0)
+    auto fetch = [&](LoadSet& L, unsigned stage) {
+        const unsigned so = stage * sstride;
+        L.tw = *reinterpret_cast<const cplx*>(rdw + so);
+        L.v[0] = *reinterpret_cast<const cplx*>(rd0 + so); L.u[0] = *reinterpret_cast<const cplx*>(rd0 + so + 1024u);
+        L.v[1] = *reinterpret_cast<const cplx*>(rd1 + so); L.u[1] = *reinterpret_cast<const cplx*>(rd1 + so + 1024u);
+        if (three_c) { L.v[2] = *reinterpret_cast<const cplx*>(rd2 + so); L.u[2] = *reinterpret_cast<const cplx*>(rd2 + so + 1024u); }
+        else { L.v[2] = make_double2(0.0, 0.0); L.u[2] = make_double2(0.0, 0.0); }
+    };
+    auto compute = [&](const LoadSet& L) {
+        double wx[4], wy[4];
+#define SFFT_SWZ(v, G) __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x13 | ((4 * (G)) << 5)), \
+                                        __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x13 | ((4 * (G)) << 5)))
+        wx[0] = SFFT_SWZ(L.tw.x, 0); wx[1] = SFFT_SWZ(L.tw.x, 1); wx[2] = SFFT_SWZ(L.tw.x, 2); wx[3] = SFFT_SWZ(L.tw.x, 3);
+        wy[0] = SFFT_SWZ(L.tw.y, 0); wy[1] = SFFT_SWZ(L.tw.y, 1); wy[2] = SFFT_SWZ(L.tw.y, 2); wy[3] = SFFT_SWZ(L.tw.y, 3);
+#undef SFFT_SWZ
+        auto slot = [&](auto SL, auto DU) {
+            constexpr int sl = decltype(SL)::value;
+            constexpr int du = decltype(DU)::value;
+            const bool dual = du == 2 ? d0 : (du == 1);
+            const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode >= 2) ? 1 : 2];
+            const cplx ua = L.u[sl == 1 ? 1 : 0], ub = L.u[(sl == 0 || mode >= 2) ? 1 : 2];
+            const cplx H = dual ? make_double2(fma(va.x, va.x, va.y * va.y), fma(vb.x, vb.x, vb.y * vb.y)) : cmulc(va, vb);
+            const cplx Hh = dual ? make_double2(fma(ua.x, ua.x, ua.y * ua.y), fma(ub.x, ub.x, ub.y * ub.y)) : cmulc(ua, ub);
+            const cplx Ye = make_double2(H.x + Hh.x, H.y + Hh.y), Yo = make_double2(H.x - Hh.x, H.y - Hh.y);
+            g0x[sl] += Ye.x;
+            g0y[sl] += Ye.y;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (HALF && (gq & 1)) continue;
+                const double bx = gq < 2 ? Ye.x : Yo.x, by = gq < 2 ? Ye.y : Yo.y;
+                Sx[sl][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], bx, Sx[sl][0][gq], 0, 0, 0);
+                Sx[sl][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], by, Sx[sl][1][gq], 0, 0, 0);
+                Sx[sl][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], bx, Sx[sl][2][gq], 0, 0, 0);
+                Sx[sl][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], by, Sx[sl][3][gq], 0, 0, 0);
+            }
+        };
+        using DU0 = std::integral_constant<int, 0>; using DU1 = std::integral_constant<int, 1>; using DU2 = std::integral_constant<int, 2>;
+        if (mode == 0) { if (use0) slot(std::integral_constant<int, 0>{}, DU2{}); }
+        if (mode == 1) {
+            if (use0) slot(std::integral_constant<int, 0>{}, DU0{});
+            if (use1) slot(std::integral_constant<int, 1>{}, DU0{});
+            if (use2) slot(std::integral_constant<int, 2>{}, DU0{});
+        }
+        if (mode >= 2) { slot(std::integral_constant<int, 0>{}, DU1{}); slot(std::integral_constant<int, 2>{}, DU0{}); }
+        if (mode == 3) {
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts) {
+                const cplx H = cmulc(L.v[ts], L.v[2]);           // FI_x conj(FJ)
+                const cplx Hh = cmulc(L.u[ts], L.u[2]);
+                const cplx Ye = make_double2(H.x + Hh.x, H.y + Hh.y), Yo = make_double2(H.x - Hh.x, H.y - Hh.y);
+                t0x[ts] += Ye.x;
+                t0y[ts] += Ye.y;
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    const double bx = gq == 0 ? Ye.x : Yo.x, by = gq == 0 ? Ye.y : Yo.y;
+                    St[ts][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[2 * gq], bx, St[ts][0][gq], 0, 0, 0);
+                    St[ts][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[2 * gq], by, St[ts][1][gq], 0, 0, 0);
+                    St[ts][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[2 * gq], bx, St[ts][2][gq], 0, 0, 0);
+                    St[ts][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[2 * gq], by, St[ts][3][gq], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // steps i (4 + 4 rows each): global loads of step i + 2 and the LDS stage of step i + 1 are under way while step i is computed
+    cplx pa0, pa1, pb0 = make_double2(0.0, 0.0), pb1 = make_double2(0.0, 0.0);      // loads in flight: set P
+    cplx qa0, qa1, qb0 = make_double2(0.0, 0.0), qb1 = make_double2(0.0, 0.0);      //                   set Q
+    G1W_ISSUE(pa0, pa1, pb0, pb1);   // step 0
+    G1W_ISSUE(qa0, qa1, qb0, qb1);   // step 1
+    __syncthreads();                 // (the previous tile's last reads of the ring are done)
+    G1W_STASH(pa0, pa1, pb0, pb1, 0u);
+    G1W_ISSUE(pa0, pa1, pb0, pb1);   // step 2
+    for (int l = lb; l < le; l += 8) {
+        LoadSet L;
+        __syncthreads();             // stage 0 holds step i; nobody reads stage 1 any more
+        if (mode >= 0) fetch(L, 0u);
+        G1W_STASH(qa0, qa1, qb0, qb1, 1u);
+        G1W_ISSUE(qa0, qa1, qb0, qb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mode >= 0) compute(L);
+        __syncthreads();             // stage 1 holds step i + 1; nobody reads stage 0 any more
+        if (mode >= 0) fetch(L, 1u);
+        G1W_STASH(pa0, pa1, pb0, pb1, 0u);
+        G1W_ISSUE(pa0, pa1, pb0, pb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mode >= 0) compute(L);
+    }
+#undef G1W_ISSUE
+#undef G1W_STASH
+    };
+    if (!has) run(std::integral_constant<int, -1>{});
+    else if (theta) run(std::integral_constant<int, 3>{});
+    else if (three) run(std::integral_constant<int, 1>{});
+    else if (use2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 0>{});
+    if (has && act) {
+    auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual) {
+        constexpr int sl = decltype(SL)::value;
+        double sx = g0x[sl], sy = g0y[sl];
+        sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
+        sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
+        cplx* g = Gp + gp_off + (size_t)chunk * PH * Nhp;
+        if (dual) {
+            cplx* g2 = Gp + gp_off2 + (size_t)chunk * PH * Nhp;
+            if (kq == 0 && lag0 == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (HALF && (q & 1)) continue;
+                const int r = lag0 + (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1);
+                if (r <= h) {
+                    g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][0][q], Sx[sl][2][q]);
+                    g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][0][q], -Sx[sl][2][q]);
+                    g2[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][3][q], Sx[sl][1][q]);
+                    g2[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][3][q], -Sx[sl][1][q]);
+                }
+            }
+            return;
+        }
+        if (kq == 0 && lag0 == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (HALF && (q & 1)) continue;
+            const int r = lag0 + (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1);
+            if (r <= h) {
+                const double s1 = Sx[sl][0][q], s2 = Sx[sl][1][q], s3 = Sx[sl][2][q], s4 = Sx[sl][3][q];
+                g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
+                g[(size_t)(h - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
+            }
+        }
+    };
+    if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0);
+    if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false);
+    if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false);
+    if (theta) {
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+            double sx = t0x[ts], sy = t0y[ts];
+            sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
+            sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
+            cplx* g = Gp + (ts == 0 ? gt0 : gt1) + (size_t)chunk * PHt * Nhp;
+            if (kq == 0) g[(size_t)ht * Nhp + m] = make_double2(sx, sy);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = q == 0 ? 2 * (kq + 1) : 2 * kq + 1;
+                if (r <= ht) {
+                    const double s1 = St[ts][0][q], s2 = St[ts][1][q], s3 = St[ts][2][q], s4 = St[ts][3][q];
+                    g[(size_t)(ht + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
+                    g[(size_t)(ht - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
+                }
+            }
+        }
+    }
+    }
+    }
+}
+
+// The last column of the half spectrum (m = Nh - 1) when it is a tile of its own ((Nh - 1) % 16 == 0, e.g. 2049 = 128 x 16 + 1): the
+// workgroup launch above then covers (Nh - 1) / 16 whole tiles -- 128 x 4 chunks = 512 workgroups = two whole rounds of 256 CUs instead
+// of 516 -- and this kernel takes that column's lag sums directly, one workgroup per (pass, chunk): thread = (lag, row slice), the
+// slices added up through LDS.  Same partial buffers, same chunks (rows [lb, le) and their partners N0 / 2 further down), every lag
+// of the pass in one go (lag0 launches do not repeat it).
+__global__ void __launch_bounds__(256) greek_g1_lastcol(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, const int* __restrict__ list,
+                                                        cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay, int rows_per_chunk,
+                                                        const cplx* __restrict__ W0tab, int HM)
+{
+    const G1Pass ps = passes[list[blockIdx.x]];
+    const int chunk = blockIdx.y, h = ps.h, PH = 2 * h + 1, m = Nh - 1;
+    const int nsl = 256 / PH, tid = threadIdx.x;
+    const int li = tid % PH, sl = tid / PH;
+    const int r = li - h, ar = r < 0 ? -r : r;
+    const int lb = chunk * (rows_per_chunk / 2), le = min(N0 / 2, lb + rows_per_chunk / 2);
+    const size_t plane_sz = (size_t)N0 * Nhp, co = lay.col(m), rs = (size_t)lay.rstride;
+    const cplx* __restrict__ A = spec + (size_t)ps.a_plane * plane_sz + co;
+    const cplx* __restrict__ B = spec + (size_t)ps.b_plane * plane_sz + co;
+    double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;        // dual: (ax, ay) = sum tw |a|^2, (bx, by) = sum tw |b|^2
+    if (sl < nsl)
+        for (int x = lb + sl; x < le; x += nsl) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int row = x + hf * (N0 / 2);
+                const cplx a = A[(size_t)row * rs], b = B[(size_t)row * rs];
+                cplx tw = W0tab[(size_t)row * HM + min(ar, HM - 1)];
+                if (r < 0) tw.y = -tw.y;
+                if (ps.dual) {
+                    const double pa = fma(a.x, a.x, a.y * a.y), pb = fma(b.x, b.x, b.y * b.y);
+                    ax = fma(tw.x, pa, ax); ay = fma(tw.y, pa, ay);
+                    bx = fma(tw.x, pb, bx); by = fma(tw.y, pb, by);
+                } else {
+                    const cplx H = cmulc(a, b);
+                    ax += tw.x * H.x - tw.y * H.y;
+                    ay += tw.x * H.y + tw.y * H.x;
+                }
+            }
+        }
+    __shared__ double red[4][256];
+    red[0][tid] = ax; red[1][tid] = ay; red[2][tid] = bx; red[3][tid] = by;
+    __syncthreads();
+    if (tid < PH) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int q = 0; q < nsl; ++q) { s0 += red[0][tid + q * PH]; s1 += red[1][tid + q * PH]; s2 += red[2][tid + q * PH]; s3 += red[3][tid + q * PH]; }
+        Gp[ps.gp_off + ((size_t)chunk * PH + tid) * Nhp + m] = make_double2(s0, s1);
+        if (ps.dual) Gp[ps.gp_off2 + ((size_t)chunk * PH + tid) * Nhp + m] = make_double2(s2, s3);
+    }
 }
 
 // ---- redundant Omega passes (polynomial kernel bases) ---------------------------------------------------------------------

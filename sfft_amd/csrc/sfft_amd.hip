@@ -209,6 +209,11 @@ struct sfft_plan {
     unsigned long long* d_g1trace = nullptr;   // env SFFT_G1_TRACE=file: per-wave start / end stamps of the grouped Omega launch (development aid)
     G1Group* d_groups = nullptr;        // pass groups of the Omega launch
     int n_groups = 0;
+    // the same groups in blocks of up to eight that share their planes through LDS (greek_g1_mfma4w; env SFFT_G1_WG=1, off by default)
+    G1Group* d_groups_w = nullptr;
+    G1Blk* d_blks = nullptr;
+    int* d_lastcol = nullptr;           // passes whose last spectrum column goes through greek_g1_lastcol
+    int n_blks = 0, g1w = 0, g1w_ni = 0, n_lastcol = 0;
     int omg_reduce = 0;                 // env SFFT_OMG_REDUCE=1: one Omega pass per moment class is transformed, the others are derived (measured: no net gain, off)
     OmgReduce omgr; double* d_edge = nullptr; double* d_strip = nullptr; hipEvent_t ev_strip = nullptr;
     int syrk4 = 0;                      // rank-256 update of the outer-blocked factorisation on v_mfma_f64_4x4x4_4b_f64 (SFFT_SYRK4=0: 16 x 16 x 4)
@@ -1072,6 +1077,66 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             }
             PLAN_TRY(dev_alloc(p, &p->d_groups, groups.size()));
             PLAN_HIP(hipMemcpy(p->d_groups, groups.data(), groups.size() * sizeof(G1Group), hipMemcpyHostToDevice));
+            // Blocks of up to eight groups whose planes (at most G1W_NP) are loaded once per step and shared through LDS
+            // (greek_g1_mfma4w): greedily, the next group of a block is the one that adds the fewest new planes.
+            // Measured SLOWER than one wave per group (4096^2: 0.505 vs 0.339 ms; config 3: 14.9 vs 10.3 ms; config 5: 10.7 vs 7.8 ms): the
+            // barrier per step puts all eight waves into the same phase, so nobody computes while the 56 KB of operands of a step leave
+            // LDS.  Off unless SFFT_G1_WG=1.
+            if (getenv("SFFT_G1_WG") && atoi(getenv("SFFT_G1_WG")) == 1 && !groups.empty()) {
+                std::vector<G1Blk> blks;
+                std::vector<G1Group> gw;
+                std::vector<char> taken(groups.size(), 0);
+                size_t left = groups.size();
+                int ni = 0;
+                while (left) {
+                    G1Blk b; memset(&b, 0, sizeof(b));
+                    b.g0 = (int)gw.size();
+                    auto fresh = [&](const G1Group& g) {
+                        int c = 0;
+                        for (int k = 0; k < 3; ++k) {
+                            bool in = false;
+                            for (int q = 0; q < b.np; ++q) in = in || b.plane[q] == g.plane[k];
+                            for (int q = 0; q < k; ++q) in = in || g.plane[q] == g.plane[k];
+                            if (!in) ++c;
+                        }
+                        return c;
+                    };
+                    auto add = [&](size_t gi) {
+                        const G1Group& g = groups[gi];
+                        for (int k = 0; k < 3; ++k) {
+                            bool in = false;
+                            for (int q = 0; q < b.np; ++q) in = in || b.plane[q] == g.plane[k];
+                            if (!in) b.plane[b.np++] = g.plane[k];
+                        }
+                        gw.push_back(g); taken[gi] = 1; --left; ++b.ng;
+                    };
+                    size_t first = 0;
+                    while (taken[first]) ++first;
+                    add(first);
+                    while (b.ng < 8 && left) {
+                        int best = -1, bestc = 99;
+                        for (size_t gi = 0; gi < groups.size(); ++gi) if (!taken[gi]) {
+                            const int c = fresh(groups[gi]);
+                            if (b.np + c <= G1W_NP && c < bestc) { best = (int)gi; bestc = c; }
+                        }
+                        if (best < 0) break;
+                        add((size_t)best);
+                    }
+                    ni = std::max(ni, b.np + 1);
+                    blks.push_back(b);
+                }
+                p->n_blks = (int)blks.size(); p->g1w_ni = ni; p->g1w = 1;
+                PLAN_TRY(dev_alloc(p, &p->d_groups_w, gw.size()));
+                PLAN_HIP(hipMemcpy(p->d_groups_w, gw.data(), gw.size() * sizeof(G1Group), hipMemcpyHostToDevice));
+                PLAN_TRY(dev_alloc(p, &p->d_blks, blks.size()));
+                PLAN_HIP(hipMemcpy(p->d_blks, blks.data(), blks.size() * sizeof(G1Blk), hipMemcpyHostToDevice));
+                std::vector<int> lc;
+                for (int k = 0; k < nl; ++k) lc.push_back(k);
+                if (p->theta_in_groups) for (int a = 0; a < p->n_the_fused; ++a) lc.push_back(the_pass[a]);
+                p->n_lastcol = (int)lc.size();
+                PLAN_TRY(dev_alloc(p, &p->d_lastcol, lc.size()));
+                PLAN_HIP(hipMemcpy(p->d_lastcol, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
         }
         PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
         PLAN_HIP(hipMemcpy(p->d_passes, p->passes.data(), p->passes.size() * sizeof(G1Pass), hipMemcpyHostToDevice));
@@ -1303,7 +1368,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_edge, p->d_strip, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_groups_w, p->d_blks, p->d_lastcol, p->d_g1trace, p->d_edge, p->d_strip, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1767,6 +1832,29 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             const bool dit = g1_decimated(p);
             // lag half-widths beyond 16 (KerHW 9 .. 16): the 16 lags lag0 + 1 .. lag0 + 16 per launch (the planes are read once per launch)
             for (int lag0 = 0; lag0 < h; lag0 += 16) {
+            if (dit && p->g1w) {
+                // workgroups of eight waves, the planes of a block shared through LDS (greek_g1_mfma4w); the last spectrum column on its own
+                // when it would be a tile by itself
+                const bool lastcol = p->Nh > 16 && (p->Nh - 1) % 16 == 0;
+                const int ncbw = lastcol ? (p->Nh - 1) / 16 : ncb16;
+                const int ntiles = ncbw * p->S;
+                const int cux = std::max(1, p->num_cu / 8);
+                int tpr = 0, rounds = 0, nwg;
+                if (p->n_blks > 1) {
+                    tpr = std::max(1, cux / p->n_blks);
+                    rounds = ((ntiles + 7) / 8 + tpr - 1) / tpr;
+                    nwg = 8 * tpr * p->n_blks;
+                } else nwg = 8 * ((ntiles * p->n_blks + 7) / 8);
+                const size_t ldsb = (size_t)2 * p->g1w_ni * 2048;
+                if (lastcol && lag0 == 0)
+                    hipLaunchKernelGGL(greek_g1_lastcol, dim3(p->n_lastcol, p->S), dim3(256), 0, s, p->d_spec, p->d_passes, p->d_lastcol, p->d_gp, p->N0, p->Nh,
+                                       p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm);
+                const bool halfl = lag0 > 0 && h - lag0 <= 8, two = p->g1w_ni > 8;
+                auto KW = halfl ? (two ? greek_g1_mfma4w<true, true> : greek_g1_mfma4w<true, false>)
+                                : (two ? greek_g1_mfma4w<false, true> : greek_g1_mfma4w<false, false>);
+                hipLaunchKernelGGL(KW, dim3(nwg), dim3(512), ldsb, s, p->d_spec, p->d_passes, p->d_groups_w, p->d_blks, p->n_blks, p->d_gp,
+                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncbw, p->S, lag0, tpr, rounds, p->g1w_ni);
+            } else
             if (dit && lag0 > 0 && h - lag0 <= 8)
                 hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);

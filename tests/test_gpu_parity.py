@@ -1258,6 +1258,22 @@ def test_derived_omega_patches_equal_transformed_ones(dev, shape, w, DK):
     assert rms(red[1] - full[1]) <= 1e-7 * rms(full[1])
 
 
+@pytest.mark.parametrize("shape,w,DK", [((256, 288), 8, 2), ((320, 4096), 8, 2), ((512, 384), 5, 3), ((384, 96), 12, 3)])
+def test_omega_launch_variants_agree(dev, shape, w, DK):
+    """The Omega + Theta launch in its off-by-default forms against the default (one wave per pass group, four equal row chunks):
+    SFFT_G1_WG=1 (greek_g1_mfma4w: workgroups of eight waves share a block's planes through LDS, the last spectrum column through
+    greek_g1_lastcol when it would be a tile of its own -- N1 = 288 and 4096 here -- and the persistent form when a tile has more
+    than one block -- order 3), and SFFT_G1_RPC (uneven row chunks).  Both measured slower; same system."""
+    from sfft_amd.utils.synthetic import make_pair
+    pair = make_pair(*shape, seed=5 + w, mask=True, density=400.0)
+    ref = _subtract_with_env(dev, {}, shape, w, DK, 1, pair)
+    for env in ({"SFFT_G1_WG": "1"}, {"SFFT_G1_RPC": "%d" % (16 * max(1, (3 * shape[0] // 8) // 16))}, {"SFFT_G1_WG": "1", "SFFT_G1_S": "2"}):
+        alt = _subtract_with_env(dev, env, shape, w, DK, 1, pair)
+        assert np.max(np.abs(alt[2] - ref[2])) <= 1e-11 * np.max(np.abs(ref[2])), env
+        assert np.max(np.abs(alt[3] - ref[3])) <= 1e-11 * np.max(np.abs(ref[3])), env
+        assert rms(alt[1] - ref[1]) <= 1e-7 * rms(ref[1]), env
+
+
 def test_solver_chain_replays_as_graph_on_a_side_stream(dev):
     """On a capturable stream the ~35 launches of the factorisation and back substitution are captured once per plan and
     replayed with hipGraphLaunch (flag stamps come from a device counter, so the arguments are constant).  Same solution as
