@@ -715,8 +715,9 @@ def test_bspline_matches_reference(dev, name):
 
 
 def test_bspline_background_matches_oracle(dev):
-    """B-spline BACKGROUND variation has no runnable CPU code in the reference (parity unpinned, see
-    tests/golden/make_golden_bspline.py); checked against the restated oracle only."""
+    """B-spline BACKGROUND variation at a larger shape against the restated oracle (the oracle itself is pinned for B-spline
+    backgrounds by the bs_*_bkgbspl* fixtures: the reference's dev-version code with its mistyped function name corrected in memory,
+    tests/golden/make_golden_bspline.py; those fixtures run through the parametrised golden tests above)."""
     from oracle import bspline_oracle as BO
     from sfft_amd.BSplineSFFT import SingleSFFTConfigure as BSSC, GeneralSFFTSubtract as BGSS
     from sfft_amd.utils.synthetic import make_pair
