@@ -562,18 +562,23 @@ struct G1Group {
 // lag0 / HALF (lag half-widths 17 .. 32, e.g. KerHW 12: h = 24): a launch covers the 16 lags lag0 + 1 .. lag0 + 16 (lag0 = 0 or 16; the lag-0
 // sums belong to the first launch); HALF = true (DIT only) issues just the lag groups lag0 + {2,4,6,8} and lag0 + {1,3,5,7} -- the second
 // launch of h <= 24 needs no others -- i.e. half the matrix instructions of a step.
-template <bool MASK, bool DIT = false, bool HALF = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
+// QUAD (SFFT_G1_QUAD=1): four independent waves per workgroup, one per SIMD, and a dynamic LDS request of more than half the CU's
+// (never touched) so that ONE such workgroup fits a CU: the launch then holds one wave per SIMD -- which costs it 8 % on its own, a
+// lone wave nearly saturates a SIMD's issue -- and leaves half the registers and LDS of every CU to the memory-bound kernels of the
+// other pairs in flight (rows_r2c_4096, rows_c2r_diff_4096, vconv_mixed2: 256 threads, <= 240 registers, <= 70 KB).
+template <bool MASK, bool DIT = false, bool HALF = false, bool QUAD = false>
+__global__ void __launch_bounds__(QUAD ? 256 : 64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
                                                         const G1Group* __restrict__ groups, int ngroup,
                                                         cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
                                                         int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S,
                                                         unsigned long long* __restrict__ trace, int lag0)
 {
     const unsigned long long t_start = trace ? wall_clock64() : 0ULL;      // (SFFT_G1_TRACE: start / end stamp and XCD of every wave)
-    const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
+    const int lane = QUAD ? (int)(threadIdx.x & 63) : (int)threadIdx.x, n = lane & 15, kq = lane >> 4;
     const int total = ncb * S * ngroup;
-    const int per = (total + 7) >> 3;
-    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);      // the groups of a tile run back to back on one XCD
+    const int per = QUAD ? 4 * ((total + 31) >> 5) : (total + 7) >> 3;
+    // the groups of a tile run back to back on one XCD (QUAD: four consecutive list entries per workgroup)
+    const int logical = (int)(blockIdx.x & 7) * per + (QUAD ? 4 * (int)(blockIdx.x >> 3) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(blockIdx.x >> 3));
     if (logical >= total) return;
     const int tile = logical / ngroup;
     const int chunk = tile / ncb;

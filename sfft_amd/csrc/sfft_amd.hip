@@ -72,6 +72,7 @@ static int stream_device(hipStream_t s)
 extern "C" const char* sfft_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 
+#define G1_QUAD_LDS (81 * 1024)      // more than half of the CU's 160 KB: one QUAD workgroup of the Omega launch per CU
 #include "device_common.hpp"
 #include "fft_generic.hpp"
 #include "fft_fourstep.hpp"
@@ -214,6 +215,7 @@ struct sfft_plan {
     G1Blk* d_blks = nullptr;
     int* d_lastcol = nullptr;           // passes whose last spectrum column goes through greek_g1_lastcol
     int n_blks = 0, g1w = 0, g1w_ni = 0, n_lastcol = 0;
+    int g1_quad = 0;                    // env SFFT_G1_QUAD=1: the Omega launch as four-wave workgroups, one per CU
     int omg_reduce = 0;                 // env SFFT_OMG_REDUCE=1: one Omega pass per moment class is transformed, the others are derived (measured: no net gain, off)
     OmgReduce omgr; double* d_edge = nullptr; double* d_strip = nullptr; hipEvent_t ev_strip = nullptr;
     int syrk4 = 0;                      // rank-256 update of the outer-blocked factorisation on v_mfma_f64_4x4x4_4b_f64 (SFFT_SYRK4=0: 16 x 16 x 4)
@@ -746,6 +748,11 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096_q, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (const char* ev = getenv("SFFT_G1_QUAD")) p->g1_quad = atoi(ev);
+    if (p->g1_quad) {
+        PLAN_HIP(hipFuncSetAttribute((const void*)greek_g1_mfma4g<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G1_QUAD_LDS));
+        PLAN_HIP(hipFuncSetAttribute((const void*)greek_g1_mfma4g<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G1_QUAD_LDS));
+    }
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1854,6 +1861,16 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
                                 : (two ? greek_g1_mfma4w<false, true> : greek_g1_mfma4w<false, false>);
                 hipLaunchKernelGGL(KW, dim3(nwg), dim3(512), ldsb, s, p->d_spec, p->d_passes, p->d_groups_w, p->d_blks, p->n_blks, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncbw, p->S, lag0, tpr, rounds, p->g1w_ni);
+            } else
+            if (dit && p->g1_quad) {
+                // four waves per workgroup, one workgroup per CU (see greek_g1_mfma4g, QUAD)
+                const int nwgq = 8 * ((totg + 31) / 32);
+                if (lag0 > 0 && h - lag0 <= 8)
+                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                                       p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
+                else
+                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, false, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                                       p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             } else
             if (dit && lag0 > 0 && h - lag0 <= 8)
                 hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,

@@ -1268,7 +1268,8 @@ def test_omega_launch_variants_agree(dev, shape, w, DK):
     from sfft_amd.utils.synthetic import make_pair
     pair = make_pair(*shape, seed=5 + w, mask=True, density=400.0)
     ref = _subtract_with_env(dev, {}, shape, w, DK, 1, pair)
-    for env in ({"SFFT_G1_WG": "1"}, {"SFFT_G1_RPC": "%d" % (16 * max(1, (3 * shape[0] // 8) // 16))}, {"SFFT_G1_WG": "1", "SFFT_G1_S": "2"}):
+    for env in ({"SFFT_G1_WG": "1"}, {"SFFT_G1_RPC": "%d" % (16 * max(1, (3 * shape[0] // 8) // 16))}, {"SFFT_G1_WG": "1", "SFFT_G1_S": "2"},
+                {"SFFT_G1_QUAD": "1"}):
         alt = _subtract_with_env(dev, env, shape, w, DK, 1, pair)
         assert np.max(np.abs(alt[2] - ref[2])) <= 1e-11 * np.max(np.abs(ref[2])), env
         assert np.max(np.abs(alt[3] - ref[3])) <= 1e-11 * np.max(np.abs(ref[3])), env
