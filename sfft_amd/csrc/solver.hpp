@@ -29,6 +29,33 @@ __global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__
 
 typedef double d4s __attribute__((ext_vector_type(4)));
 
+// A 16 x 16 x 4 fp64 tile product, optionally (-DSFFT_CHOL_M4=1) as FOUR v_mfma_f64_4x4x4_4b_f64: the 16 x 16 x 4 instruction occupies the
+// matrix pipe for ~93 cycles, the four 4 x 4 x 4 ones for ~60 (profiles/r02_mfma_f64_peak.txt: 47 vs 74 TFLOP/s sustained).  Same B
+// operand (lane 16 k + n holds B[k][n]) and the same accumulator layout (component bi of lane 16 i + n holds C[4 bi + i][n]);
+// instruction bi wants A[4 bi + (lane & 3)][k] in lane 16 k + 4 blk + (lane & 3), i.e. the 16 x 16 x 4 form's A operand gathered from
+// lane 16 k + 4 bi + (lane & 3): one ds_swizzle per half of the double.  MEASURED SLOWER in these latency chains (one wave per SIMD:
+// update of the next diagonal tile, triangular solves, rank-4 updates of the diagonal factorisation): solve 0.975 - 0.99 ms against
+// 0.88 - 0.93 at n = 1735, 7.89 against 7.70 ms at n = 7207 -- eight swizzles and four instructions per product cost a lone wave more
+// issue time than the shorter pipe occupancy gives back.  Default 0.  (chol_syrk has its own 4 x 4 x 4 form, template M4, also off.)
+#ifndef SFFT_CHOL_M4
+#define SFFT_CHOL_M4 0
+#endif
+__device__ __forceinline__ d4s mfma16(double av, double bv, d4s acc)
+{
+#if SFFT_CHOL_M4
+#define SFFT_SWZ4(G) __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(av), 0x13 | ((4 * (G)) << 5)), \
+                                      __builtin_amdgcn_ds_swizzle(__double2loint(av), 0x13 | ((4 * (G)) << 5)))
+    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(0), bv, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(1), bv, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(2), bv, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(3), bv, acc[3], 0, 0, 0);
+#undef SFFT_SWZ4
+    return acc;
+#else
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#endif
+}
+
 // 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no IEEE division / sqrt sequences on the
 // critical path of the factorisation)
 __device__ __forceinline__ double rsqrt_nr(double d)
@@ -136,7 +163,7 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
                         const double fc = Fw[col][cg];
                         const double aop = (col > j0 + 3) ? -fc : 0.0;
                         d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, lf, acc, 0, 0, 0);
+                        acc = mfma16(aop, lf, acc);
                         a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
                     }
                 }
@@ -395,7 +422,6 @@ __global__ void __launch_bounds__(256) chol_back_step(const double* __restrict__
 // block column then factors it redundantly and solves its own 64 rows.  Halves the number of dependent launches of the
 // factorisation (update and panel used to be 20 + 27 us each, most of it launch / first-load latency).  Only for full blocks
 // (n - k >= CB); the last, partial block keeps the two-kernel path.
-typedef double d4s __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld, int n, int kp, double* Draw, unsigned int* flag,
                                                  const unsigned int* __restrict__ epoch_ctr, unsigned int step_id, int* __restrict__ status,
@@ -456,7 +482,7 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
     for (int ks = 0; ks < CB / 4; ++ks) {
         const double av = Li[16 * wv + ln][4 * ks + lk];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) c[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Lj[16 * jt + ln][4 * ks + lk], c[jt], 0, 0, 0);
+        for (int jt = 0; jt < 4; ++jt) c[jt] = mfma16(av, Lj[16 * jt + ln][4 * ks + lk], c[jt]);
     }
     if (tj != 0) {
 #pragma unroll
@@ -644,7 +670,7 @@ __device__ __forceinline__ void chol_inv16_mfma(const double (*Dl)[CB + 1], cons
     for (int ks = 0; ks < 4; ++ks) {
         const double av = ((ln >> 2) == ks) ? Vd[R + ln][lk] : 0.0;                          // D^-1 [i = ln][k = 4 ks + lk]
         const double bv = (ks > (ln >> 2)) ? Dl[R + 4 * ks + lk][R + ln] : 0.0;              // (L_bb - D)[k][j = ln]
-        nA = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, nA, 0, 0, 0);
+        nA = mfma16(av, bv, nA);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) Ws[0][lk + 4 * q][ln] = nA[q];
@@ -652,14 +678,14 @@ __device__ __forceinline__ void chol_inv16_mfma(const double (*Dl)[CB + 1], cons
     __builtin_amdgcn_wave_barrier();
     d4s n2 = (d4s){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) n2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[0][ln][4 * ks + lk], Ws[0][4 * ks + lk][ln], n2, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) n2 = mfma16(Ws[0][ln][4 * ks + lk], Ws[0][4 * ks + lk][ln], n2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) Ws[1][lk + 4 * q][ln] = n2[q];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     d4s n3 = (d4s){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) n3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[0][ln][4 * ks + lk], Ws[1][4 * ks + lk][ln], n3, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) n3 = mfma16(Ws[0][ln][4 * ks + lk], Ws[1][4 * ks + lk][ln], n3);
 #pragma unroll
     for (int q = 0; q < 4; ++q) Ws[2][lk + 4 * q][ln] = ((lk + 4 * q == ln) ? 1.0 : 0.0) - nA[q] + n2[q] - n3[q];      // I - N + N^2 - N^3
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -668,7 +694,7 @@ __device__ __forceinline__ void chol_inv16_mfma(const double (*Dl)[CB + 1], cons
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const double bv = (ks == (ln >> 2)) ? Vd[R + 4 * ks + lk][ln & 3] : 0.0;             // D^-1 [k][j = ln]
-        wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[2][ln][4 * ks + lk], bv, wacc, 0, 0, 0);
+        wacc = mfma16(Ws[2][ln][4 * ks + lk], bv, wacc);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) W16t[b][ln][lk + 4 * q] = wacc[q];
@@ -696,7 +722,7 @@ __device__ __forceinline__ void chol_inv64_mfma(const double (*Dl)[CB + 1], cons
             for (int m = c; m < r; ++m)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dl[16 * r + ln][16 * m + 4 * ks + lk], Wf[16 * m + 4 * ks + lk][16 * c + ln], acc, 0, 0, 0);
+                    acc = mfma16(Dl[16 * r + ln][16 * m + 4 * ks + lk], Wf[16 * m + 4 * ks + lk][16 * c + ln], acc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) Sm[wv][lk + 4 * q][ln] = acc[q];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -704,7 +730,7 @@ __device__ __forceinline__ void chol_inv64_mfma(const double (*Dl)[CB + 1], cons
             d4s x = (d4s){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(W16t[r][4 * ks + lk][ln], Sm[wv][4 * ks + lk][ln], x, 0, 0, 0);      // A[i][k] = W_rr[i][k]
+                x = mfma16(W16t[r][4 * ks + lk][ln], Sm[wv][4 * ks + lk][ln], x);      // A[i][k] = W_rr[i][k]
 #pragma unroll
             for (int q = 0; q < 4; ++q) Wf[16 * r + lk + 4 * q][16 * c + ln] = -x[q];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -730,7 +756,7 @@ __device__ __forceinline__ void df_trsm_mfma(double (*T)[CB + 1], const double (
         for (int bp = 0; bp < b; ++bp)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[R0 + ln][16 * bp + 4 * ks + lk], Dl[16 * b + ln][16 * bp + 4 * ks + lk], acc, 0, 0, 0);
+                acc = mfma16(-T[R0 + ln][16 * bp + 4 * ks + lk], Dl[16 * b + ln][16 * bp + 4 * ks + lk], acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) T[R0 + lk + 4 * q][16 * b + ln] = acc[q];           // Y_b
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -738,7 +764,7 @@ __device__ __forceinline__ void df_trsm_mfma(double (*T)[CB + 1], const double (
         d4s x = (d4s){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            x = __builtin_amdgcn_mfma_f64_16x16x4f64(T[R0 + ln][16 * b + 4 * ks + lk], W16t[b][4 * ks + lk][ln], x, 0, 0, 0);     // B[k][j] = W_bb[j][k]
+            x = mfma16(T[R0 + ln][16 * b + 4 * ks + lk], W16t[b][4 * ks + lk][ln], x);     // B[k][j] = W_bb[j][k]
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q) T[R0 + lk + 4 * q][16 * b + ln] = x[q];             // X_b
@@ -815,7 +841,7 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
                 for (int ks = 0; ks < CB / 4; ++ks) {
                     const double av = -Li[16 * wv + ln][4 * ks + lk];
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) c[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Lj[16 * jt + ln][4 * ks + lk], c[jt], 0, 0, 0);
+                    for (int jt = 0; jt < 4; ++jt) c[jt] = mfma16(av, Lj[16 * jt + ln][4 * ks + lk], c[jt]);
                 }
             }
             __syncthreads();
@@ -878,8 +904,8 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
                 const double av = -Li[16 * wv + ln][4 * ks + lk];
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
-                    cx[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Lj[16 * jt + ln][4 * ks + lk], cx[jt], 0, 0, 0);
-                    cd[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[16 * jt + ln][4 * ks + lk], cd[jt], 0, 0, 0);
+                    cx[jt] = mfma16(av, Lj[16 * jt + ln][4 * ks + lk], cx[jt]);
+                    cd[jt] = mfma16(av, Li[16 * jt + ln][4 * ks + lk], cd[jt]);
                 }
             }
         }
@@ -924,7 +950,7 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
             for (int ks = 0; ks < CB / 4; ++ks) {
                 const double av = -T[16 * wv + ln][4 * ks + lk];
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) cd[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[16 * jt + ln][4 * ks + lk], cd[jt], 0, 0, 0);
+                for (int jt = 0; jt < 4; ++jt) cd[jt] = mfma16(av, T[16 * jt + ln][4 * ks + lk], cd[jt]);
             }
             __syncthreads();
         }
@@ -1100,7 +1126,7 @@ __global__ void __launch_bounds__(256) chol_panel4(double* __restrict__ A, int l
                 for (int ks = 0; ks < CB / 4; ++ks) {
                     const double av = -T[16 * wv + ln][4 * ks + lk];
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) cT[sp][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[16 * jt + ln][4 * ks + lk], cT[sp][jt], 0, 0, 0);
+                    for (int jt = 0; jt < 4; ++jt) cT[sp][jt] = mfma16(av, B[16 * jt + ln][4 * ks + lk], cT[sp][jt]);
                 }
             }
         };
