@@ -753,8 +753,9 @@ __global__ void __launch_bounds__(QUAD ? 256 : 64) __attribute__((amdgpu_waves_p
     else if (use2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 0>{});
     if (!act) return;
-    auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual) {
+    auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual, int h) {      // h: the lag half width of THIS slot's pass
         constexpr int sl = decltype(SL)::value;
+        const int PH = 2 * h + 1;
         double sx = g0x[sl], sy = g0y[sl];
         sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
         sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
@@ -787,9 +788,9 @@ __global__ void __launch_bounds__(QUAD ? 256 : 64) __attribute__((amdgpu_waves_p
             }
         }
     };
-    if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0);
-    if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false);
-    if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false);
+    if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0, passes[k0].h);
+    if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false, passes[k1].h);
+    if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false, passes[k2].h);
     if (theta) {
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts) {
@@ -1045,8 +1046,9 @@ __global__ void __launch_bounds__(512) greek_g1_mfma4w(const cplx* __restrict__ 
     else if (use2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 0>{});
     if (has && act) {
-    auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual) {
+    auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual, int h) {      // h: the lag half width of THIS slot's pass
         constexpr int sl = decltype(SL)::value;
+        const int PH = 2 * h + 1;
         double sx = g0x[sl], sy = g0y[sl];
         sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
         sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
@@ -1079,9 +1081,9 @@ __global__ void __launch_bounds__(512) greek_g1_mfma4w(const cplx* __restrict__ 
             }
         }
     };
-    if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0);
-    if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false);
-    if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false);
+    if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0, passes[k0].h);
+    if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false, passes[k1].h);
+    if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false, passes[k2].h);
     if (theta) {
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts) {

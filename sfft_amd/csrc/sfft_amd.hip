@@ -225,6 +225,8 @@ struct sfft_plan {
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
+    int theta_slots = 0;                // 1: half width 9 .. 16 (KerHW 9 .. 16): the Theta passes as ordinary slots in groups of their own behind the Omega groups
+    int n_groups_omg = 0;               //    (first launch only: n_groups counts them, n_groups_omg does not; env SFFT_THETA_SLOTS=0: a launch of their own)
     int rows_r24 = 0;                   // 16 / 24: 6144- / 9216-point row axis on the register-resident kernels of fft_r24.hpp (env SFFT_NO_ROWS_R24=1: the generic pass, A/B)
     int cols_r24 = 0;                   // the same for the column axis (env SFFT_NO_COLS_R24=1)
     int no_wx_support = 0;              // env SFFT_NO_WX_SUPPORT=1: the generic weighted column pass reads rows whose row factor is zero too (A/B)
@@ -1064,6 +1066,26 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                     p->theta_in_groups = 1;
                 }
             }
+            // Half widths 9 .. 16 (KerHW 9 .. 16: config 5): too wide to ride as the edge groups' half slots, and their own launch
+            // (greek_g1_mfma4<2>, one pass per wave) re-reads all Fij + 1 planes: 1.7 ms of a config-5 pair.  They become ordinary slots
+            // of the FIRST launch (lags 1 .. 16) in groups of their own -- two passes (a, J), (a + 1, J) on the planes (a, a + 1, J) --
+            // behind the Omega groups, which is where the later launches (lags 17 ..) stop.
+            p->n_groups_omg = (int)groups.size();
+            if (!p->theta_in_groups && p->gamma_analytic && p->n_dense_w == p->n_the && hG >= 9 && hG <= 16 && hO <= 32 &&
+                !(getenv("SFFT_THETA_FUSED") && atoi(getenv("SFFT_THETA_FUSED")) == 0) && !(getenv("SFFT_THETA_SLOTS") && atoi(getenv("SFFT_THETA_SLOTS")) == 0)) {
+                for (int a = 0; a + 1 < p->Fij; a += 2) {
+                    G1Group g = blank(a, a + 1, JP);
+                    g.mask = 6; g.pass[1] = the_pass[a + 1]; g.pass[2] = the_pass[a];          // slot 1 = (v1, v2), slot 2 = (v0, v2)
+                    groups.push_back(g);
+                }
+                if (p->Fij % 2) {
+                    G1Group g = blank(p->Fij - 1, JP, p->Fij - 1);
+                    g.mask = 1; g.pass[0] = the_pass[p->Fij - 1];
+                    groups.push_back(g);
+                }
+                p->n_the_fused = p->Fij;
+                p->theta_slots = 1;
+            }
             if (getenv("SFFT_G1_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_g1trace, (size_t)3 * 65536)); PLAN_HIP(hipMemset(p->d_g1trace, 0, (size_t)3 * 65536 * 8)); }
             p->n_groups = (int)groups.size();
             // (Uneven row chunks -- S - 1 long ones and a short last one, so that the long layers hold most wave slots for the whole launch
@@ -1139,7 +1161,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                 PLAN_HIP(hipMemcpy(p->d_blks, blks.data(), blks.size() * sizeof(G1Blk), hipMemcpyHostToDevice));
                 std::vector<int> lc;
                 for (int k = 0; k < nl; ++k) lc.push_back(k);
-                if (p->theta_in_groups) for (int a = 0; a < p->n_the_fused; ++a) lc.push_back(the_pass[a]);
+                if (p->theta_in_groups || p->theta_slots) for (int a = 0; a < p->n_the_fused; ++a) lc.push_back(the_pass[a]);
                 p->n_lastcol = (int)lc.size();
                 PLAN_TRY(dev_alloc(p, &p->d_lastcol, lc.size()));
                 PLAN_HIP(hipMemcpy(p->d_lastcol, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1421,7 +1443,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_dense_w); break;
         case SFFT_Q_SCAFIJ: *v = p->nsca; break;
         case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
-        case SFFT_Q_THETA_FUSED: *v = (p->theta_in_groups && p->g1_mfma >= 3) ? 1 : 0; break;
+        case SFFT_Q_THETA_FUSED: *v = ((p->theta_in_groups || p->theta_slots) && p->g1_mfma >= 3) ? 1 : 0; break;
         case SFFT_Q_OMG_OFFDIAG: *v = p->n_omg_off; break;
         case SFFT_Q_G1_CHUNKS: *v = p->S; break;
         case SFFT_Q_G1_DECIMATED: *v = (g1_decimated(p) && 2 * p->w >= 9 && 2 * p->w <= 32) ? 1 : 0; break;
@@ -1839,6 +1861,9 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             const bool dit = g1_decimated(p);
             // lag half-widths beyond 16 (KerHW 9 .. 16): the 16 lags lag0 + 1 .. lag0 + 16 per launch (the planes are read once per launch)
             for (int lag0 = 0; lag0 < h; lag0 += 16) {
+            // (Theta passes as slots of their own groups: in the first launch only, behind the Omega groups)
+            const int ngl = (lag0 == 0 || !p->theta_slots) ? p->n_groups : p->n_groups_omg;
+            const int totl = ncb16 * p->S * ngl;
             if (dit && p->g1w) {
                 // workgroups of eight waves, the planes of a block shared through LDS (greek_g1_mfma4w); the last spectrum column on its own
                 // when it would be a tile by itself
@@ -1864,25 +1889,25 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             } else
             if (dit && p->g1_quad) {
                 // four waves per workgroup, one workgroup per CU (see greek_g1_mfma4g, QUAD)
-                const int nwgq = 8 * ((totg + 31) / 32);
+                const int nwgq = 8 * ((totl + 31) / 32);
                 if (lag0 > 0 && h - lag0 <= 8)
-                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                        p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
                 else
-                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, false, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, false, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                        p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             } else
             if (dit && lag0 > 0 && h - lag0 <= 8)
-                hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else if (dit)
-                hipLaunchKernelGGL((greek_g1_mfma4g<false, true>), dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                hipLaunchKernelGGL((greek_g1_mfma4g<false, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else if (whole)
-                hipLaunchKernelGGL(greek_g1_mfma4g<false>, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                hipLaunchKernelGGL(greek_g1_mfma4g<false>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else
-                hipLaunchKernelGGL(greek_g1_mfma4g<true>, dim3(8 * ((totg + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, p->n_groups, p->d_gp,
+                hipLaunchKernelGGL(greek_g1_mfma4g<true>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             }
             if (p->d_g1trace) {     // development aid (SFFT_G1_TRACE=file): dump the wave stamps of this launch
@@ -2209,7 +2234,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
         if (!theta_with_omega) {
-            const int fused = (p->theta_in_groups && p->g1_mfma >= 3) ? p->n_the_fused : 0;      // (the rest: a vector launch of their own)
+            const int fused = ((p->theta_in_groups || p->theta_slots) && p->g1_mfma >= 3) ? p->n_the_fused : 0;      // (the rest: a vector launch of their own)
             if (fused < p->n_dense_w && (rc = greek_g1_group(p, p->n_omg + fused, p->n_dense_w - fused, p->w, s))) return rc;
         }
         if (p->gamma_analytic && !gamma_aside) {     // Gamma block: row moments of I, then the patches (no spectra involved)
