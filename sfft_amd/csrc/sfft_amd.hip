@@ -1064,6 +1064,19 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                         g.plane[2] = JP; g.ht = hG;
                     }
                     p->theta_in_groups = 1;
+                    // odd Fij: the last plane's Theta pass (x, J) as an ordinary slot beside its lone diagonal pass (x, x): planes (x, x, J),
+                    // slot 0 = (v0, v1) = the diagonal, slot 2 = (v0, v2) = the Theta pass with its own lag half width -- instead of a
+                    // vector launch of its own that re-reads two planes (config 3: 0.32 ms)
+                    if (nf == p->Fij - 1 && !(getenv("SFFT_THETA_SLOTS") && atoi(getenv("SFFT_THETA_SLOTS")) == 0))
+                        for (G1Group& g : groups) {
+                            const G1Pass& q0 = p->passes[g.pass[0]];
+                            if (g.mask == 1 && !q0.dual && q0.a_plane == nf && q0.b_plane == nf && g.tpass[0] < 0) {
+                                g.plane[0] = nf; g.plane[1] = nf; g.plane[2] = JP;
+                                g.mask |= 4; g.pass[2] = the_pass[nf];
+                                p->n_the_fused = p->Fij;
+                                break;
+                            }
+                        }
                 }
             }
             // Half widths 9 .. 16 (KerHW 9 .. 16: config 5): too wide to ride as the edge groups' half slots, and their own launch
