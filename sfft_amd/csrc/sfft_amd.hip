@@ -2023,7 +2023,11 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
                 hipLaunchKernelGGL(SYRK_K, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
             }
             kb = r0;
-            hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A + (size_t)kb * p->ld + kb, p->ld, std::min(CB, n - kb), p->d_dbuf);
+            // chol_panel takes its diagonal block from the hand-over buffer, chol_panel4 from the matrix itself: the copy is only needed
+            // when the next panel is a chol_panel launch (the last outer block's successor, or a block column too tall for chol_panel4)
+            const bool next_p4 = (n - kb >= OB + CB) && p->panel4 && p->d_pq && (n + 1 - kb + CB - 1) / CB <= p->ncu && outer < PANEL4_MAX_OUTER;
+            if (!next_p4)
+                hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A + (size_t)kb * p->ld + kb, p->ld, std::min(CB, n - kb), p->d_dbuf);
         }
         if (side_pending) HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0));       // join: the remaining steps touch every column
     }
