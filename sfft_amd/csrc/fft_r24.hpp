@@ -318,6 +318,104 @@ __global__ void __launch_bounds__(24 * Q, 3) rows_r2c_r24(RowsArgs a, int nplane
     }
 }
 
+// rows, half complex -> real (N1 = 384 Q), two rows per transform, DIFF epilogue: the register-resident twin of rows_c2r_diff (same
+// arguments; see rows_c2r_diff_4096 for the packing).  The generic pass keeps the 6144- / 9216-point sequence in LDS (one workgroup
+// per CU, ten trips through LDS): 0.49 ms of a config-3 pair, 1.16 ms of a config-5 pair (1.8 TB/s).  Z = X0 + i X1 is conjugated on
+// input so that the forward transform acts as the inverse; thread j loads the elements m = j + NT r, the mirrored half of the
+// spectrum (m > N1 / 2) from column N1 - m with the sign of its imaginary part flipped; the stage-3 threads hold the 24 results
+// n = j + NQ k3 of both rows and finish them in batches of EB (all J / background-table loads of a batch before its stores).
+// LB / EB: elements per batch of loads / results per batch of the epilogue (9216 points: 576 threads = three waves on one SIMD,
+// 168 registers each).
+template <int Q, int NQB>
+__global__ void __launch_bounds__(24 * Q) rows_c2r_diff_r24(const cplx* __restrict__ FD, const double* __restrict__ J, const double* __restrict__ bpq,
+                                                            BkgArgs bk, double* __restrict__ DIFF, int N0, SpecLayout lay, const cplx* __restrict__ tw)
+{
+    typedef R24<Q> F;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    constexpr int N1 = F::N, NQ = F::NQ;
+    constexpr int LB = (Q == 24) ? 4 : 8, EB = (Q == 24) ? 2 : 4;
+    const int j = threadIdx.x;
+    const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
+    const bool has1 = l1 < N0;
+    const cplx* __restrict__ f0 = FD + (size_t)l0 * lay.rstride;
+    const cplx* __restrict__ f1 = FD + (size_t)(has1 ? l1 : l0) * lay.rstride;
+    const double h1 = has1 ? 1.0 : 0.0;
+    cplx u[16];
+#pragma unroll
+    for (int hb = 0; hb < 16 / LB; ++hb) {
+        cplx a0[LB], a1[LB];
+#pragma unroll
+        for (int r = 0; r < LB; ++r) {
+            const int m = j + F::NT * (LB * hb + r);
+            const int mm = (m > N1 / 2) ? N1 - m : m;
+            const unsigned mo = (unsigned)lay.col(mm) * (unsigned)sizeof(cplx);
+            a0[r] = *at_byte(f0, mo); a1[r] = *at_byte(f1, mo);
+        }
+#pragma unroll
+        for (int r = 0; r < LB; ++r) {
+            const int m = j + F::NT * (LB * hb + r);
+            const bool mir = m > N1 / 2;
+            const int mm = mir ? N1 - m : m;
+            cplx x0 = a0[r], x1 = make_double2(a1[r].x * h1, a1[r].y * h1);
+            if (mm == 0 || mm == N1 / 2) { x0.y = 0.0; x1.y = 0.0; }
+            if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
+            u[LB * hb + r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    cplx xin[24];
+    const bool act = F::stage3_wave();
+    fft_r24_front<Q>(u, xin, j, F::stage2_wave(), act, lds, tw);
+    if (!act) return;
+    twiddle24(xin, tw, j);
+    cplx G[3][8];
+    dft24_g(xin, G);
+    double c0[NQB], c1[NQB];
+    bkg_row_coeffs<NQB>(bk, bpq, l0, N0, c0);
+    bkg_row_coeffs<NQB>(bk, bpq, has1 ? l1 : l0, N0, c1);
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {             // the row's coefficients are the same in every lane: keep them in scalar registers
+        const bool on = q < bk.nq;
+        const double v0 = on ? c0[q] : 0.0, v1 = on ? c1[q] : 0.0;
+        c0[q] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v0)), __builtin_amdgcn_readfirstlane(__double2loint(v0)));
+        c1[q] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
+    }
+    const double* __restrict__ j0 = J + (size_t)l0 * N1;
+    const double* __restrict__ j1 = J + (size_t)(has1 ? l1 : l0) * N1;
+    double* __restrict__ d0 = DIFF + (size_t)l0 * N1;
+    double* __restrict__ d1 = DIFF + (size_t)(has1 ? l1 : l0) * N1;
+    const unsigned jb = (unsigned)j * (unsigned)sizeof(double);
+#pragma unroll
+    for (int cb = 0; cb < 24 / EB; ++cb) {
+        const int c = cb / (8 / EB), dq = EB * (cb % (8 / EB));
+        double jv0[EB], jv1[EB], tb[EB][NQB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int n0 = NQ * (dq + e + 8 * c);
+            jv0[e] = *at_byte(j0 + n0, jb);
+            jv1[e] = *at_byte(j1 + n0, jb);
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) tb[e][q] = *at_byte(bk.tby + (size_t)min(q, bk.nq - 1) * N1 + n0, jb);      // clamped: always valid
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int n0 = NQ * (dq + e + 8 * c);
+            const cplx z = dft24_x(G, dq + e, c);    // conj(result): row 0 = z.x, row 1 = -z.y
+            double B0 = 0.0, B1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) {
+                B0 = fma(c0[q], tb[e][q], B0);
+                B1 = fma(c1[q], tb[e][q], B1);
+            }
+            *at_byte(d0 + n0, jb) = jv0[e] - B0 - z.x;
+            if (has1) *at_byte(d1 + n0, jb) = jv1[e] - B1 + z.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ================================================================================================
 // The 577-point sub-transform of a four-step column axis (9232 = 16 x 577, config 5) by Rader's algorithm, in registers:
 // the two 576-point transforms of the cyclic convolution are 24 x 24, 24 threads per sequence with 24 points each, and every stage is

@@ -733,6 +733,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     p->rows_r24 = (p->no_fast_fft || getenv("SFFT_NO_ROWS_R24")) ? 0 : r24_q(p->ax1);
     p->cols_r24 = (p->no_fast_fft || getenv("SFFT_NO_COLS_R24")) ? 0 : r24_q(p->ax0);
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_r24<24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!p->ax0.big) {
         pick_col_tile(p->ax0, &p->TC, &p->MS);
@@ -2459,6 +2460,17 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
             else
                 hipLaunchKernelGGL(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
+                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
+        }
+        else if (p->rows_r24 && p->nby <= 4 && !getenv("SFFT_NO_INV_R24") && (p->rows_r24 == 16 || getenv("SFFT_INV_R24_9216"))) {
+            // 6144-point rows: the register-resident inverse pass (fft_r24.hpp): config 3 inverse 0.49 -> 0.30 ms.  (9216 points: its 576
+            // threads put three waves on one SIMD, 168 registers each, and the kernel spills 316 bytes: 1.21 ms against the generic pass's
+            // 1.13 -- behind SFFT_INV_R24_9216=1.)
+            if (p->rows_r24 == 16)
+                hipLaunchKernelGGL((rows_c2r_diff_r24<16, 4>), dim3((p->N0 + 1) / 2), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, FD, d_J,
+                                   d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
+            else
+                hipLaunchKernelGGL((rows_c2r_diff_r24<24, 4>), dim3((p->N0 + 1) / 2), dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
         }
         else if (p->nby <= 4)
