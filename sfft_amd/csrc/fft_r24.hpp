@@ -341,36 +341,7 @@ __global__ void __launch_bounds__(24 * Q) rows_c2r_diff_r24(const cplx* __restri
     const cplx* __restrict__ f0 = FD + (size_t)l0 * lay.rstride;
     const cplx* __restrict__ f1 = FD + (size_t)(has1 ? l1 : l0) * lay.rstride;
     const double h1 = has1 ? 1.0 : 0.0;
-    cplx u[16];
-#pragma unroll
-    for (int hb = 0; hb < 16 / LB; ++hb) {
-        cplx a0[LB], a1[LB];
-#pragma unroll
-        for (int r = 0; r < LB; ++r) {
-            const int m = j + F::NT * (LB * hb + r);
-            const int mm = (m > N1 / 2) ? N1 - m : m;
-            const unsigned mo = (unsigned)lay.col(mm) * (unsigned)sizeof(cplx);
-            a0[r] = *at_byte(f0, mo); a1[r] = *at_byte(f1, mo);
-        }
-#pragma unroll
-        for (int r = 0; r < LB; ++r) {
-            const int m = j + F::NT * (LB * hb + r);
-            const bool mir = m > N1 / 2;
-            const int mm = mir ? N1 - m : m;
-            cplx x0 = a0[r], x1 = make_double2(a1[r].x * h1, a1[r].y * h1);
-            if (mm == 0 || mm == N1 / 2) { x0.y = 0.0; x1.y = 0.0; }
-            if (mir) { x0.y = -x0.y; x1.y = -x1.y; }
-            u[LB * hb + r] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    cplx xin[24];
-    const bool act = F::stage3_wave();
-    fft_r24_front<Q>(u, xin, j, F::stage2_wave(), act, lds, tw);
-    if (!act) return;
-    twiddle24(xin, tw, j);
-    cplx G[3][8];
-    dft24_g(xin, G);
+    // (the background coefficients of the two rows first, while nothing else is live)
     double c0[NQB], c1[NQB];
     bkg_row_coeffs<NQB>(bk, bpq, l0, N0, c0);
     bkg_row_coeffs<NQB>(bk, bpq, has1 ? l1 : l0, N0, c1);
@@ -381,6 +352,38 @@ __global__ void __launch_bounds__(24 * Q) rows_c2r_diff_r24(const cplx* __restri
         c0[q] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v0)), __builtin_amdgcn_readfirstlane(__double2loint(v0)));
         c1[q] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
     }
+    // N1 / 2 = 8 NT: the elements r < 8 (m = j + NT r < N1 / 2) come straight from column m, the elements r >= 8 from column N1 - m with
+    // the imaginary part's sign flipped -- known per r at compile time; m = 0 and m = N1 / 2 (thread 0, r = 0 and r = 8) are real
+    cplx u[16];
+    const double keep = (j == 0) ? 0.0 : 1.0;
+#pragma unroll
+    for (int hb = 0; hb < 16 / LB; ++hb) {
+        cplx a0[LB], a1[LB];
+#pragma unroll
+        for (int r = 0; r < LB; ++r) {
+            const int rr = LB * hb + r;
+            const int mm = (rr < 8) ? j + F::NT * rr : N1 - F::NT * rr - j;
+            const unsigned mo = (unsigned)lay.col(mm) * (unsigned)sizeof(cplx);
+            a0[r] = *at_byte(f0, mo); a1[r] = *at_byte(f1, mo);
+        }
+#pragma unroll
+        for (int r = 0; r < LB; ++r) {
+            const int rr = LB * hb + r;
+            cplx x0 = a0[r], x1 = make_double2(a1[r].x * h1, a1[r].y * h1);
+            if (rr == 0 || rr == 8) { x0.y *= keep; x1.y *= keep; }
+            if (rr >= 8) { x0.y = -x0.y; x1.y = -x1.y; }
+            u[rr] = make_double2(x0.x - x1.y, -(x0.y + x1.x));      // conj(X0 + i X1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    cplx xin[24];
+    const bool act = F::stage3_wave();
+    fft_r24_front<Q>(u, xin, j, F::stage2_wave(), act, lds, tw);
+    if (!act) return;
+    twiddle24(xin, tw, j);
+    cplx G[3][8];
+    dft24_g(xin, G);
+    __builtin_amdgcn_sched_barrier(0);          // (the epilogue's loads issued ahead of this point are spilled at 9216 points)
     const double* __restrict__ j0 = J + (size_t)l0 * N1;
     const double* __restrict__ j1 = J + (size_t)(has1 ? l1 : l0) * N1;
     double* __restrict__ d0 = DIFF + (size_t)l0 * N1;

@@ -2462,10 +2462,11 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
                 hipLaunchKernelGGL(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
         }
-        else if (p->rows_r24 && p->nby <= 4 && !getenv("SFFT_NO_INV_R24") && (p->rows_r24 == 16 || getenv("SFFT_INV_R24_9216"))) {
-            // 6144-point rows: the register-resident inverse pass (fft_r24.hpp): config 3 inverse 0.49 -> 0.30 ms.  (9216 points: its 576
-            // threads put three waves on one SIMD, 168 registers each, and the kernel spills 316 bytes: 1.21 ms against the generic pass's
-            // 1.13 -- behind SFFT_INV_R24_9216=1.)
+        else if (p->rows_r24 && p->nby <= 4 && getenv("SFFT_INV_R24") && atoi(getenv("SFFT_INV_R24")) == 1) {
+            // 6144- / 9216-point rows: the register-resident inverse pass (fft_r24.hpp), OFF by default.  Alone it is faster (config 3
+            // inverse 0.48 -> 0.29 ms, config 5 1.15 -> 1.00 ms) but with two pairs in flight the configs lose throughput (config 3: 44.0 ->
+            // 43.3 pairs/s, config 5: 34.4 -> 33.9): its 246 registers x 384 threads fill a CU's register file, where the generic pass
+            // (168 registers, one workgroup per CU) leaves room for the other pair's Omega waves.  Latency switch: SFFT_INV_R24=1.
             if (p->rows_r24 == 16)
                 hipLaunchKernelGGL((rows_c2r_diff_r24<16, 4>), dim3((p->N0 + 1) / 2), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
