@@ -56,10 +56,10 @@ COLS_KERNEL = {(9232, 9216): "strided_dft (four-step 9232 = 16 x 577 column axis
 CONFIGS = {
     2: dict(N0=4096, N1=4096, w=8, DK=2, DB=2, batch=64, streams=4,
             name="BASELINE configs[1]: 4096x4096 pairs, KerHW 8, KerPolyOrder 2, BGPolyOrder 2, ConstPhotRatio, fp64"),
-    3: dict(N0=6144, N1=6144, w=8, DK=2, DB=2, batch=4, streams=2, bspline=True,
+    3: dict(N0=6144, N1=6144, w=8, DK=2, DB=2, batch=6, streams=3, bspline=True,
             name="BASELINE configs[2]: BSplineSFFT, 6144x6144 pairs, KerHW 8, B-spline kernel degree 2 with 2x2 internal knots "
                  "(Fij 25, NEQ 7231), constant scaling, polynomial background degree 2, fp64"),
-    5: dict(N0=9232, N1=9216, w=12, DK=3, DB=3, batch=2, streams=1,
+    5: dict(N0=9232, N1=9216, w=12, DK=3, DB=3, batch=4, streams=2,
             name="BASELINE configs[4]: 9232x9216 pairs, KerHW 12, KerPolyOrder 3, BGPolyOrder 3, ConstPhotRatio, fp64"),
 }
 
@@ -168,7 +168,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE config (1-based as in SURVEY 8d): 2 = headline")
     ap.add_argument("--pairs", type=int, default=0, help="config-4 mode: a fixed batch of this many config-2 pairs dealt round-robin "
                     "to the ranks (62 = one DECam focal plane); a step = the whole batch")
-    ap.add_argument("--batch", type=int, default=0, help="distinct pairs per GPU and step (default: 64 / 4 / 2 for config 2 / 3 / 5)")
+    ap.add_argument("--batch", type=int, default=0, help="distinct pairs per GPU and step (default: 64 / 6 / 4 for config 2 / 3 / 5, with 4 / 3 / 2 pairs in flight)")
     ap.add_argument("--streams", type=int, default=0, help="independent pairs in flight per GPU (one plan + stream + host thread each)")
     ap.add_argument("--size", type=int, default=0, help="override the image side (square), e.g. for a quick run")
     ap.add_argument("--kerhw", type=int, default=0)
