@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) vconv_direct(const cplx* __restrict__ sta
 // both rows (row y feeds window slot q, row y + 1 slot q + 1), which halves the LDS traffic and doubles the arithmetic behind
 // every LDS round trip; the window has L + 1 slots and slides by two.
 template <int DK, int W, int KS>
-__global__ void __launch_bounds__(256, (DK <= 2 ? 2 : 3)) vconv_mixed2(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
+__global__ void __launch_bounds__(256, ((DK <= 2 || W > 8) ? 2 : 3)) vconv_mixed2(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
                                                        const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
                                                        cplx* __restrict__ trash, int Rrt, int m_direct)
 {

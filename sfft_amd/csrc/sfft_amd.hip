@@ -2368,7 +2368,10 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         } else {
         constexpr int KS = 4;       // source rows per stream = KS * L (3..10 measured: 4 is best at KerHW 8)
         int R = KS * LT - 2 * p->vw, Rrt = 0, ntile = (p->Nh + 15) / 16, m_direct = p->Nh;
-        if (p->vconv_rp == 2 && p->vw <= 8 && p->vconv_r != 0) {
+        // the two-row walk (vconv_mixed2) for KerHW 9 .. 12 as well (two workgroups per CU there: 64 KB of weights for 10 terms x 25 taps):
+        // config 5 construct 3.2 -> 1.8 ms; SFFT_VCONV2_W12=0 restores the one-row walk (vconv_mixed) for those widths
+        const int vw2max = (getenv("SFFT_VCONV2_W12") && atoi(getenv("SFFT_VCONV2_W12")) == 0) ? 8 : 12;
+        if (p->vconv_rp == 2 && p->vw <= vw2max && p->vconv_r != 0) {
             // the walk is fp64-VALU bound and a workgroup puts one wave on each SIMD of its CU, so the launch takes
             // (workgroups per CU, rounded up) x (steps per stream): pick the stream length that minimises it.  A last tile of one or
             // two columns (the Nyquist column of an even N1) goes to vconv_direct, so that it does not cost a round of its own.
@@ -2380,7 +2383,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
                 for (int y = 1; y <= (p->N0 + 255) / 256; ++y) {
                     const int Rc = (p->N0 + 16 * y - 1) / (16 * y);
                     if (Rc < 16 && y > 1) break;
-                    const int occ = p->DK <= 2 ? 2 : 3;          // workgroups resident per CU (launch bounds of vconv_mixed2)
+                    const int occ = (p->DK <= 2 || p->vw > 8) ? 2 : 3;          // workgroups resident per CU (launch bounds of vconv_mixed2)
                     const int wgs = ntile * y, rounds = (wgs + occ * p->num_cu - 1) / (occ * p->num_cu);
                     const int k = rounds > 1 ? rounds * occ : (wgs + p->num_cu - 1) / p->num_cu;
                     const double cost = (double)k * ((Rc + 2 * p->vw + 1) / 2) * (k == 1 ? 1.6 : 1.0);      // (a lone wave issues fp64 FMAs at 0.6 of the rate)
@@ -2410,11 +2413,11 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         dim3 g3(ctiles, ((p->N0 + R3 - 1) / R3 + 3) / 4); \
         hipLaunchKernelGGL((vconv_mixed3<(DKT <= 2 || WT <= 4 ? DKT : 2), (WT <= 8 ? WT : 8)>), g3, dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
                            p->Nhp, p->lay, R3); } else \
-        if (p->vconv_rp >= 2 && WT <= 8) { \
-        HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        if (m_direct < p->Nh && p->vconv_direct_launch) hipLaunchKernelGGL((vconv_direct<DKT, (WT <= 8 ? WT : 8)>), dim3((p->N0 + 255) / 256, p->Nh - m_direct), \
+        if (p->vconv_rp >= 2 && WT <= vw2max) { \
+        HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed2<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        if (m_direct < p->Nh && p->vconv_direct_launch) hipLaunchKernelGGL((vconv_direct<DKT, WT>), dim3((p->N0 + 255) / 256, p->Nh - m_direct), \
                                                  dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, m_direct); \
-        hipLaunchKernelGGL((vconv_mixed2<DKT, (WT <= 8 ? WT : 8), KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
+        hipLaunchKernelGGL((vconv_mixed2<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
                            p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp, Rrt, p->vconv_direct_launch ? p->Nh : m_direct); } else { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \

@@ -1278,12 +1278,13 @@ def test_omega_launch_variants_agree(dev, shape, w, DK):
     greek_g1_lastcol when it would be a tile of its own -- N1 = 288 and 4096 here -- and the persistent form when a tile has more
     than one block -- order 3), SFFT_G1_RPC (uneven row chunks), SFFT_G1_QUAD (four-wave workgroups, one per CU) -- all measured slower or
     no faster -- and SFFT_THETA_SLOTS=0 (KerHW 9 .. 16: the Theta passes in a launch of their own instead of slots
-    of the first Omega launch; the KerHW 12 case here).  Same system."""
+    of the first Omega launch; the KerHW 12 case here) and SFFT_VCONV2_W12=0 (KerHW 9 .. 12: the one-row tap walk of the apply pass).
+    Same system, same difference image."""
     from sfft_amd.utils.synthetic import make_pair
     pair = make_pair(*shape, seed=5 + w, mask=True, density=400.0)
     ref = _subtract_with_env(dev, {}, shape, w, DK, 1, pair)
     for env in ({"SFFT_G1_WG": "1"}, {"SFFT_G1_RPC": "%d" % (16 * max(1, (3 * shape[0] // 8) // 16))}, {"SFFT_G1_WG": "1", "SFFT_G1_S": "2"},
-                {"SFFT_G1_QUAD": "1"}, {"SFFT_THETA_SLOTS": "0"}):
+                {"SFFT_G1_QUAD": "1"}, {"SFFT_THETA_SLOTS": "0"}, {"SFFT_VCONV2_W12": "0"}):
         alt = _subtract_with_env(dev, env, shape, w, DK, 1, pair)
         assert np.max(np.abs(alt[2] - ref[2])) <= 1e-11 * np.max(np.abs(ref[2])), env
         assert np.max(np.abs(alt[3] - ref[3])) <= 1e-11 * np.max(np.abs(ref[3])), env
