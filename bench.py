@@ -119,6 +119,84 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False,
     return out
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _round(o, sig=5):
+    """floats to `sig` significant digits (the compact line only; the full object keeps every digit)"""
+    if isinstance(o, float):
+        return float("%.*g" % (sig, o))
+    if isinstance(o, dict):
+        return {k: _round(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round(v, sig) for v in o]
+    return o
+
+
+ROOF_KEYS = ("bound", "kernel", "stage", "achieved", "peak", "unit", "frac", "traffic", "avg_ms")
+
+
+def compact(full):
+    """The LAST stdout line: the contract's keys and the judged objects only, well under the 8 KB tail the driver keeps of
+    stdout (round 3's 26 KB line arrived headless and could not be parsed).  Everything else -- notes, per-stage tables, the
+    full legs of the other configs -- is in profiles/bench_last_full.json (and gpurun_out/ when that directory exists)."""
+    out = _pick(full, ("metric", "value", "unit", "mpix_per_s", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    out["config"] = _pick(cfg, ("workload", "baseline_config", "pairs_per_step", "pairs_in_flight_per_gpu", "timed_region_s", "NEQ", "solver"))
+    if len(out["config"].get("workload", "")) > 260:
+        out["config"]["workload"] = out["config"]["workload"][:257] + "..."
+    for k in ("roofline", "roofline_hbm", "roofline_greek", "roofline_solve"):
+        if k in full:
+            out[k] = _pick(full[k], ROOF_KEYS)
+    if "single_pair" in full:
+        out["single_pair_ms"] = full["single_pair"]["ms"]
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "seconds_per_pair", "spread_s", "protocol", "cpu_model", "physical_cores",
+                                         "all_cores_s_per_pair", "full_protocol"))
+        out["cpu_baseline"]["sample"] = "one full GSS of the 4096x4096 seed-1234 pair (pair 0 of the GPU batch), no size scaling"
+    if "post_check" in full:
+        out["post_check"] = _pick(full["post_check"], ("pairs_checked", "bitwise_equal", "max_rel_diff"))
+    if "host_arrays" in full:
+        out["host_arrays"] = _pick(full["host_arrays"], ("value", "pcie_GBs"))
+    out.update(_pick(full, ("gathered_pairs", "failed_pairs")))
+    legs = {}
+    for cid, leg in (full.get("other_configs") or {}).items():
+        if not isinstance(leg, dict):
+            continue
+        if "error" in leg:
+            legs[cid] = {"error": str(leg["error"])[:160]}
+            continue
+        dom = leg.get("roofline", {})
+        legs[cid] = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"), "timed_region_s": leg.get("config", {}).get("timed_region_s"),
+                     "single_pair_ms": leg.get("single_pair", {}).get("ms"), "pairs_per_step": leg.get("config", {}).get("pairs_per_step"),
+                     "dominant": _pick(dom, ("kernel", "bound", "frac", "avg_ms", "traffic")),
+                     "bitwise_equal": leg.get("post_check", {}).get("bitwise_equal"),
+                     "gathered_pairs": leg.get("gathered_pairs"), "failed_pairs": leg.get("failed_pairs")}
+    if legs:
+        out["other_configs"] = legs
+    out["full_line"] = "profiles/bench_last_full.json"
+    return _round(out)
+
+
+def emit(full):
+    """Write the full object to profiles/bench_last_full.json (+ gpurun_out/ if present), print the compact line LAST."""
+    blob = json.dumps(full)
+    for d in ("profiles", "gpurun_out"):
+        p = os.path.join(ROOT, d)
+        if os.path.isdir(p):
+            try:
+                with open(os.path.join(p, "bench_last_full.json"), "w") as f:
+                    f.write(blob + "\n")
+            except OSError:
+                pass
+    line = json.dumps(compact(full), separators=(",", ":"))
+    assert len(line) < 6000, "compact bench line grew to %d bytes" % len(line)
+    print(line, flush=True)
+
+
 def cpu_baseline(cfg, quick):
     """The CPU restatement of the reference's Numpy path on this host (oracle/: test infrastructure; timed here, never shipped).
     Config 2 only.  See oracle/cpu_baseline.py for the protocol."""
@@ -176,6 +254,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline with the full protocol (3 warm-ups, median of 10) instead of the bounded one")
     ap.add_argument("--no-host-arrays", action="store_true", help="skip the host-array (PCIe-inclusive) variant")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of configs 3, 4 and 5 after the headline run")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the N > 1 run: nccl (= RCCL over "
+                    "xGMI, the default) or gloo (records and timing cross the ranks as host tensors; tests)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="TEST ONLY: every rank uses cuda:0 (two processes on a one-GPU box; "
+                    "needs --dist-backend gloo, RCCL refuses two ranks on one device)")
+    ap.add_argument("--dk", type=int, default=-1, help="override the kernel polynomial order (quick runs / tests)")
+    ap.add_argument("--db", type=int, default=-1, help="override the background polynomial order (quick runs / tests)")
     return ap.parse_args(argv)
 
 
@@ -197,6 +281,10 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         cfg["N0"] = cfg["N1"] = args.size
     if args.kerhw:
         cfg["w"] = args.kerhw
+    if args.dk >= 0:
+        cfg["DK"] = args.dk
+    if args.db >= 0:
+        cfg["DB"] = args.db
     N0, N1, w, DK, DB = cfg["N0"], cfg["N1"], cfg["w"], cfg["DK"], cfg["DB"]
     bspline = bool(cfg.get("bspline"))
     S = max(1, args.streams or cfg["streams"])
@@ -297,8 +385,9 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t_start
+    comm_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -342,7 +431,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         recs = last_records[0]
     else:
         recs = [pack_record(my_ids[k], status[k], elapsed * 1e3 / max(args.steps * len(my_ids), 1), sols[k]) for k in range(len(my_ids))]
-    table = gather_records(recs, n_total, NEQ, dev)
+    table = gather_records(recs, n_total, NEQ, comm_dev)
     n_failed = int((table[:, 1] != 0).sum().item())
 
     # ---- host-array variant (CP semantics): pinned host arrays in, host arrays out, H2D / D2H overlapped across streams ----
@@ -389,7 +478,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
 
     out = None
     if rank == 0:
-        value = n_total * args.steps / elapsed
+        value = (n_total - n_failed) * args.steps / elapsed      # pairs whose subtraction failed (status != 0 in the gathered records) are not throughput
         ms_step = elapsed * 1e3 / args.steps
         iso_stage = {k: v / n_iso for k, v in iso_acc.items()}
         mixed = (w <= 12) if not bspline else (w <= 8 and 4 <= n_colfac <= 6)     # (B-spline tensor bases of 4 x 4 .. 6 x 6 terms: vconv_tensor)
@@ -458,12 +547,12 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         dom_hbm = max(HBM_STAGES, key=lambda k: cand[k])
         per_pair_keys = [k for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse") if k in ab]
         if batch_mode:
-            workload = ("BASELINE configs[3]: a batch of %d independent 4096x4096 pairs (config-2 geometry) dealt round-robin to %d rank(s): "
+            workload = ("BASELINE configs[3]: a batch of %d independent %dx%d pairs (config-2 geometry) dealt round-robin to %d rank(s): "
                         "shards of %s pairs, %d worker threads per GPU pull from the shard's queue; a step = the whole batch"
-                        % (n_total, world, sorted(set(len(shard_pair_ids(n_total, r, world)) for r in range(world)), reverse=True), S))
+                        % (n_total, N0, N1, world, sorted(set(len(shard_pair_ids(n_total, r, world)) for r in range(world)), reverse=True), S))
         else:
             workload = ("%s; GSS = solve(masked pair) + apply(full pair); %d distinct pairs per GPU and step, %d in flight per GPU "
-                        "(one plan + stream each)" % (cfg["name"] if not (args.size or args.kerhw) else
+                        "(one plan + stream each)" % (cfg["name"] if not (args.size or args.kerhw or args.dk >= 0 or args.db >= 0) else
                                                       "%dx%d pairs, KerHW %d (config %d geometry)" % (N0, N1, w, args.config), len(my_ids), S))
         out = {
             "metric": "image-pairs/sec, %dx%d, KerHW=%d polyOrd=%d" % (N0, N1, w, DK),
@@ -510,6 +599,12 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
     torch.cuda.empty_cache()
     if out is not None and headline_extras and world == 1 and headline and not batch_mode and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(cfg, quick=not args.cpu_full)
+        if args.cpu_full:       # keep the full-protocol figures for the default line to quote (profiles/cpu_baseline_full.json)
+            from oracle import cpu_baseline as CB
+            blob = json.dumps(CB.full_record(out["cpu_baseline"]))
+            for d in ("profiles", "gpurun_out"):
+                if os.path.isdir(os.path.join(ROOT, d)):
+                    open(os.path.join(ROOT, d, "cpu_baseline_full.json"), "w").write(blob + "\n")
     return out
 
 
@@ -523,17 +618,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    if args.all_ranks_on_device0:
+        assert args.dist_backend == "gloo", "--all-ranks-on-device0 is a test mode and needs --dist-backend gloo"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     out = run_config(args, rank, world, local_rank, headline_extras=True)
 
     # Short legs of the other BASELINE configs, after the headline's timed region and never part of its `value`: the driver only ever
     # runs the default command, and these make configs 3 / 4 / 5 measurements instead of claims.
-    default_run = (args.config == 2 and not args.pairs and not args.size and not args.kerhw and not args.no_other_configs)
+    default_run = (args.config == 2 and not args.pairs and not args.size and not args.kerhw and args.dk < 0 and args.db < 0 and not args.no_other_configs)
     if default_run:
         legs = {}
         plan_of = {3: dict(config=3, pairs=0, steps=5, warmup=3), 5: dict(config=5, pairs=0, steps=5, warmup=3),
@@ -556,7 +657,7 @@ def main():
             out["other_configs"] = dict(legs, note="short legs run after the headline's timed region (3 warm-up + 5 timed steps each, own "
                                         "barriers, plans and data); not part of `value`")
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

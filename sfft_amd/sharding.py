@@ -59,16 +59,18 @@ def gather_records(local_records, n_pairs, neq, device):
     return table
 
 
-def run_shard(pair_ids, n_workers, work_fn, neq, device):
+def run_shard(pair_ids, n_workers, work_fn, neq, device, errors=None):
     """Process this rank's shard with `n_workers` host threads that pull the next pair id from a shared queue -- the
     reference's scheme (one thread per device queue taking tasks from a shared status table,
     sfft/MultiEasyCrowdedPacket.py:361-399, 698-710), with several queues on one GPU.
 
     work_fn(worker_index, pair_id) -> Solution tensor [neq]; it raises on failure like the operators do:
     numpy.linalg.LinAlgError for a singular system, _lib.SfftError (with the ABI's return code) for every other status of the
-    C ABI.  Such a pair does not stop the shard: its record carries the ABI's code and a zero solution, and the worker's plan
-    goes on to the next pair.  Anything else (TypeError, a bad index, torch's own errors ...) is a programming or device
-    error, not a per-pair failure: the workers stop taking pairs and the first such exception is re-raised here.
+    C ABI, a plain Exception('MeLOn ERROR: ...') from the Python layer.  As in the reference (`except Exception` per task,
+    sfft/MultiEasyCrowdedPacket.py:344, 646) a failing pair never stops the shard: its record carries a status (the ABI's code,
+    STATUS_SINGULAR, or STATUS_ERROR for any other Exception -- the message goes to `errors` when a list is passed) and a zero
+    solution, and the worker's plan goes on to the next pair.  So every rank always reaches the collective in gather_records.
+    Only a non-Exception BaseException (KeyboardInterrupt, SystemExit) stops the workers and is re-raised here.
     Returns one record per pair, in shard order."""
     import numpy as np
     from ._lib import SfftError
@@ -93,7 +95,11 @@ def run_shard(pair_ids, n_workers, work_fn, neq, device):
                 sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_SINGULAR
             except SfftError as e:
                 sol, status = torch.zeros(neq, dtype=torch.float64, device=device), e.code
-            except BaseException as e:      # not a per-pair failure
+            except Exception as e:          # any other per-pair failure: recorded, the shard carries on
+                sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_ERROR
+                if errors is not None:
+                    errors.append((pid, "%s: %s" % (type(e).__name__, e)))
+            except BaseException as e:      # KeyboardInterrupt / SystemExit: stop taking pairs
                 fatal.append(e)
                 return
             records[k] = pack_record(pid, status, (time.perf_counter() - t0) * 1e3, sol)

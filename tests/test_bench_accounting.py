@@ -38,20 +38,53 @@ def test_algorithmic_bytes_and_flops_of_config2():
     assert ab["B_alg_reference"] == 183 * 4 * 16 * N0 * N1 + 156 * 16 * N0 * N1 + 13 * 16 * N0 * N1 + 5 * 8 * N0 * N1
 
 
-def test_committed_bench_line_keeps_the_contract():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
-    assert lines, "no committed default bench line under profiles/"
-    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline"):
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline")
+
+
+def _check_contract(d):
+    for k in CONTRACT:
         assert k in d, k
     assert d["unit"] == "image-pairs/s" and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "4096x4096" in d["config"]["workload"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 * r["frac"] + 1e-9
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and d["value"] > 100 * c["value"]
+
+
+def _last_full_line():
+    p = os.path.join(ROOT, "profiles", "bench_last_full.json")
+    if os.path.exists(p):
+        return json.loads(open(p).read().strip().splitlines()[-1])
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    assert lines, "no committed default bench line under profiles/"
+    return json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_keeps_the_contract():
+    _check_contract(_last_full_line())
+
+
+def test_compact_line_is_small_and_keeps_the_contract():
+    """Round 3's 26 KB line outgrew the driver's ~8 KB stdout tail and arrived unparseable: the LAST stdout line is now a compact
+    object built from the full one (which goes to profiles/bench_last_full.json)."""
+    b = _bench()
+    full = _last_full_line()
+    c = b.compact(full)
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    _check_contract(c)
+    for k in ("roofline", "roofline_hbm", "roofline_greek", "roofline_solve"):
+        assert set(c[k]) <= set(b.ROOF_KEYS) and "note" not in c[k] and c[k]["frac"] <= 1.0
+    assert set(c["post_check"]) == {"pairs_checked", "bitwise_equal", "max_rel_diff"}
+    for cid in ("3", "4", "5"):
+        leg = c["other_configs"][cid]
+        for k in ("value", "ms_per_step", "timed_region_s", "single_pair_ms", "dominant", "bitwise_equal"):
+            assert k in leg, (cid, k)
+    assert abs(c["value"] - full["value"]) <= 1e-4 * full["value"]
+    assert json.loads(line) == c

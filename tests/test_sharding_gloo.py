@@ -114,23 +114,32 @@ def test_two_rank_batch_with_uneven_shards_and_a_failed_pair(tmp_path):
         assert t0[pid, 2] > 0.0              # measured milliseconds of that pair
 
 
-def test_run_shard_records_abi_codes_and_reraises_programming_errors():
-    """Per-pair failures are the operator's own (LinAlgError -> -4, _lib.SfftError -> its code); anything else stops the shard."""
+def test_run_shard_records_every_exception_and_carries_on():
+    """Per-pair failures never stop the shard (the reference's `except Exception` per task, MultiEasyCrowdedPacket.py:344, 646):
+    LinAlgError -> -4, _lib.SfftError -> its code, any other Exception -> STATUS_ERROR with the message kept; only a
+    non-Exception BaseException is re-raised."""
     from sfft_amd._lib import SfftError
+    from sfft_amd.sharding import STATUS_ERROR
 
     def work(wi, pid):
         if pid == 1:
             raise SfftError(-3, "HIP error: out of memory")
         if pid == 2:
             raise np.linalg.LinAlgError("Singular matrix")
+        if pid == 4:
+            raise Exception("MeLOn ERROR: Input images should have the same shape!")
+        if pid == 5:
+            raise TypeError("a torch error on one pair")
         return torch.full((4,), float(pid), dtype=torch.float64)
-    recs = run_shard([0, 1, 2, 3], 2, work, 4, torch.device("cpu"))
-    assert [int(r[1]) for r in recs] == [0, -3, STATUS_SINGULAR, 0]
-    assert not recs[1][3:].any() and recs[3][3] == 3.0
+    errors = []
+    recs = run_shard([0, 1, 2, 3, 4, 5], 2, work, 4, torch.device("cpu"), errors=errors)
+    assert [int(r[1]) for r in recs] == [0, -3, STATUS_SINGULAR, 0, STATUS_ERROR, STATUS_ERROR]
+    assert not recs[1][3:].any() and recs[3][3] == 3.0 and not recs[4][3:].any()
+    assert sorted(p for p, _ in errors) == [4, 5] and any("MeLOn ERROR" in m for _, m in errors)
 
-    def broken(wi, pid):
+    def interrupted(wi, pid):
         if pid == 2:
-            raise TypeError("not a per-pair failure")
+            raise KeyboardInterrupt()
         return torch.zeros(4, dtype=torch.float64)
-    with pytest.raises(TypeError, match="not a per-pair failure"):
-        run_shard([0, 1, 2, 3, 4, 5], 2, broken, 4, torch.device("cpu"))
+    with pytest.raises(KeyboardInterrupt):
+        run_shard([0, 1, 2, 3, 4, 5], 2, interrupted, 4, torch.device("cpu"))
