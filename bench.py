@@ -51,7 +51,6 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s sp
 FP64_PEAK_TFLOPS = 78.6    # fp64 vector = fp64 matrix (MFMA) peak on MI355X (public spec; the guide has no fp64 MFMA row)
 HBM_COPY_MEASURED_GBS = 5700.0   # a plain 16-byte-per-lane copy kernel on this device: 5.6 - 5.8 TB/s for contiguous chunks with non-temporal
                                  # accesses, 5.2 - 5.6 plain (scripts/micro/hbm_stream2.hip, profiles/r03_hbm_stream2.txt); the guide quotes 6290
-COLS_KERNEL = {(9232, 9216): "strided_dft (four-step 9232 = 16 x 577 column axis)", (6144, 6144): "cols_fwd_weighted (6144-point mixed-radix axis)"}
 
 CONFIGS = {
     2: dict(N0=4096, N1=4096, w=8, DK=2, DB=2, batch=64, streams=4,
@@ -408,6 +407,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             iso_ms.append((time.perf_counter() - t1) * 1e3)
             for kk, v in plans[0].stage_ms().items():
                 iso_acc[kk] = iso_acc.get(kk, 0.0) + v
+            stage_kernels = plans[0].stage_kernels()          # the kernels each stage launched (names as at the launch sites: what rocprof lists)
             same = bool(torch.equal(fresh_s, sols[k])) and bool(torch.equal(fresh_d, diffs[k]))
             post["bitwise_equal"] = post["bitwise_equal"] and same
             if not same:
@@ -494,22 +494,21 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         except Exception:
             pass
-        fast = (N0 == 4096 and N1 == 4096)
+        # per config ("2" / "3" / "5") and stage; only for the configs' own geometry
+        native = not (args.size or args.kerhw or args.dk >= 0 or args.db >= 0)
+        pmc_cfg = pmc.get(str(args.config), {}) if native else {}
         g1_mfma = bool(plans[0].query("G1_MFMA"))
-        KERNEL_OF = {"fwd_cols": "cols_fwd_weighted_4096_q" if fast else COLS_KERNEL.get((N0, N1), "cols_fwd_weighted"),
-                     "fwd_rows": "rows_r2c_4096" if fast else "rows_r2c",
-                     "greek_g1": ("greek_g1_mfma4g (Omega passes in groups%s)" % (" + the Theta passes" if theta_fused else "")) if g1_mfma
-                                 else "greek_g1<12, 2, true> (Omega passes, vector kernel in two lag bands)",
-                     "greek_g1b": ("" if theta_fused else "greek_g1<8, 2> (Theta passes) + ") + "row_moments / gamma_rows / gamma_patches (Gamma block)",
-                     "prelim_apply": "rows_r2c_4096 (apply pass)" if fast else "rows_r2c (+ cols_fwd_weighted) of the apply pass",
-                     "inverse": "rows_c2r_diff_4096" if fast else "rows_c2r_diff (+ cols_c2c)",
-                     "solve": "chol_dataflow (+ chol_inv_diag, chol_back_all, scatter_solution)" if plans[0].query("CHOL_DATAFLOW") else
-                              "chol_step / chol_panel / chol_syrk chain (+ chol_back_all)",
-                     "construct": ("vconv_tensor" if bspline else "vconv_mixed2<2, 8, 4>") if mixed and w <= 8 else ("vconv_mixed" if mixed else "construct_fd")}
+        # names of the kernels each stage launched in the isolated run (sfft_stage_kernels): the minor helpers are dropped from the label
+        MINOR = ("set_i32", "zero_f64", "chol_begin", "scatter_solution", "delta_finish", "kernel_ctab_mixed", "chol_copy_diag")
+
+        def label(stage):
+            names = [k for k in stage_kernels.get(stage, []) if k not in MINOR]
+            return " + ".join(names) if names else stage
+        KERNEL_OF = {k: label(k) for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse")}
 
         def roof(stages, dom="fwd_cols"):
             ach = ab[dom] / (max(stages[dom], 1e-6) * 1e-3) / 1e9      # (a stage that was not timed separately, e.g. SFFT_STAGE_INTERLEAVE=1, reads 0)
-            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if headline else None
+            traffic = pmc_cfg.get(dom, {}).get("hbm_bytes_per_launch")
             return {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "sustained_peak_measured": HBM_COPY_MEASURED_GBS,
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": stages[dom]}
@@ -517,7 +516,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         def roof_flops(stages):
             # `achieved` prices the MATRIX-pipe work only (the lag sums); the products and butterflies on the vector ALUs are listed beside it
             tf = ab["greek_g1_mfma_flops"] / (stages["greek_g1"] * 1e-3) / 1e12
-            traffic = pmc.get("greek_g1", {}).get("hbm_bytes_per_launch") if headline else None
+            traffic = pmc_cfg.get("greek_g1", {}).get("hbm_bytes_per_launch")
             return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_mfma_flops"],
                     "valu_flops_per_launch": ab["greek_g1_flops"] - ab["greek_g1_mfma_flops"],
@@ -536,14 +535,27 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             fl = n_sys ** 3 / 3.0                       # Cholesky factorisation (the triangular solves are O(n^2))
             tf = fl / (max(stages["solve"], 1e-6) * 1e-3) / 1e12
             return {"bound": "mfma", "regime": "latency: a chain of dependent 64-column block steps, not throughput", "kernel": KERNEL_OF["solve"],
-                    "stage": "solve", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
+                    "stage": "solve", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                    "traffic": pmc_cfg.get("solve", {}).get("hbm_bytes_per_launch"),
                     "alg_flops_per_launch": fl, "unknowns": n_sys, "avg_ms": stages["solve"]}
 
         # the dominant stage by kernel time of one pair, among everything that is timed
         HBM_STAGES = [k for k in ("fwd_rows", "fwd_cols", "prelim_apply", "construct", "inverse") if k in ab]
         cand = {k: iso_stage.get(k, 0.0) for k in HBM_STAGES + ["greek_g1", "solve"]}
         dom = max(cand, key=lambda k: cand[k])
-        roofline = roof_solve(iso_stage) if dom == "solve" else roof_flops(iso_stage) if (dom == "greek_g1" and g1_mfma) else roof(iso_stage, dom)
+        def roof_greek(stages):
+            """the Omega + Theta launch: priced on the matrix pipe unless its measured HBM traffic over its duration exceeds 4 TB/s -- then it sits
+            on the memory side (config 3: 7x over-fetch) and is reported as bound "hbm" with the TRAFFIC rate as `achieved`"""
+            r = roof_flops(stages) if g1_mfma else roof(stages, "greek_g1")
+            t = r.get("traffic")
+            if t and g1_mfma:
+                rate = t / (stages["greek_g1"] * 1e-3) / 1e9
+                r["hbm_traffic_GBs"] = rate
+                if rate > 4000.0:
+                    r = dict(r, bound="hbm", mfma_frac=r["frac"], mfma_achieved_tflops=r["achieved"], achieved=rate, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=rate / HBM_PEAK_GBS)
+            return r
+        roofline = roof_solve(iso_stage) if dom == "solve" else roof_greek(iso_stage) if dom == "greek_g1" else roof(iso_stage, dom)
         dom_hbm = max(HBM_STAGES, key=lambda k: cand[k])
         per_pair_keys = [k for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse") if k in ab]
         if batch_mode:
@@ -569,7 +581,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
                              kernel_ms_per_pair={k: iso_stage[k] for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "greek_g2", "fill", "solve",
                                                                            "prelim_apply", "construct", "inverse") if k in iso_stage}),
             "roofline_hbm": dict(roof(iso_stage, dom_hbm), measured="same events, same launches: the HBM-bound stage with the most time"),
-            "roofline_greek": dict(roof_flops(iso_stage), measured="same events, same launches"),
+            "roofline_greek": dict(roof_greek(iso_stage), measured="same events, same launches"),
             "roofline_solve": dict(roof_solve(iso_stage), measured="same events, same launches"),
             "hbm_stages": {k: {"GBs": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9, "frac": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "ms": iso_stage[k], "alg_bytes": ab[k], "kernel": KERNEL_OF.get(k, k)} for k in HBM_STAGES},
@@ -584,6 +596,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
                                "note": "reference-algorithm bytes (SURVEY 8d) x pairs/s per GPU; context, not the roofline: the build's own "
                                        "algorithmic bytes per pair are listed beside it"},
             "gathered_pairs": int(table.shape[0]), "failed_pairs": n_failed,
+            "stage_kernels": stage_kernels,     # the kernels each stage launched, as the library recorded them (sfft_stage_kernels)
         }
         if batch_mode:
             ms = table[:, 2].cpu().numpy()

@@ -48,7 +48,7 @@ enum {
     SFFT_Q_SCAFIJ,                  /* scaling terms of a plan made by sfft_plan_create_varscale (0 otherwise) */
     SFFT_Q_SOLVE_GRAPH,             /* 1 once the factorisation chain of this plan has been captured and replays as a hipGraph */
     SFFT_Q_THETA_FUSED,             /* 1: the Theta passes ride in the Omega launch of this plan (stage GREEK_G1 then carries them) */
-    SFFT_Q_OMG_OFFDIAG,             /* Omega products I_a x conj(I_b), a < b, that are transformed (all Fij (Fij - 1) / 2 unless SFFT_OMG_REDUCE=1) */
+    SFFT_Q_OMG_OFFDIAG,             /* Omega products I_a x conj(I_b), a < b, that are transformed (all Fij (Fij - 1) / 2 of them) */
     SFFT_Q_OMG_DIAG,                /* the same for a = b */
     SFFT_Q_G1_DECIMATED,            /* 1: the Omega launch of this plan takes a radix-2 decimation step along the rows (half the matrix instructions) */
     SFFT_Q_G1_CHUNKS,               /* row chunks of the Greek stage-1 launches: each writes one partial lag sum per pass, lag and spectrum column */
@@ -194,6 +194,11 @@ int sfft_set_timing(sfft_plan* plan, int enable);
 
 /* milliseconds spent in stage `stage` (SFFT_ST_*) during the most recent timed call; synchronises */
 int sfft_stage_ms(sfft_plan* plan, int stage, float* ms);
+
+/* Names of the HIP kernels stage `stage` has launched since timing was last enabled (sfft_set_timing(plan, 1) clears the lists), as
+ * written at their launch sites, each once, ';'-separated, NUL-terminated, truncated to `cap` bytes -- so that a benchmark line can name the
+ * kernels its stage times belong to (the reference prints stage letters only, sfft/sfftcore/SFFTSubtract.py:594-597). */
+int sfft_stage_kernels(sfft_plan* plan, int stage, char* buf, int cap);
 
 /* force the LU fallback for every solve (1) or let the plan choose (0, default: Cholesky first) */
 int sfft_set_force_lu(sfft_plan* plan, int enable);

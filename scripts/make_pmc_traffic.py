@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
-"""Build profiles/pmc_traffic.json from two pmc_summary.py outputs (FETCH_SIZE, WRITE_SIZE; KB per launch).
+"""Build profiles/pmc_traffic.json from a scripts/gpu_round.sh output directory:
 
-    python scripts/make_pmc_traffic.py profiles/rXX_pmc_FETCH_SIZE.txt profiles/rXX_pmc_WRITE_SIZE.txt > profiles/pmc_traffic.json
+    python scripts/make_pmc_traffic.py gpurun_out/r04 > profiles/pmc_traffic.json
 
-Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE x2 for 16-byte-per-lane streaming reads
-on gfx950; WRITE_SIZE as is.  Keys are the stage names bench.py uses; kernels launched several times per pair with
-different plane counts (the FFT passes) are scaled from the mean launch to the launch bench.py times by the ratio of
-algorithmic bytes (4096^2, KerHW 8, orders 2/2: Fij = 6)."""
+For each config directory cfg2 / cfg3 / cfg5 it reads pmc_FETCH_SIZE.txt and pmc_WRITE_SIZE.txt (scripts/pmc_summary.py: mean KB per
+launch and launch count per kernel) and bench_streams1_full.json (whose `stage_kernels` says which kernels each stage launched, as
+recorded by the library) and writes, per config and stage, the HBM-side bytes of that stage for ONE image pair:
+    sum over the stage's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x launches / pairs profiled.
+Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE x2 for 16-byte-per-lane streaming reads on gfx950;
+WRITE_SIZE as is (calibration: rows_c2r_diff_4096 writes 131072.0 KB = exactly the 134217728-byte DIFF image).  A kernel that serves
+two stages (the row pass: fwd_rows of the solve and prelim_apply of the apply) is split between them by their algorithmic bytes."""
 import json
+import os
+import re
 import sys
 
 
@@ -22,36 +27,55 @@ def parse(path):
     return out
 
 
-fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
-Fij = 6
-spec, img = 4096 * 2049 * 16, 4096 * 4096 * 8
+def base(name):
+    return re.sub(r"\s+", "", name.replace("void ", "").split("<")[0].split("(")[0])
 
 
-def entry(kernels, scale=1.0, note=None):
-    # a listed name matches a profiled kernel exactly or as the part before its template arguments ("greek_g1_mfma4g" -> "greek_g1_mfma4g<false, true>")
-    def hit(name, k):
-        return name == k or name.startswith(k + "<")
-    f = sum(v[1] for name, v in fetch.items() if any(hit(name, k) for k in kernels))
-    w = sum(v[1] for name, v in write.items() if any(hit(name, k) for k in kernels))
-    e = {"kernels": kernels, "fetch_kb_raw": f, "write_kb": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 * scale}
-    if note:
-        e["note"] = note
-    return e
-
-
-doc = {
-    "_about": "HBM-side bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB units) over "
-              "`bench.py --streams 1 --steps 3 --warmup 1` on MI355X, 4096^2 KerHW 8 orders 2/2. FETCH_SIZE x2 (16-byte-per-lane "
-              "streaming reads on gfx950, MI355X_MICROARCH.md), WRITE_SIZE unchanged (calibration: rows_c2r_diff_4096 writes "
-              "131072.0 KB = exactly the 134217728-byte DIFF image).",
-    "source_files": [sys.argv[1].split("/")[-1], sys.argv[2].split("/")[-1]],
-    # cols_fwd_weighted_4096_q: one launch per pair (solve pass: 4 stage planes in, 7 planes out); the apply pass has no column transform
-    "fwd_cols": entry(["cols_fwd_weighted_4096_q"]),
-    # rows_r2c_4096: solve launch (2 images in, 4 stage planes out) vs apply launch (1 in, 3 out)
-    "fwd_rows": entry(["rows_r2c_4096"], (2 * img + 4 * spec) / (0.5 * (2 * img + 4 * spec + img + 3 * spec)),
-                      "mean over the solve and apply launches scaled to the solve launch"),
-    "greek_g1": entry(["greek_g1_mfma4g", "greek_g1_mfma<2, false>", "greek_g1_mfma4<2>"]),
-    "greek_g1b": entry(["greek_g1<8, 2>", "greek_g1_row0", "row_moments<5>", "gamma_rows", "gamma_patches"]),
-    "construct": entry(["vconv_mixed2<2, 8, 4>", "vconv_mixed<2, 8, 4>", "vconv_direct", "kernel_ctab_mixed"]),
-}
+root = sys.argv[1]
+doc = {"_about": "HBM-side bytes per stage and image pair from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB) over "
+                 "`bench.py --config C --streams 1 --batch 4 --steps 2 --warmup 1`; FETCH_SIZE x2 (16-byte-per-lane streaming reads on gfx950, "
+                 "MI355X_MICROARCH.md), WRITE_SIZE as is; stage -> kernels from the library's own record (sfft_stage_kernels); made by "
+                 "scripts/make_pmc_traffic.py from " + os.path.basename(root.rstrip("/"))}
+for cfg in ("2", "3", "5"):
+    d = os.path.join(root, "cfg" + cfg)
+    try:
+        fetch, write = parse(os.path.join(d, "pmc_FETCH_SIZE.txt")), parse(os.path.join(d, "pmc_WRITE_SIZE.txt"))
+        full = json.load(open(os.path.join(d, "bench_streams1_full.json")))
+    except Exception as e:
+        doc[cfg] = {"error": str(e)}
+        continue
+    sk = full["stage_kernels"]
+    ab = {k: v["alg_bytes"] for k, v in full.get("hbm_stages", {}).items()}
+    # bytes per kernel base name summed over all launches of the profiled run
+    tot, launches = {}, {}
+    for tab, mul in ((fetch, 2.0), (write, 1.0)):
+        for name, (n, mean_kb) in tab.items():
+            b = base(name)
+            tot[b] = tot.get(b, 0.0) + mul * mean_kb * 1024.0 * n
+            launches[b] = max(launches.get(b, 0), n)
+    # pairs the profiled run subtracted: fill_system runs once per pair
+    pairs = max(1, launches.get("fill_system", 1))
+    users = {}
+    for st, names in sk.items():
+        if st == "prelim_solve":
+            continue
+        for n in names:
+            users.setdefault(base(n), []).append(st)
+    out = {"pairs_profiled": pairs}
+    for st, names in sk.items():
+        if st == "prelim_solve" or not names:
+            continue
+        total, used = 0.0, []
+        for b in sorted(set(base(n) for n in names)):
+            if b not in tot:
+                continue
+            share = 1.0
+            sts = sorted(set(users[b]))
+            if len(sts) > 1:          # split by algorithmic bytes when they are known for every user, else evenly
+                share = ab[st] / sum(ab[s] for s in sts) if all(s in ab for s in sts) else 1.0 / len(sts)
+            total += share * tot[b] / pairs
+            used.append(b if share == 1.0 else "%s (%.2f of it)" % (b, share))
+        if used:
+            out[st] = {"kernels": used, "hbm_bytes_per_launch": total}
+    doc[cfg] = out
 print(json.dumps(doc, indent=1))

@@ -26,7 +26,7 @@ STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply
 
 EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_create_varscale", "sfft_plan_set_regularization", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
            "sfft_get_system", "sfft_get_solver_system", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",
-           "sfft_grid_convolve", "sfft_spec_abs2_accumulate", "sfft_real_rsqrt", "sfft_spec_multiply", "sfft_half_to_full_real", "sfft_set_timing", "sfft_stage_ms", "sfft_set_force_lu",
+           "sfft_grid_convolve", "sfft_spec_abs2_accumulate", "sfft_real_rsqrt", "sfft_spec_multiply", "sfft_half_to_full_real", "sfft_set_timing", "sfft_stage_ms", "sfft_stage_kernels", "sfft_set_force_lu",
            "sfft_last_error", "sfft_version"]
 
 
@@ -74,6 +74,7 @@ def _load():
     lib.sfft_grid_convolve.argtypes = [dp, dp, dp, ip, ip, ip, ip, ip, dp, ip, vp]
     lib.sfft_set_timing.argtypes = [vp, ip]
     lib.sfft_stage_ms.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_float)]
+    lib.sfft_stage_kernels.argtypes = [vp, ip, ctypes.c_char_p, ip]
     lib.sfft_set_force_lu.argtypes = [vp, ip]
     for name in EXPORTS:
         getattr(lib, name).restype = ctypes.c_int

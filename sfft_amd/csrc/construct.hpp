@@ -511,83 +511,6 @@ __global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ 
     }
 }
 
-// vconv_mixed3: register-stationary taps.  Three lanes share a spectrum column; lane group g keeps the FIJ x TPG table entries of
-// the taps q = g TPG .. g TPG + TPG - 1 (TPG = ceil(L / 3)) in registers for the whole walk, so the inner loop has no LDS traffic
-// at all: per source row TPG x 24 FMAs on register operands against 3 + 3 loads.  Group g walks source rows shifted by its first
-// tap, so that at every step the three groups complete their parts of the SAME output row; two lane shuffles add them up and
-// group 0 stores.  A wave is 20 columns (five 4-column panels) x 3 groups; the walk is unrolled TPG times so that the sliding
-// window of TPG accumulators never moves between registers.  R output rows per wave; the first TPG - 1 steps only fill the window.
-template <int DK, int W>
-__global__ void __launch_bounds__(256, 2) vconv_mixed3(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
-                                                       const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay, int R)
-{
-    constexpr int L = 2 * W + 1, NJ = DK + 1, FIJ = (DK + 1) * (DK + 2) / 2, TPG = (L + 2) / 3, NC = 20;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int g = lane / NC, cl = lane - g * NC;
-    const int gc = g < 3 ? g : 2;
-    const int m = blockIdx.x * NC + cl;
-    const bool active = g < 3 && m < Nh;
-    const int mc = m < Nh ? m : Nh - 1;
-    const int X0 = (blockIdx.y * 4 + wv) * R;          // first output row of this wave
-    if (X0 >= N0) return;
-    cplx c[FIJ][TPG];
-#pragma unroll
-    for (int t = 0; t < FIJ; ++t)
-#pragma unroll
-        for (int j = 0; j < TPG; ++j) {
-            const int q = gc * TPG + j;
-            c[t][j] = (q < L) ? Ctab[((size_t)t * L + (size_t)q) * Nhp + mc] : make_double2(0.0, 0.0);
-        }
-    const size_t plane_sz = (size_t)N0 * Nhp, mo = lay.col(mc), rs = (size_t)lay.rstride;
-    cplx acc[TPG];
-#pragma unroll
-    for (int j = 0; j < TPG; ++j) acc[j] = make_double2(0.0, 0.0);
-    // step s completes output row X0 - (TPG - 1) + s; group g is then at source row (that row) - (first tap of g) = ... - (g TPG - W)
-    int y = (X0 - (TPG - 1) - (gc * TPG - W)) % N0;
-    if (y < 0) y += N0;
-    const int nstep = R + TPG - 1;
-#pragma unroll 1
-    for (int s0 = 0; s0 < nstep; s0 += TPG) {
-#pragma unroll
-        for (int u = 0; u < TPG; ++u) {
-            cplx S[NJ];
-            double fx[NJ];
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) {
-                S[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
-                fx[jj] = jj ? kbx[(size_t)jj * N0 + y] : 1.0;
-            }
-#pragma unroll
-            for (int j = 0; j < TPG; ++j) {          // tap g TPG + j of source row y lands in the output row of window slot (u + j) mod TPG
-                const int sl = (u + j) % TPG;
-                double ax = acc[sl].x, ay = acc[sl].y;
-#pragma unroll
-                for (int jj = 0; jj <= DK; ++jj) {
-                    double ex = 0.0, ey = 0.0;                         // E_j = sum_i cx^i[y] C'_(i,j)[a]
-#pragma unroll
-                    for (int ii = 0; ii <= DK - jj; ++ii) {
-                        const int t = ii * (DK + 1) - (ii * (ii - 1)) / 2 + jj;
-                        if (ii == 0) { ex = c[t][j].x; ey = c[t][j].y; continue; }           // cx^0 = 1
-                        ex = fma(fx[ii], c[t][j].x, ex);
-                        ey = fma(fx[ii], c[t][j].y, ey);
-                    }
-                    ax = fma(S[jj].x, ex, fma(-S[jj].y, ey, ax));
-                    ay = fma(S[jj].x, ey, fma(S[jj].y, ex, ay));
-                }
-                acc[sl] = make_double2(ax, ay);
-            }
-            // window slot u is complete in all three groups
-            double vx = acc[u].x, vy = acc[u].y;
-            vx += __shfl_down(vx, NC) + __shfl_down(vx, 2 * NC);
-            vy += __shfl_down(vy, NC) + __shfl_down(vy, 2 * NC);
-            acc[u] = make_double2(0.0, 0.0);
-            const int st = s0 + u, xo = X0 - (TPG - 1) + st;
-            if (g == 0 && active && st >= TPG - 1 && st < nstep && xo < N0) D[mo + (size_t)xo * rs] = make_double2(vx, vy);
-            if (++y == N0) y = 0;
-        }
-    }
-}
-
 // separately varying scaling: DIFF -= SCALE * I * sum_s a_s00 * sbx[sp[s]][row] * sby[sq[s]][col]  (the centre term of
 // Construct_FDIFF, BSplineSFFT.py:2489-2497, taken in real space: it is a plain product there)
 struct ScaArgs {

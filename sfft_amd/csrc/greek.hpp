@@ -184,165 +184,6 @@ __global__ void __launch_bounds__(64) greek_g1(const cplx* __restrict__ spec, co
 // scalar-register bottleneck), and the 64 accumulators per lane of the vector version become 16 four-vectors.
 typedef double d4v __attribute__((ext_vector_type(4)));
 
-// NT = 16-column tiles per wave (2: 142 registers with the two load sets of the pipelined loop, three waves per SIMD, measured
-// best; 1 and 4 are slower).
-// PACK (h <= 8): the 16 rows of A hold wx of lags 1..8 and then wy of lags 1..8, so two MFMAs per tile give all four sums
-// (A Hx -> S1 in rows 0..7, S3 in rows 8..15; A Hy -> S4, S2); correct, but measured no faster than the vector kernel for the
-// short passes, so the host does not use it.  B of a pass may be a column factor (Gamma passes of plans that keep them).
-// Measured at 4096^2, KerHW 8 (15 ordinary + 3 dual diagonal Omega passes, 9.58 M MFMAs): 0.45 ms = 44 - 47 TFLOP/s, which is what a
-// loop of nothing but this instruction sustains on the device (scripts/micro/mfma_f64_peak.hip); the vector kernel: 0.65 ms.
-template <int NT, bool PACK>
-__global__ void __launch_bounds__(64, (NT == 4 ? 2 : 3)) greek_g1_mfma(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, int pass0,
-                                                                       cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
-                                                                       int rows_per_chunk, const cplx* __restrict__ W0tab, int HM,
-                                                                       const cplx* __restrict__ Xp, int ncb, int S, int npass)
-{
-    const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
-    const int total = ncb * S * npass;
-    const int per = (total + 7) >> 3;
-    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (logical >= total) return;
-    const int tile = logical / npass;
-    const int chunk = tile / ncb;
-    const int m0 = (tile - chunk * ncb) * 16 * NT;
-    const G1Pass pr = passes[pass0 + (logical - tile * npass)];
-    const int h = pr.h, PH = 2 * h + 1;
-    const int lb = chunk * rows_per_chunk;
-    const int le = min(N0, lb + rows_per_chunk);
-    const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
-    const bool colfac = pr.b_plane < 0;
-    const cplx* __restrict__ A = spec + (size_t)pr.a_plane * plane_sz;
-    const cplx* __restrict__ B = colfac ? A : spec + (size_t)pr.b_plane * plane_sz;
-    const cplx* __restrict__ xp = Xp + (size_t)pr.bp * N0;
-    const int tcol = min(PACK ? 1 + (n & 7) : 1 + n, HM - 1);   // twiddle column (lag) this lane feeds into A (lags beyond the table: unused rows of D)
-    size_t co[NT];
-    bool act[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int m = m0 + 16 * t + n;
-        act[t] = m < Nh;
-        co[t] = lay.col(act[t] ? m : Nh - 1);
-    }
-    constexpr int NS = PACK ? 2 : 4;                       // accumulator tiles per column tile
-    d4v Sx[NT][NS];
-    double g0x[NT], g0y[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int q = 0; q < NS; ++q) Sx[t][q] = (d4v){0.0, 0.0, 0.0, 0.0};
-        g0x[t] = g0y[t] = 0.0;
-    }
-    // Software pipeline, written out as two register sets that alternate (the compiler sinks a plain "load next, use
-    // current" formulation back to load-then-wait within one step, which left every step exposed to the L2 latency): the
-    // loads of step s + 1 are issued, a scheduling barrier pins them there, then the MFMAs of step s run.  Addresses are
-    // 32-bit byte offsets from wave-uniform plane bases (scalar base + vector offset loads), advanced by one add and one
-    // clamp per step; rows past the chunk are masked by vf, so the clamp only has to keep the reads inside the plane.
-    struct LoadSet { cplx tw, a[NT], b[NT]; };
-    const char* __restrict__ Ab = reinterpret_cast<const char*>(A);
-    const char* __restrict__ Bb = reinterpret_cast<const char*>(B);
-    const char* __restrict__ Xb = reinterpret_cast<const char*>(xp);
-    const char* __restrict__ Wb = reinterpret_cast<const char*>(W0tab) + (size_t)tcol * sizeof(cplx);
-    unsigned cob[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) cob[t] = (unsigned)(co[t] * sizeof(cplx));
-    const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
-    const unsigned rlast = (unsigned)(N0 - 1);
-    const unsigned r0 = min((unsigned)(lb + kq), rlast);
-    unsigned rowb = r0 * rsb, twb = r0 * hmb, xb = r0 * (unsigned)sizeof(cplx);
-    const unsigned rowb_max = rlast * rsb, twb_max = rlast * hmb, xb_max = rlast * (unsigned)sizeof(cplx);
-    // DG: two diagonal Omega passes side by side (plane A with itself, plane B with itself).  Their products |A|^2, |B|^2 are real,
-    // so each needs only two of the four sums: one wave does both with the loads and MFMAs of one ordinary pass -- and walks the
-    // rows at the pace of the ordinary passes, which the L2 sharing of a tile depends on (single diagonal passes at half the
-    // MFMAs ran ahead of the others and doubled the kernel's HBM traffic)
-    auto run = [&](auto CF, auto DGt) {
-        constexpr bool cf = decltype(CF)::value;
-        constexpr bool DG = decltype(DGt)::value;
-        auto issue = [&](LoadSet& L) {
-            L.tw = *reinterpret_cast<const cplx*>(Wb + twb);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                L.a[t] = *reinterpret_cast<const cplx*>(Ab + (cob[t] + rowb));
-                L.b[t] = cf ? *reinterpret_cast<const cplx*>(Xb + xb) : *reinterpret_cast<const cplx*>(Bb + (cob[t] + rowb));
-            }
-            rowb = min(rowb + 4u * rsb, rowb_max);
-            twb = min(twb + 4u * hmb, twb_max);
-            if (cf) xb = min(xb + 4u * (unsigned)sizeof(cplx), xb_max);
-        };
-        auto compute = [&](const LoadSet& L, double vf) {
-            const double wx = L.tw.x * vf, wy = L.tw.y * vf;
-            const double wp = (n < 8) ? wx : wy;                        // PACK: rows 0..7 of A are wx, rows 8..15 are wy
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                // DG: H.x = |a|^2, H.y = |b|^2 (two real products; g0x / g0y are their lag-0 sums)
-                const cplx H = DG ? make_double2(fma(L.a[t].x, L.a[t].x, L.a[t].y * L.a[t].y), fma(L.b[t].x, L.b[t].x, L.b[t].y * L.b[t].y))
-                                  : cmulc(L.a[t], L.b[t]);
-                g0x[t] = fma(H.x, vf, g0x[t]);
-                g0y[t] = fma(H.y, vf, g0y[t]);
-                if (PACK) {
-                    Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.x, Sx[t][0], 0, 0, 0);      // S1 | S3
-                    Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp, H.y, Sx[t][1], 0, 0, 0);      // S4 | S2
-                } else {
-                    Sx[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.x, Sx[t][0], 0, 0, 0);      // S1            (DG: S1 of |A|^2)
-                    Sx[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.y, Sx[t][1], 0, 0, 0);      // S2            (DG: S3 of |B|^2)
-                    Sx[t][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(wy, H.x, Sx[t][2], 0, 0, 0);      // S3            (DG: S3 of |A|^2)
-                    Sx[t][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx, H.y, Sx[t][3], 0, 0, 0);      // S4            (DG: S1 of |B|^2)
-                }
-            }
-        };
-        LoadSet L0, L1;
-        issue(L0);
-        for (int l = lb; l < le; l += 8) {
-            issue(L1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(L0, (l + kq < le) ? 1.0 : 0.0);
-            issue(L0);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(L1, (l + 4 + kq < le) ? 1.0 : 0.0);      // (a step past the chunk runs on zero weights)
-        }
-    };
-    const bool diag = !colfac && !PACK && pr.dual;
-    if (colfac) run(std::true_type{}, std::false_type{});
-    else if (diag) run(std::false_type{}, std::true_type{});
-    else run(std::false_type{}, std::false_type{});
-    cplx* g = Gp + pr.gp_off + (size_t)chunk * PH * Nhp;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        double sx = g0x[t], sy = g0y[t];
-        sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
-        sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
-        const int m = m0 + 16 * t + n;
-        if (!act[t]) continue;
-        if (diag) {     // two real, even sequences: G(+-r) = S1 +- i S3 for |A|^2 (Sx[0], Sx[2]) and for |B|^2 (Sx[3], Sx[1])
-            cplx* g2 = Gp + pr.gp_off2 + (size_t)chunk * PH * Nhp;
-            if (kq == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = kq + 4 * q + 1;
-                if (r <= h) {
-                    g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[t][0][q], Sx[t][2][q]);
-                    g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[t][0][q], -Sx[t][2][q]);
-                    g2[(size_t)(h + r) * Nhp + m] = make_double2(Sx[t][3][q], Sx[t][1][q]);
-                    g2[(size_t)(h - r) * Nhp + m] = make_double2(Sx[t][3][q], -Sx[t][1][q]);
-                }
-            }
-            continue;
-        }
-        if (kq == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
-#pragma unroll
-        for (int q = 0; q < (PACK ? 2 : 4); ++q) {
-            const int r = kq + 4 * q + 1;               // D row (lane >> 4) + 4 q holds lag index r - 1
-            if (r <= h) {
-                const double s1 = Sx[t][0][q];
-                const double s2 = PACK ? Sx[t][1][q + 2] : Sx[t][1][q];
-                const double s3 = PACK ? Sx[t][0][q + 2] : Sx[t][2][q];
-                const double s4 = PACK ? Sx[t][1][q] : Sx[t][3][q];
-                g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
-                g[(size_t)(h - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
-            }
-        }
-    }
-}
-
 // The same passes on the OTHER fp64 matrix instruction.  A loop of independent v_mfma_f64_16x16x4_f64 sustains 47 TFLOP/s on MI355X,
 // one of v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction) 71 - 74.5 (scripts/micro/mfma_f64_peak.hip,
 // profiles/r02_mfma_f64_peak.txt).  Its layout (scripts/micro/mfma_f64_4x4_layout.hip): A_blk[i][k] in lane 16 k + 4 blk + i,
@@ -535,9 +376,6 @@ __global__ void __launch_bounds__(64, 3) greek_g1_mfma4(const cplx* __restrict__
 // 61 at two waves per SIMD: vector fp64 work is not hidden beside the matrix pipe, it takes ~6 cycles of it per instruction.  A step
 // here carries ~24 fp64 vector instructions, 16 ds_swizzle, ~10 integer instructions and 4 loads beside its 48 matrix instructions;
 // a wave alone on its SIMD needs 1345 cycles per step (720 of them matrix instructions), and two waves sharing a SIMD twice that.
-#ifndef DF_BURST
-#define DF_BURST 1     // steps whose loads are issued together (measured: 1, 2, 3 all 0.455 ms at 4096^2)
-#endif
 struct G1Group {
     int plane[3];     // planes v0, v1, v2 loaded per step (an unused v2 repeats v0)
     int mask;         // bit s set: slot s is in use.  Slot 0 = (v0, v1), slot 1 = (v1, v2), slot 2 = (v0, v2): fixed operand pairs
@@ -546,9 +384,6 @@ struct G1Group {
     int ht;
 };
 
-#ifndef G4G_WAVES
-#define G4G_WAVES 2
-#endif
 // MASK = false: every row chunk is a whole number of 8-row iterations (4096 / 8 chunks: 512 rows), so no step ever runs past its chunk
 // and the per-step row mask (a compare, two selects, two multiplies and the masked lag-0 sums) drops out of the loop -- vector
 // instructions are not free beside the matrix pipe here.
@@ -562,23 +397,19 @@ struct G1Group {
 // lag0 / HALF (lag half-widths 17 .. 32, e.g. KerHW 12: h = 24): a launch covers the 16 lags lag0 + 1 .. lag0 + 16 (lag0 = 0 or 16; the lag-0
 // sums belong to the first launch); HALF = true (DIT only) issues just the lag groups lag0 + {2,4,6,8} and lag0 + {1,3,5,7} -- the second
 // launch of h <= 24 needs no others -- i.e. half the matrix instructions of a step.
-// QUAD (SFFT_G1_QUAD=1): four independent waves per workgroup, one per SIMD, and a dynamic LDS request of more than half the CU's
-// (never touched) so that ONE such workgroup fits a CU: the launch then holds one wave per SIMD -- which costs it 8 % on its own, a
-// lone wave nearly saturates a SIMD's issue -- and leaves half the registers and LDS of every CU to the memory-bound kernels of the
-// other pairs in flight (rows_r2c_4096, rows_c2r_diff_4096, vconv_mixed2: 256 threads, <= 240 registers, <= 70 KB).
-template <bool MASK, bool DIT = false, bool HALF = false, bool QUAD = false>
-__global__ void __launch_bounds__(QUAD ? 256 : 64) __attribute__((amdgpu_waves_per_eu(G4G_WAVES, G4G_WAVES))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
+template <bool MASK, bool DIT = false, bool HALF = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) greek_g1_mfma4g(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes,
                                                         const G1Group* __restrict__ groups, int ngroup,
                                                         cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
                                                         int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S,
                                                         unsigned long long* __restrict__ trace, int lag0)
 {
     const unsigned long long t_start = trace ? wall_clock64() : 0ULL;      // (SFFT_G1_TRACE: start / end stamp and XCD of every wave)
-    const int lane = QUAD ? (int)(threadIdx.x & 63) : (int)threadIdx.x, n = lane & 15, kq = lane >> 4;
+    const int lane = (int)threadIdx.x, n = lane & 15, kq = lane >> 4;
     const int total = ncb * S * ngroup;
-    const int per = QUAD ? 4 * ((total + 31) >> 5) : (total + 7) >> 3;
-    // the groups of a tile run back to back on one XCD (QUAD: four consecutive list entries per workgroup)
-    const int logical = (int)(blockIdx.x & 7) * per + (QUAD ? 4 * (int)(blockIdx.x >> 3) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(blockIdx.x >> 3));
+    const int per = (total + 7) >> 3;
+    // the groups of a tile run back to back on one XCD
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (logical >= total) return;
     const int tile = logical / ngroup;
     const int chunk = tile / ncb;
@@ -730,22 +561,17 @@ __global__ void __launch_bounds__(QUAD ? 256 : 64) __attribute__((amdgpu_waves_p
             }
         }
     };
-    // Bursts: the loads of DF_BURST steps (4 DF_BURST rows: 256 DF_BURST contiguous bytes per panel and plane) are issued together, two bursts
-    // alternating -- a DRAM page then serves one long request run per stream instead of one 256-byte piece per microsecond.
-    LoadSet LA[DF_BURST], LB[DF_BURST];
-#pragma unroll
-    for (int u = 0; u < DF_BURST; ++u) issue(LA[u]);
-    for (int l = lb; l < le; l += 8 * DF_BURST) {
-#pragma unroll
-        for (int u = 0; u < DF_BURST; ++u) issue(LB[u]);
+    // two load sets alternate: the loads of step k + 1 are in flight while step k's matrix instructions issue (bursts of 2 or 3 steps per
+    // set were measured and changed nothing)
+    LoadSet LA, LB;
+    issue(LA);
+    for (int l = lb; l < le; l += 8) {
+        issue(LB);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < DF_BURST; ++u) compute(LA[u], (!MASK || l + 4 * u + kq < le) ? 1.0 : 0.0);
-#pragma unroll
-        for (int u = 0; u < DF_BURST; ++u) issue(LA[u]);
+        compute(LA, (!MASK || l + kq < le) ? 1.0 : 0.0);
+        issue(LA);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < DF_BURST; ++u) compute(LB[u], (!MASK || l + 4 * (DF_BURST + u) + kq < le) ? 1.0 : 0.0);      // (steps past the chunk run on zero weights)
+        compute(LB, (!MASK || l + 4 + kq < le) ? 1.0 : 0.0);      // (a step past the chunk runs on zero weights)
     }
     };
     if (theta) run(std::integral_constant<int, 3>{});
@@ -811,532 +637,6 @@ __global__ void __launch_bounds__(QUAD ? 256 : 64) __attribute__((amdgpu_waves_p
         }
     }
     if (trace && lane == 0) { trace[3 * (size_t)blockIdx.x] = t_start; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)logical; }
-}
-
-// ---- the grouped Omega launch with a tile's planes shared through LDS (round 3) ------------------------------------------------------
-// greek_g1_mfma4g is bound by the memory side: every wave loads its three planes itself, so a tile's planes pass the CU's L1 three
-// times, and the sibling waves of a tile run at their own pace (and, with many groups per tile, start a good part of a wave's life
-// apart), so the XCD's L2 does not hold the rows between the first and the last reader: 1.4x (Fij = 6) to 7.5x (Fij = 25) the plane
-// bytes come from HBM.  Neither fewer vector instructions (compile-time dual flag), nor one wave per SIMD with loads two steps ahead,
-// nor other chunk counts moved it (0.33 - 0.35 ms at 4096^2 in every case).
-// Here a WORKGROUP of eight waves owns a "block" of up to eight pass groups of one tile whose planes (at most G1W_NP) are loaded ONCE
-// per step -- wave w loads plane w (and w + 8) of the block's list for the step's 4 + 4 rows, 2 KB -- into a two-stage LDS ring
-// together with the step's twiddles; after one barrier per step every wave takes the operands of its three slots from LDS.  The waves
-// of a workgroup are in lockstep by construction.  With more than one block per tile (Fij = 25: 113 groups = 15 blocks) the launch is
-// PERSISTENT: one workgroup per CU, the workgroups of an XCD form `tpr` teams of `nblk` that start their tiles together and walk them in
-// step (equal work per block), so a tile's planes are in flight for all its blocks at the same time.  Global loads run two steps
-// ahead of their use (a wave holds 2 x 2 complex values per step in flight instead of 2 x 7).
-// DIT, whole 8-row steps only (g1_decimated); HALF / lag0 as in greek_g1_mfma4g.
-// MEASURED (profiles/r03_d_*): slower than greek_g1_mfma4g everywhere -- 0.505 vs 0.339 ms at 4096^2 (Fij = 6, one block per tile), 14.9 vs
-// 10.3 ms at config 3 (15 blocks, persistent), 10.7 vs 7.8 ms at config 5.  A step is 4140 cycles here against 2690: the barrier puts all
-// eight waves into the same phase, the 56 KB of operands a step reads from LDS (440 cycles of its bandwidth) and the barrier skew are
-// exposed in front of every step's matrix instructions, and the one-block case leaves an eighth of the wave slots without matrix
-// work.  The launch needs its memory side (~0.30 ms alone) AND its instruction issue (~0.23 ms alone) to overlap, which independent
-// waves do better than lockstep ones.  Kept behind SFFT_G1_WG=1 with its parity test; not the default.
-#define G1W_NP 15
-struct G1Blk { int g0, ng, np; int plane[G1W_NP]; };
-
-// TWO: blocks have more than eight LDS items (planes + twiddles), a wave loads two of them per step.  (The loads of a step are
-// unconditional -- a wave without an item re-reads a valid address and does not store it: register values that are only
-// conditionally written go to scratch.)
-template <bool HALF, bool TWO>
-__global__ void __launch_bounds__(512) greek_g1_mfma4w(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, const G1Group* __restrict__ groups,
-                                                        const G1Blk* __restrict__ blks, int nblk, cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay,
-                                                        int rows_per_chunk, const cplx* __restrict__ W0tab, int HM, int ncb, int S, int lag0, int tpr, int rounds, int ni)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = ncb * S;
-    int tile_first, tile_step, tile_end, blk;
-    if (rounds > 0) {          // persistent: the XCD's workgroups in teams of nblk, contiguous tile ranges per XCD
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int tx = (ntiles + 7) >> 3;
-        const int t_in = slot / nblk;
-        blk = slot - t_in * nblk;
-        tile_first = xcd * tx + t_in; tile_step = tpr; tile_end = min(ntiles, (xcd + 1) * tx);
-    } else {                   // one workgroup per (tile, block), the blocks of a tile back to back on one XCD
-        const int total = ntiles * nblk, per = (total + 7) >> 3;
-        const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-        if (logical >= total) return;
-        const int t = logical / nblk;
-        blk = logical - t * nblk;
-        tile_first = t; tile_step = 1; tile_end = t + 1;
-    }
-    const G1Blk* __restrict__ bk = blks + blk;
-    const int np = bk->np, ng = bk->ng;
-    const bool has = wv < ng;
-    const G1Group gr = groups[bk->g0 + (has ? wv : 0)];
-    int it0 = 0, it1 = 0, it2 = 0;                      // LDS items of the group's three planes
-    for (int j = 0; j < np; ++j) { const int pl = bk->plane[j]; if (pl == gr.plane[0]) it0 = j; if (pl == gr.plane[1]) it1 = j; if (pl == gr.plane[2]) it2 = j; }
-    const bool use0 = (gr.mask & 1) != 0, use1 = (gr.mask & 2) != 0, use2 = (gr.mask & 4) != 0;
-    const int k0 = use0 ? gr.pass[0] : (use1 ? gr.pass[1] : gr.pass[2]), k1 = use1 ? gr.pass[1] : k0, k2 = use2 ? gr.pass[2] : k0;
-    const long long go0 = passes[k0].gp_off, go1 = passes[k1].gp_off, go2 = passes[k2].gp_off;
-    const long long gd0 = passes[k0].gp_off2;
-    const bool d0 = use0 && passes[k0].dual != 0;
-    const int h = passes[k0].h, PH = 2 * h + 1;
-    const bool theta = gr.tpass[0] >= 0;
-    const bool three = gr.plane[2] != gr.plane[0];
-    const long long gt0 = theta ? passes[gr.tpass[0]].gp_off : 0, gt1 = theta ? passes[gr.tpass[1]].gp_off : 0;
-    const int ht = gr.ht, PHt = 2 * ht + 1;
-    const size_t plane_sz = (size_t)N0 * Nhp, rs = (size_t)lay.rstride;
-    const unsigned rsb = (unsigned)(rs * sizeof(cplx)), hmb = (unsigned)(HM * sizeof(cplx));
-    const unsigned halfb = (unsigned)(N0 / 2) * rsb;
-    const int dlag = (n < 8) ? 8 * (n >> 2) + 2 * ((n & 3) + 1) : 8 * ((n >> 2) - 2) + 2 * (n & 3) + 1;
-    const unsigned tcolb = (unsigned)min(lag0 + dlag, HM - 1) * (unsigned)sizeof(cplx);
-    // the (at most two) items this wave loads: item j < np = plane j of the block, item np = the twiddles
-    const int itA = wv, itB = wv + 8;
-    const bool onA = itA <= np, onB = TWO && itB <= np, twA = itA == np, twB = TWO && itB == np;
-    const unsigned hoffA = twA ? 0u : halfb, hoffB = twB ? 0u : halfb;
-    const char* __restrict__ baseA = twA ? reinterpret_cast<const char*>(W0tab) : reinterpret_cast<const char*>(spec + (size_t)bk->plane[min(itA, np - 1)] * plane_sz);
-    const char* __restrict__ baseB = twB ? reinterpret_cast<const char*>(W0tab) : reinterpret_cast<const char*>(spec + (size_t)bk->plane[min(itB, np - 1)] * plane_sz);
-    const unsigned sstride = (unsigned)ni * 2048u;
-    // LDS slots of the two values an item loads per step: a plane's rows x' and x' + N0 / 2; the twiddles and, in the unused second half of
-    // the twiddle item, a dump for the second twiddle load and for waves without an item (their stores are unconditional too: a
-    // conditional LDS store sends the loaded values through scratch)
-    const unsigned dump = (unsigned)np * 2048u + 1024u;
-    char* const ldsA0 = smem_raw + (onA ? (unsigned)itA * 2048u : dump) + (unsigned)lane * 16u;
-    char* const ldsA1 = smem_raw + ((onA && !twA) ? (unsigned)itA * 2048u + 1024u : dump) + (unsigned)lane * 16u;
-    char* const ldsB0 = smem_raw + (onB ? (unsigned)itB * 2048u : dump) + (unsigned)lane * 16u;
-    char* const ldsB1 = smem_raw + ((onB && !twB) ? (unsigned)itB * 2048u + 1024u : dump) + (unsigned)lane * 16u;
-    const char* const rd0 = smem_raw + (unsigned)it0 * 2048u + (unsigned)lane * 16u;
-    const char* const rd1 = smem_raw + (unsigned)it1 * 2048u + (unsigned)lane * 16u;
-    const char* const rd2 = smem_raw + (unsigned)it2 * 2048u + (unsigned)lane * 16u;
-    const char* const rdw = smem_raw + (unsigned)np * 2048u + (unsigned)lane * 16u;
-
-    struct LoadSet { cplx tw, v[3], u[3]; };
-    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
-    const int chunk = tile / ncb;
-    const int m0 = (tile - chunk * ncb) * 16;
-    const int lb = chunk * (rows_per_chunk / 2);
-    const int le = min(N0 / 2, lb + rows_per_chunk / 2);
-    const int m = m0 + n;
-    const bool act = m < Nh;
-    const unsigned cob = (unsigned)(lay.col(act ? m : Nh - 1) * sizeof(cplx));
-    const unsigned r0 = (unsigned)(lb + kq);
-    const unsigned prow_max = cob + (unsigned)(N0 / 2 - 1) * rsb, trow_max = tcolb + (unsigned)(N0 - 1) * hmb;
-    unsigned offA = twA ? tcolb + r0 * hmb : cob + r0 * rsb, offB = twB ? tcolb + r0 * hmb : cob + r0 * rsb;
-    const unsigned incA = twA ? 4u * hmb : 4u * rsb, incB = twB ? 4u * hmb : 4u * rsb;
-    const unsigned maxA = twA ? trow_max : prow_max, maxB = twB ? trow_max : prow_max;
-    d4v Sx[3][4];
-    double g0x[3], g0y[3];
-    double St[2][4][2], t0x[2] = {0.0, 0.0}, t0y[2] = {0.0, 0.0};
-#pragma unroll
-    for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) St[ts][q][0] = St[ts][q][1] = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Sx[sl][q] = (d4v){0.0, 0.0, 0.0, 0.0};
-        g0x[sl] = g0y[sl] = 0.0;
-    }
-    auto run = [&](auto MODE) {
-    constexpr int mode = decltype(MODE)::value;      // -1: no group (loads and barriers only); 0 .. 3 as in greek_g1_mfma4g
-    constexpr bool three_c = mode == 1 || mode == 3;
-    // (macros on plain values, not lambdas on a struct: with the barriers of this loop between them the struct stayed in scratch)
-#define G1W_ISSUE(A0, A1, B0, B1) do { \
-        A0 = *reinterpret_cast<const cplx*>(baseA + offA); \
-        A1 = *reinterpret_cast<const cplx*>(baseA + (offA + hoffA)); \
-        offA = min(offA + incA, maxA); \
-        if (TWO) { \
-            B0 = *reinterpret_cast<const cplx*>(baseB + offB); \
-            B1 = *reinterpret_cast<const cplx*>(baseB + (offB + hoffB)); \
-            offB = min(offB + incB, maxB); \
-        } } while (0)
-#define G1W_STASH(A0, A1, B0, B1, STAGE) do { \
-        *reinterpret_cast<cplx*>(ldsA0 + (STAGE) * sstride) = A0; \
-        *reinterpret_cast<cplx*>(ldsA1 + (STAGE) * sstride) = A1; \
-        if (TWO) { \
-            *reinterpret_cast<cplx*>(ldsB0 + (STAGE) * sstride) = B0; \
-            *reinterpret_cast<cplx*>(ldsB1 + (STAGE) * sstride) = B1; \
-        } } while (0)
-    auto fetch = [&](LoadSet& L, unsigned stage) {
-        const unsigned so = stage * sstride;
-        L.tw = *reinterpret_cast<const cplx*>(rdw + so);
-        L.v[0] = *reinterpret_cast<const cplx*>(rd0 + so); L.u[0] = *reinterpret_cast<const cplx*>(rd0 + so + 1024u);
-        L.v[1] = *reinterpret_cast<const cplx*>(rd1 + so); L.u[1] = *reinterpret_cast<const cplx*>(rd1 + so + 1024u);
-        if (three_c) { L.v[2] = *reinterpret_cast<const cplx*>(rd2 + so); L.u[2] = *reinterpret_cast<const cplx*>(rd2 + so + 1024u); }
-        else { L.v[2] = make_double2(0.0, 0.0); L.u[2] = make_double2(0.0, 0.0); }
-    };
-    auto compute = [&](const LoadSet& L) {
-        double wx[4], wy[4];
-#define SFFT_SWZ(v, G) __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x13 | ((4 * (G)) << 5)), \
-                                        __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x13 | ((4 * (G)) << 5)))
-        wx[0] = SFFT_SWZ(L.tw.x, 0); wx[1] = SFFT_SWZ(L.tw.x, 1); wx[2] = SFFT_SWZ(L.tw.x, 2); wx[3] = SFFT_SWZ(L.tw.x, 3);
-        wy[0] = SFFT_SWZ(L.tw.y, 0); wy[1] = SFFT_SWZ(L.tw.y, 1); wy[2] = SFFT_SWZ(L.tw.y, 2); wy[3] = SFFT_SWZ(L.tw.y, 3);
-#undef SFFT_SWZ
-        auto slot = [&](auto SL, auto DU) {
-            constexpr int sl = decltype(SL)::value;
-            constexpr int du = decltype(DU)::value;
-            const bool dual = du == 2 ? d0 : (du == 1);
-            const cplx va = L.v[sl == 1 ? 1 : 0], vb = L.v[(sl == 0 || mode >= 2) ? 1 : 2];
-            const cplx ua = L.u[sl == 1 ? 1 : 0], ub = L.u[(sl == 0 || mode >= 2) ? 1 : 2];
-            const cplx H = dual ? make_double2(fma(va.x, va.x, va.y * va.y), fma(vb.x, vb.x, vb.y * vb.y)) : cmulc(va, vb);
-            const cplx Hh = dual ? make_double2(fma(ua.x, ua.x, ua.y * ua.y), fma(ub.x, ub.x, ub.y * ub.y)) : cmulc(ua, ub);
-            const cplx Ye = make_double2(H.x + Hh.x, H.y + Hh.y), Yo = make_double2(H.x - Hh.x, H.y - Hh.y);
-            g0x[sl] += Ye.x;
-            g0y[sl] += Ye.y;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                if (HALF && (gq & 1)) continue;
-                const double bx = gq < 2 ? Ye.x : Yo.x, by = gq < 2 ? Ye.y : Yo.y;
-                Sx[sl][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], bx, Sx[sl][0][gq], 0, 0, 0);
-                Sx[sl][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], by, Sx[sl][1][gq], 0, 0, 0);
-                Sx[sl][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[gq], bx, Sx[sl][2][gq], 0, 0, 0);
-                Sx[sl][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[gq], by, Sx[sl][3][gq], 0, 0, 0);
-            }
-        };
-        using DU0 = std::integral_constant<int, 0>; using DU1 = std::integral_constant<int, 1>; using DU2 = std::integral_constant<int, 2>;
-        if (mode == 0) { if (use0) slot(std::integral_constant<int, 0>{}, DU2{}); }
-        if (mode == 1) {
-            if (use0) slot(std::integral_constant<int, 0>{}, DU0{});
-            if (use1) slot(std::integral_constant<int, 1>{}, DU0{});
-            if (use2) slot(std::integral_constant<int, 2>{}, DU0{});
-        }
-        if (mode >= 2) { slot(std::integral_constant<int, 0>{}, DU1{}); slot(std::integral_constant<int, 2>{}, DU0{}); }
-        if (mode == 3) {
-#pragma unroll
-            for (int ts = 0; ts < 2; ++ts) {
-                const cplx H = cmulc(L.v[ts], L.v[2]);           // FI_x conj(FJ)
-                const cplx Hh = cmulc(L.u[ts], L.u[2]);
-                const cplx Ye = make_double2(H.x + Hh.x, H.y + Hh.y), Yo = make_double2(H.x - Hh.x, H.y - Hh.y);
-                t0x[ts] += Ye.x;
-                t0y[ts] += Ye.y;
-#pragma unroll
-                for (int gq = 0; gq < 2; ++gq) {
-                    const double bx = gq == 0 ? Ye.x : Yo.x, by = gq == 0 ? Ye.y : Yo.y;
-                    St[ts][0][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[2 * gq], bx, St[ts][0][gq], 0, 0, 0);
-                    St[ts][1][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[2 * gq], by, St[ts][1][gq], 0, 0, 0);
-                    St[ts][2][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wy[2 * gq], bx, St[ts][2][gq], 0, 0, 0);
-                    St[ts][3][gq] = __builtin_amdgcn_mfma_f64_4x4x4f64(wx[2 * gq], by, St[ts][3][gq], 0, 0, 0);
-                }
-            }
-        }
-    };
-    // steps i (4 + 4 rows each): global loads of step i + 2 and the LDS stage of step i + 1 are under way while step i is computed
-    cplx pa0, pa1, pb0 = make_double2(0.0, 0.0), pb1 = make_double2(0.0, 0.0);      // loads in flight: set P
-    cplx qa0, qa1, qb0 = make_double2(0.0, 0.0), qb1 = make_double2(0.0, 0.0);      //                   set Q
-    G1W_ISSUE(pa0, pa1, pb0, pb1);   // step 0
-    G1W_ISSUE(qa0, qa1, qb0, qb1);   // step 1
-    __syncthreads();                 // (the previous tile's last reads of the ring are done)
-    G1W_STASH(pa0, pa1, pb0, pb1, 0u);
-    G1W_ISSUE(pa0, pa1, pb0, pb1);   // step 2
-    for (int l = lb; l < le; l += 8) {
-        LoadSet L;
-        __syncthreads();             // stage 0 holds step i; nobody reads stage 1 any more
-        if (mode >= 0) fetch(L, 0u);
-        G1W_STASH(qa0, qa1, qb0, qb1, 1u);
-        G1W_ISSUE(qa0, qa1, qb0, qb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (mode >= 0) compute(L);
-        __syncthreads();             // stage 1 holds step i + 1; nobody reads stage 0 any more
-        if (mode >= 0) fetch(L, 1u);
-        G1W_STASH(pa0, pa1, pb0, pb1, 0u);
-        G1W_ISSUE(pa0, pa1, pb0, pb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (mode >= 0) compute(L);
-    }
-#undef G1W_ISSUE
-#undef G1W_STASH
-    };
-    if (!has) run(std::integral_constant<int, -1>{});
-    else if (theta) run(std::integral_constant<int, 3>{});
-    else if (three) run(std::integral_constant<int, 1>{});
-    else if (use2) run(std::integral_constant<int, 2>{});
-    else run(std::integral_constant<int, 0>{});
-    if (has && act) {
-    auto emit = [&](auto SL, long long gp_off, long long gp_off2, bool dual, int h) {      // h: the lag half width of THIS slot's pass
-        constexpr int sl = decltype(SL)::value;
-        const int PH = 2 * h + 1;
-        double sx = g0x[sl], sy = g0y[sl];
-        sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
-        sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
-        cplx* g = Gp + gp_off + (size_t)chunk * PH * Nhp;
-        if (dual) {
-            cplx* g2 = Gp + gp_off2 + (size_t)chunk * PH * Nhp;
-            if (kq == 0 && lag0 == 0) { g[(size_t)h * Nhp + m] = make_double2(sx, 0.0); g2[(size_t)h * Nhp + m] = make_double2(sy, 0.0); }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (HALF && (q & 1)) continue;
-                const int r = lag0 + (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1);
-                if (r <= h) {
-                    g[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][0][q], Sx[sl][2][q]);
-                    g[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][0][q], -Sx[sl][2][q]);
-                    g2[(size_t)(h + r) * Nhp + m] = make_double2(Sx[sl][3][q], Sx[sl][1][q]);
-                    g2[(size_t)(h - r) * Nhp + m] = make_double2(Sx[sl][3][q], -Sx[sl][1][q]);
-                }
-            }
-            return;
-        }
-        if (kq == 0 && lag0 == 0) g[(size_t)h * Nhp + m] = make_double2(sx, sy);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (HALF && (q & 1)) continue;
-            const int r = lag0 + (q < 2 ? 8 * q + 2 * (kq + 1) : 8 * (q - 2) + 2 * kq + 1);
-            if (r <= h) {
-                const double s1 = Sx[sl][0][q], s2 = Sx[sl][1][q], s3 = Sx[sl][2][q], s4 = Sx[sl][3][q];
-                g[(size_t)(h + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
-                g[(size_t)(h - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
-            }
-        }
-    };
-    if (use0) emit(std::integral_constant<int, 0>{}, go0, gd0, d0, passes[k0].h);
-    if (use1) emit(std::integral_constant<int, 1>{}, go1, 0LL, false, passes[k1].h);
-    if (use2) emit(std::integral_constant<int, 2>{}, go2, 0LL, false, passes[k2].h);
-    if (theta) {
-#pragma unroll
-        for (int ts = 0; ts < 2; ++ts) {
-            double sx = t0x[ts], sy = t0y[ts];
-            sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16);
-            sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32);
-            cplx* g = Gp + (ts == 0 ? gt0 : gt1) + (size_t)chunk * PHt * Nhp;
-            if (kq == 0) g[(size_t)ht * Nhp + m] = make_double2(sx, sy);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r = q == 0 ? 2 * (kq + 1) : 2 * kq + 1;
-                if (r <= ht) {
-                    const double s1 = St[ts][0][q], s2 = St[ts][1][q], s3 = St[ts][2][q], s4 = St[ts][3][q];
-                    g[(size_t)(ht + r) * Nhp + m] = make_double2(s1 - s2, s3 + s4);
-                    g[(size_t)(ht - r) * Nhp + m] = make_double2(s1 + s2, s4 - s3);
-                }
-            }
-        }
-    }
-    }
-    }
-}
-
-// The last column of the half spectrum (m = Nh - 1) when it is a tile of its own ((Nh - 1) % 16 == 0, e.g. 2049 = 128 x 16 + 1): the
-// workgroup launch above then covers (Nh - 1) / 16 whole tiles -- 128 x 4 chunks = 512 workgroups = two whole rounds of 256 CUs instead
-// of 516 -- and this kernel takes that column's lag sums directly, one workgroup per (pass, chunk): thread = (lag, row slice), the
-// slices added up through LDS.  Same partial buffers, same chunks (rows [lb, le) and their partners N0 / 2 further down), every lag
-// of the pass in one go (lag0 launches do not repeat it).
-__global__ void __launch_bounds__(256) greek_g1_lastcol(const cplx* __restrict__ spec, const G1Pass* __restrict__ passes, const int* __restrict__ list,
-                                                        cplx* __restrict__ Gp, int N0, int Nh, int Nhp, SpecLayout lay, int rows_per_chunk,
-                                                        const cplx* __restrict__ W0tab, int HM)
-{
-    const G1Pass ps = passes[list[blockIdx.x]];
-    const int chunk = blockIdx.y, h = ps.h, PH = 2 * h + 1, m = Nh - 1;
-    const int nsl = 256 / PH, tid = threadIdx.x;
-    const int li = tid % PH, sl = tid / PH;
-    const int r = li - h, ar = r < 0 ? -r : r;
-    const int lb = chunk * (rows_per_chunk / 2), le = min(N0 / 2, lb + rows_per_chunk / 2);
-    const size_t plane_sz = (size_t)N0 * Nhp, co = lay.col(m), rs = (size_t)lay.rstride;
-    const cplx* __restrict__ A = spec + (size_t)ps.a_plane * plane_sz + co;
-    const cplx* __restrict__ B = spec + (size_t)ps.b_plane * plane_sz + co;
-    double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;        // dual: (ax, ay) = sum tw |a|^2, (bx, by) = sum tw |b|^2
-    if (sl < nsl)
-        for (int x = lb + sl; x < le; x += nsl) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int row = x + hf * (N0 / 2);
-                const cplx a = A[(size_t)row * rs], b = B[(size_t)row * rs];
-                cplx tw = W0tab[(size_t)row * HM + min(ar, HM - 1)];
-                if (r < 0) tw.y = -tw.y;
-                if (ps.dual) {
-                    const double pa = fma(a.x, a.x, a.y * a.y), pb = fma(b.x, b.x, b.y * b.y);
-                    ax = fma(tw.x, pa, ax); ay = fma(tw.y, pa, ay);
-                    bx = fma(tw.x, pb, bx); by = fma(tw.y, pb, by);
-                } else {
-                    const cplx H = cmulc(a, b);
-                    ax += tw.x * H.x - tw.y * H.y;
-                    ay += tw.x * H.y + tw.y * H.x;
-                }
-            }
-        }
-    __shared__ double red[4][256];
-    red[0][tid] = ax; red[1][tid] = ay; red[2][tid] = bx; red[3][tid] = by;
-    __syncthreads();
-    if (tid < PH) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int q = 0; q < nsl; ++q) { s0 += red[0][tid + q * PH]; s1 += red[1][tid + q * PH]; s2 += red[2][tid + q * PH]; s3 += red[3][tid + q * PH]; }
-        Gp[ps.gp_off + ((size_t)chunk * PH + tid) * Nhp + m] = make_double2(s0, s1);
-        if (ps.dual) Gp[ps.gp_off2 + ((size_t)chunk * PH + tid) * Nhp + m] = make_double2(s2, s3);
-    }
-}
-
-// ---- redundant Omega passes (polynomial kernel bases) ---------------------------------------------------------------------
-// Omega[(ij),(i'j')](rho) = sum_x I(x) cx^i cy^j * I(x + rho) cx(x0 + r)^i' cy(x1 + e)^j'  (circular).  Where the shift does not wrap,
-// cx(x0 + r) = cx + r / N0 and cy(x1 + e) = cy + e / N1 exactly, so over the INTERIOR pixels of a lag (no wrap in either axis)
-//   Omega_int[(ij),(i'j')] = sum_{u <= i', v <= j'} C(i',u) C(j',v) (r/N0)^(i'-u) (e/N1)^(j'-v) M_(i+u, j+v),
-//   M_ab(rho) = sum_{x interior} I(x) I(x + rho) cx^a cy^b:
-// every pass of a "moment class" (i + i', j + j') carries the same top moment.  One pass per class is transformed (15 of the 21 at
-// orders 2 / 2, 28 of 55 at order 3); the others follow from the moments, lag by lag (omega_derive), once the contribution of the
-// pixels whose shift DOES wrap -- |r| rows and |e| columns at the image border, for every lag -- has been taken out of the kept
-// patches and put into the derived ones.  Those border sums are exact real-space sums (omega_strips): region A = the rows that wrap
-// (all columns), region B = the columns that wrap in the rows that do not; in each the weights factor into a part that is constant
-// along the long axis and a part summed along it ((DK+1)^2 running sums per row or column).  The border columns come from a small
-// transposed copy (edge_cols) so that region B reads contiguously too.  Checked against the reference-made fixtures like every
-// other patch (the 96 x 80, KerHW 8 fixtures have a third of their pixels in the border regions).
-#define OMGR_MAXPAIR 55
-#define OMGR_MAXCLS 28
-struct OmgReduce {
-    int npl, npair, ncls, nskip, h;          // planes, pairs (a <= b, patch order), moment classes, derived pairs, lag half width
-    unsigned char pi[10], pj[10];            // exponents of plane k
-    unsigned char pa[OMGR_MAXPAIR], pb[OMGR_MAXPAIR];      // pair k = (plane pa, plane pb)
-    unsigned char cls_pair[OMGR_MAXCLS];     // the transformed pair of each class, classes in order of total degree
-    unsigned char skip_pair[OMGR_MAXPAIR];   // derived pairs
-};
-
-// Ec[c][x0]: the HE leftmost (c < HE) and HE rightmost columns of the image, one contiguous row per column
-__global__ void __launch_bounds__(256) edge_cols(const double* __restrict__ I, double* __restrict__ Ec, int N0, int N1, int HE)
-{
-    const int x0 = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (x0 >= N0) return;
-    const int x1 = c < HE ? c : N1 - 2 * HE + c;
-    Ec[(size_t)c * N0 + x0] = I[(size_t)x0 * N1 + x1];
-}
-
-template <int DK> struct PolyPl {
-    static constexpr int NE = DK + 1, NPL = (DK + 1) * (DK + 2) / 2, NPAIR = NPL * (NPL + 1) / 2;
-    __host__ __device__ static constexpr int pi(int k) { int c = 0; for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { if (c == k) return i; ++c; } return 0; }
-    __host__ __device__ static constexpr int pj(int k) { int c = 0; for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { if (c == k) return j; ++c; } return 0; }
-};
-
-// part[(lag * 2h + q) * NPAIR + k]: the sum over ONE border line of the lag of I_a(x) I_b(x + rho), pair k = (a <= b) in patch order.
-// Line q < h: row q of region A (exists when q < |r|); line q >= h: column q - h of region B (when q - h < |e|).  One workgroup per
-// (lag, line): 4096 products, (DK+1)^2 running sums, one block reduction.
-template <int DK>
-__global__ void __launch_bounds__(256) omega_strips(const double* __restrict__ I, const double* __restrict__ Ec, int N0, int N1, int h,
-                                                    double* __restrict__ part)
-{
-    typedef PolyPl<DK> PP;
-    constexpr int NE = PP::NE, NPL = PP::NPL, NPAIR = PP::NPAIR;
-    const int PH = 2 * h + 1;
-    const int r = (int)blockIdx.x / PH - h, e = (int)blockIdx.x % PH - h;
-    const int q = blockIdx.y, tid = threadIdx.x;
-    const bool rowline = q < h;
-    const int ql = rowline ? q : q - h;
-    if (ql >= (rowline ? abs(r) : abs(e))) return;
-    const double i0 = 1.0 / (double)N0, i1 = 1.0 / (double)N1;
-    double t[NE][NE];
-#pragma unroll
-    for (int a = 0; a < NE; ++a)
-#pragma unroll
-        for (int b = 0; b < NE; ++b) t[a][b] = 0.0;
-    double wa[NE], wb[NE];                  // powers of the line's own coordinate (unshifted / shifted)
-    wa[0] = wb[0] = 1.0;
-    if (rowline) {
-        // region A: a row whose shift wraps, every column
-        const int x0 = (r > 0 ? N0 - r : 0) + ql;
-        int x0p = x0 + r; if (x0p >= N0) x0p -= N0; if (x0p < 0) x0p += N0;
-        const double* __restrict__ ra = I + (size_t)x0 * N1;
-        const double* __restrict__ rb = I + (size_t)x0p * N1;
-#pragma unroll 4
-        for (int x1 = tid; x1 < N1; x1 += 256) {
-            int x1p = x1 + e; if (x1p >= N1) x1p -= N1; if (x1p < 0) x1p += N1;
-            const double prod = ra[x1] * rb[x1p];
-            const double v = (double)(x1 + 1) * i1, vs = (double)(x1p + 1) * i1;
-            double qa = prod;
-#pragma unroll
-            for (int a = 0; a < NE; ++a) {
-                double qb = qa;
-#pragma unroll
-                for (int b = 0; b < NE; ++b) { t[a][b] += qb; qb *= vs; }
-                qa *= v;
-            }
-        }
-        const double u = (double)(x0 + 1) * i0, us = (double)(x0p + 1) * i0;
-#pragma unroll
-        for (int a = 1; a < NE; ++a) { wa[a] = wa[a - 1] * u; wb[a] = wb[a - 1] * us; }
-    } else {
-        // region B: a column whose shift wraps, in the rows that do not
-        const int x1 = (e > 0 ? N1 - e : 0) + ql;
-        int x1p = x1 + e; if (x1p >= N1) x1p -= N1; if (x1p < 0) x1p += N1;
-        const int ca = x1 < h ? x1 : x1 - (N1 - 2 * h), cbp = x1p < h ? x1p : x1p - (N1 - 2 * h);
-        const double* __restrict__ ea = Ec + (size_t)ca * N0;
-        const double* __restrict__ eb = Ec + (size_t)cbp * N0 + r;
-        const int xlo = r >= 0 ? 0 : -r, xhi = r >= 0 ? N0 - r : N0;
-#pragma unroll 4
-        for (int x0 = xlo + tid; x0 < xhi; x0 += 256) {
-            const double prod = ea[x0] * eb[x0];
-            const double u = (double)(x0 + 1) * i0, us = (double)(x0 + r + 1) * i0;
-            double qa = prod;
-#pragma unroll
-            for (int a = 0; a < NE; ++a) {
-                double qb = qa;
-#pragma unroll
-                for (int b = 0; b < NE; ++b) { t[a][b] += qb; qb *= us; }
-                qa *= u;
-            }
-        }
-        const double v = (double)(x1 + 1) * i1, vs = (double)(x1p + 1) * i1;
-#pragma unroll
-        for (int a = 1; a < NE; ++a) { wa[a] = wa[a - 1] * v; wb[a] = wb[a - 1] * vs; }
-    }
-    __shared__ double red[4][NE * NE];
-    __shared__ double tt[NE][NE];
-#pragma unroll
-    for (int a = 0; a < NE; ++a)
-#pragma unroll
-        for (int b = 0; b < NE; ++b) {
-            double v = t[a][b];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if ((tid & 63) == 0) red[tid >> 6][a * NE + b] = v;
-        }
-    __syncthreads();
-    if (tid < NE * NE) tt[tid / NE][tid % NE] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    __syncthreads();
-    if (tid < NPAIR) {
-        // pair tid = (a <= b): row lines weight the x powers (i, i') and sum the y powers (j, j'); column lines the other way round
-        int a = 0, k = tid;
-        while (k >= NPL - a) { k -= NPL - a; ++a; }
-        const int b = a + k;
-        int ia = 0, ja = 0, ib = 0, jb = 0, c = 0;
-        for (int i = 0; i <= DK; ++i) for (int j = 0; j <= DK - i; ++j) { if (c == a) { ia = i; ja = j; } if (c == b) { ib = i; jb = j; } ++c; }
-        double wA = 1.0, wB = 1.0;
-        const int ea2 = rowline ? ia : ja, eb2 = rowline ? ib : jb;
-        for (int z = 0; z < ea2; ++z) wA *= wa[1];
-        for (int z = 0; z < eb2; ++z) wB *= wb[1];
-        const double sum = rowline ? tt[ja][jb] : tt[ia][ib];
-        part[((size_t)blockIdx.x * 2 * h + q) * NPAIR + tid] = wA * wB * sum;
-    }
-}
-
-// One workgroup (64 threads) per lag: the border sums of the lag (thread k: pair k over its lines), then the interior moments from the
-// transformed patches and the derived patches.  patches: [npair][PH][PH] at omg_off; alpha = the factor the patches carry over the
-// plain correlation sums (SCALE^3).
-__global__ void __launch_bounds__(64) omega_derive(double* __restrict__ patches, const double* __restrict__ part, OmgReduce R,
-                                                   int N0, int N1, double alpha)
-{
-    const int PH = 2 * R.h + 1, lag = blockIdx.x, tid = threadIdx.x;
-    const int r = lag / PH - R.h, e = lag % PH - R.h;
-    __shared__ double strip[OMGR_MAXPAIR];
-    __shared__ double M[7][7];
-    if (tid < R.npair) {
-        double sacc = 0.0;
-        const int nr = abs(r), ne = abs(e);
-        for (int q = 0; q < nr; ++q) sacc += part[((size_t)lag * 2 * R.h + q) * R.npair + tid];
-        for (int q = 0; q < ne; ++q) sacc += part[((size_t)lag * 2 * R.h + R.h + q) * R.npair + tid];
-        strip[tid] = alpha * sacc;
-    }
-    if (tid < 49) M[tid / 7][tid % 7] = 0.0;
-    __syncthreads();
-    if (tid != 0) return;
-    const double rN = (double)r / (double)N0, eN = (double)e / (double)N1;
-    const double rp[4] = {1.0, rN, rN * rN, rN * rN * rN}, ep[4] = {1.0, eN, eN * eN, eN * eN * eN};
-    const double bin[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
-    const size_t PP2 = (size_t)PH * PH;
-    for (int c = 0; c < R.ncls; ++c) {
-        const int k = R.cls_pair[c], a = R.pa[k], b = R.pb[k];
-        const int i = R.pi[a], j = R.pj[a], i2 = R.pi[b], j2 = R.pj[b];
-        double val = patches[(size_t)k * PP2 + lag] - strip[k];
-        for (int u = 0; u <= i2; ++u)
-            for (int v = 0; v <= j2; ++v) {
-                if (u == i2 && v == j2) continue;
-                val -= bin[i2][u] * bin[j2][v] * rp[i2 - u] * ep[j2 - v] * M[i + u][j + v];
-            }
-        M[i + i2][j + j2] = val;
-    }
-    for (int q = 0; q < R.nskip; ++q) {
-        const int k = R.skip_pair[q], a = R.pa[k], b = R.pb[k];
-        const int i = R.pi[a], j = R.pj[a], i2 = R.pi[b], j2 = R.pj[b];
-        double val = strip[k];
-        for (int u = 0; u <= i2; ++u)
-            for (int v = 0; v <= j2; ++v) val += bin[i2][u] * bin[j2][v] * rp[i2 - u] * ep[j2 - v] * M[i + u][j + v];
-        patches[(size_t)k * PP2 + lag] = val;
-    }
 }
 
 // W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)

@@ -72,7 +72,46 @@ static int stream_device(hipStream_t s)
 extern "C" const char* sfft_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* sfft_version(void) { return "sfft_amd 0.1 (gfx950)"; }
 
-#define G1_QUAD_LDS (81 * 1024)      // more than half of the CU's 160 KB: one QUAD workgroup of the Omega launch per CU
+// ---- which kernels a timed stage launched (sfft_stage_kernels) -----------------------------------------------------------------
+// Every launch of this file goes through SFFT_LAUNCH.  While a StageTimer of a plan with timing enabled is alive, the name of each
+// launched kernel (the macro argument as written, template arguments included) is appended once to that stage's list; the
+// factorisation chain, which replays as a hipGraph after its first call, keeps the list of the capture and notes it on every replay.
+static thread_local std::string* tl_klog = nullptr;
+static void note_kernel(const char* name)
+{
+    std::string n;
+    for (const char* c = name; *c; ++c) if (*c != ' ' && !(c == name && *c == '(')) n.push_back(*c);
+    if (!n.empty() && name[0] == '(' && n.back() == ')') n.pop_back();
+    std::string& L = *tl_klog;
+    size_t pos = 0;
+    while (pos <= L.size()) {           // entries are separated by ';'
+        const size_t e = L.find(';', pos);
+        const size_t len = (e == std::string::npos ? L.size() : e) - pos;
+        if (len == n.size() && L.compare(pos, len, n) == 0) return;
+        if (e == std::string::npos) break;
+        pos = e + 1;
+    }
+    if (!L.empty()) L.push_back(';');
+    L += n;
+}
+static void note_kernels(const std::string& list)
+{
+    size_t pos = 0;
+    while (pos < list.size()) {
+        const size_t e = list.find(';', pos);
+        const std::string n = list.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        if (!n.empty()) note_kernel(n.c_str());
+        if (e == std::string::npos) break;
+        pos = e + 1;
+    }
+}
+struct KLogScope {      // route the names of the launches in this scope to `log` (nullptr: leave as is)
+    std::string* prev; bool on;
+    explicit KLogScope(std::string* log) : prev(tl_klog), on(log != nullptr) { if (on) tl_klog = log; }
+    ~KLogScope() { if (on) tl_klog = prev; }
+};
+#define SFFT_LAUNCH(kernel, ...) do { if (tl_klog) note_kernel(#kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
+
 #include "device_common.hpp"
 #include "fft_generic.hpp"
 #include "fft_fourstep.hpp"
@@ -137,7 +176,7 @@ struct sfft_plan {
     std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
     std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
-    int n_omg_off = 0, n_omg_diag = 0;  // Omega products actually transformed (off-diagonal / diagonal): all of them unless omg_reduce
+    int n_omg_off = 0, n_omg_diag = 0;  // Omega products that are transformed (off-diagonal / diagonal)
     int n_omg_launch = 0;               // Omega pass records that are launched (the rest are partners of dual diagonal passes)
     // polynomial plans: the Gamma block straight from row moments of I (gamma_patches) instead of column-factor passes
     int gamma_analytic = 0; double* d_cyp = nullptr; double* d_rowmomI = nullptr; double* d_gamR = nullptr; GammaArgs ga;
@@ -160,7 +199,6 @@ struct sfft_plan {
     cplx* d_stage = nullptr;            // fast path: row-pass output, one plane per distinct (image, column factor) (lazy)
     int n_stage_alloc = 0;
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
-    hipStream_t s3 = nullptr; hipEvent_t ev_la_panel = nullptr, ev_la_side = nullptr;   // solver side stream of the outer-blocked Cholesky's look-ahead (SFFT_CHOL_LA=1; off by default)
     hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr, ev_mom = nullptr, ev_gam = nullptr; int no_overlap = 0;
     const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
     cplx* d_gp = nullptr;
@@ -193,35 +231,20 @@ struct sfft_plan {
     int* d_status = nullptr;
     size_t ws_bytes = 0;
     int last_solver = 0, force_lu = 0;
-    int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row,
-                                        // 3: register-stationary taps (vconv_mixed3: measured 2.5x slower, the walk is load-latency bound at 2 waves per SIMD)
+    int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row (vconv_mixed)
     int num_cu = 256;
-    int stage_interleave = 0;           // env SFFT_STAGE_INTERLEAVE=1: forward transforms plane at a time (row pass, then the column pass of its outputs)
     int vconv_direct_launch = 0;        // env SFFT_VCONV_DIRECT=1: the leftover columns of the mixed-domain apply in a launch of their own (vconv_direct)
     int g1_dit = 1;                     // env SFFT_G1_DIT=0: grouped Omega launch without the radix-2 decimation step along the rows
     int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
-    int vconv3_r = 0;                   // env SFFT_VCONV3_R: output rows per wave of vconv_mixed3 (0: whole resident rounds)
-    int theta_mfma = 0;                 // env SFFT_THETA_MFMA=1: Theta passes in the Omega passes' matrix-core launch (3.13 -> 3.05 ms for one pair,
-                                        // but 488 -> 463 pairs/s pipelined: the vector launch overlaps better with the other pairs' kernels)
     int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 3;                    // Omega passes on the matrix cores: 3 = greek_g1_mfma4g (pass groups that share plane loads, v_mfma_f64_4x4x4_4b_f64),
-                                        // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 1: greek_g1_mfma (16x16x4), 0: vector kernel (A/B testing)
+                                        // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 0: vector kernel (A/B testing)
     unsigned long long* d_g1trace = nullptr;   // env SFFT_G1_TRACE=file: per-wave start / end stamps of the grouped Omega launch (development aid)
     G1Group* d_groups = nullptr;        // pass groups of the Omega launch
     int n_groups = 0;
-    // the same groups in blocks of up to eight that share their planes through LDS (greek_g1_mfma4w; env SFFT_G1_WG=1, off by default)
-    G1Group* d_groups_w = nullptr;
-    G1Blk* d_blks = nullptr;
-    int* d_lastcol = nullptr;           // passes whose last spectrum column goes through greek_g1_lastcol
-    int n_blks = 0, g1w = 0, g1w_ni = 0, n_lastcol = 0;
-    int g1_quad = 0;                    // env SFFT_G1_QUAD=1: the Omega launch as four-wave workgroups, one per CU
-    int omg_reduce = 0;                 // env SFFT_OMG_REDUCE=1: one Omega pass per moment class is transformed, the others are derived (measured: no net gain, off)
-    OmgReduce omgr; double* d_edge = nullptr; double* d_strip = nullptr; hipEvent_t ev_strip = nullptr;
-    int syrk4 = 0;                      // rank-256 update of the outer-blocked factorisation on v_mfma_f64_4x4x4_4b_f64 (SFFT_SYRK4=0: 16 x 16 x 4)
     int panel4 = 1, ncu = 0;            // env SFFT_PANEL4=0: the panel steps of the outer-blocked factorisation as four launches (chol_panel + 3 chol_step)
     unsigned int* d_pq = nullptr;       // [PANEL4_MAX_OUTER] role counters of chol_panel4 + [16] its hand-off flags
-    int sol_memset = 0;                 // env SFFT_SOL_MEMSET=1: zero the solution with hipMemsetAsync (a memset node in the solver graph) instead of a kernel
     int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
     int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
     int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
@@ -233,7 +256,12 @@ struct sfft_plan {
     std::vector<int> kbx_lo, kbx_hi;    // [nkx] first row / one past the last row where the kernel row factor is nonzero
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
+    // A/B switches of the launch paths, read ONCE at plan creation (never getenv on a hot path)
+    int no_dft16_regs = 0, no_rader_r24 = 0, no_gamma_aside = 0, vconv2_w12 = 1, inv_r24 = 0;
+    int launch_error = 0;               // a launch path met a case it does not serve (set by launch_pass; reported by the entry points)
     int timing = 0;
+    std::string stage_kernels[SFFT_ST_COUNT];      // kernels each stage launched in the most recent timed call (sfft_stage_kernels)
+    std::string graph_kernels;                     // kernels captured into the solver graph
     hipEvent_t ev[SFFT_ST_COUNT][2];
     bool ev_valid[SFFT_ST_COUNT];
     bool have_system = false;
@@ -384,10 +412,10 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N, bool rader)
     const long double PI = acosl(-1.0L);
     // any factorisation N = A * B with both factors on chip; cost per element ~ passes over LDS of the two sub-transforms
     // (1 for a direct power-of-two / 2^a 3^b length, 4 M / len for Bluestein: two transforms of M >= 2 len - 1 plus products)
-    auto cost = [rader](int len) {
+    auto cost = [](int len, bool may_rader) {      // (only factor B is ever built with Rader: subA carries the four-step twiddles)
         int e2, e3;
         if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return 1.0;
-        if (rader && rader_ok(len)) return 2.5;      // two transforms of len - 1 points
+        if (may_rader && rader_ok(len)) return 2.5;      // two transforms of len - 1 points
         return 4.0 * bluestein_len(len) / len;
     };
     int A = 0, B = 0;
@@ -397,7 +425,7 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N, bool rader)
         const int b = N / a;
         if (!fits_on_chip(a) || !fits_on_chip(b)) continue;
         auto padded = [](int len) { int e2, e3; if (is_pow2(len) || is_2a3b(len, &e2, &e3)) return len; return bluestein_len(len); };
-        const double c = cost(a) + cost(b) + 1e-6 * (padded(a) + padded(b));      // (ties: the smaller on-chip transforms)
+        const double c = cost(a, false) + cost(b, rader) + 1e-6 * (padded(a) + padded(b));      // (ties: the smaller on-chip transforms)
         if (c < best) { best = c; A = a; B = b; }
     }
     if (!A) return set_err(SFFT_ERR_UNSUPPORTED_SIZE,
@@ -595,17 +623,19 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_NO_WX_SUPPORT")) p->no_wx_support = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
-    if (const char* ev = getenv("SFFT_THETA_MFMA")) p->theta_mfma = atoi(ev);
     if (getenv("SFFT_NO_GRAPH")) p->use_graph = 0;
     if (getenv("SFFT_TEST_FAIL_CHOL")) p->test_fail_chol = 1;
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
-    if (const char* ev = getenv("SFFT_VCONV3_R")) p->vconv3_r = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_R")) p->vconv_r = atoi(ev);
     if (const char* ev = getenv("SFFT_G1_DIT")) p->g1_dit = atoi(ev);
-    if (const char* ev = getenv("SFFT_STAGE_INTERLEAVE")) p->stage_interleave = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_DIRECT")) p->vconv_direct_launch = atoi(ev);
-    if (const char* ev = getenv("SFFT_G1_MFMA")) p->g1_mfma = atoi(ev);
+    if (const char* ev = getenv("SFFT_G1_MFMA")) { p->g1_mfma = atoi(ev); if (p->g1_mfma == 1) p->g1_mfma = 2; }
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
+    if (getenv("SFFT_NO_DFT16_REGS")) p->no_dft16_regs = 1;
+    if (getenv("SFFT_NO_RADER_R24")) p->no_rader_r24 = 1;
+    if (getenv("SFFT_NO_GAMMA_ASIDE")) p->no_gamma_aside = 1;
+    if (const char* ev = getenv("SFFT_VCONV2_W12")) p->vconv2_w12 = atoi(ev);
+    if (const char* ev = getenv("SFFT_INV_R24")) p->inv_r24 = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
     if (BS.mode == 3) {
         if (BS.ScaFij < 1 || BS.ScaFij > BS.Fij || BS.nsx < 1 || BS.nsx > 16 || BS.nsy < 1 || BS.nsy > 16) {
@@ -751,11 +781,6 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096_q, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (const char* ev = getenv("SFFT_G1_QUAD")) p->g1_quad = atoi(ev);
-    if (p->g1_quad) {
-        PLAN_HIP(hipFuncSetAttribute((const void*)greek_g1_mfma4g<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G1_QUAD_LDS));
-        PLAN_HIP(hipFuncSetAttribute((const void*)greek_g1_mfma4g<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G1_QUAD_LDS));
-    }
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -879,40 +904,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         const bool dual_diag = p->g1_mfma && hO >= 9 && (hO <= 16 || (hO <= 32 && p->g1_mfma >= 3)) && p->Fij >= 2 && !getenv("SFFT_NO_DUAL_DIAG");
         omg_pass.assign((size_t)p->Fij * (p->Fij + 1) / 2, -1);
         auto okey = [&](int a, int b) { return a * p->Fij - (a * (a - 1)) / 2 + (b - a); };      // (a <= b) -> k, the job / patch order
-        // Polynomial kernel bases: the passes of one "moment class" (i + i', j + j') differ by known combinations of lower moments and
-        // by border sums (greek.hpp, "redundant Omega passes"): one pass per class is transformed -- a diagonal pass if the class has
-        // one, else the edge (2m, 2m + 1) that shares its planes with a dual-diagonal pass, else the first -- the rest are derived.
-        std::vector<char> omg_skip(omg_pass.size(), 0);
-        memset(&p->omgr, 0, sizeof(p->omgr));
-        if (p->DK >= 2 && p->DK <= 3 && p->g1_mfma >= 3 && hO >= 9 && hO <= 16 && N0 >= 8 * hO && N1 >= 8 * hO && p->Fij <= 10 &&
-            getenv("SFFT_OMG_REDUCE") && atoi(getenv("SFFT_OMG_REDUCE")) == 1) {
-            OmgReduce& R = p->omgr;
-            R.npl = p->Fij; R.h = hO; R.npair = (int)omg_pass.size();
-            for (int k = 0; k < p->Fij; ++k) { R.pi[k] = (unsigned char)p->kpair[2 * k]; R.pj[k] = (unsigned char)p->kpair[2 * k + 1]; }
-            for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) { R.pa[okey(a, b)] = (unsigned char)a; R.pb[okey(a, b)] = (unsigned char)b; }
-            for (int deg = 0; deg <= 2 * p->DK; ++deg)
-                for (int ca = deg; ca >= 0; --ca) {
-                    const int cb = deg - ca;
-                    int best = -1, rank = 99;
-                    for (int k = 0; k < R.npair; ++k) {
-                        const int a = R.pa[k], b = R.pb[k];
-                        if (R.pi[a] + R.pi[b] != ca || R.pj[a] + R.pj[b] != cb) continue;
-                        const int rk = (a == b) ? 0 : ((a % 2 == 0 && b == a + 1) ? 1 : 2);
-                        if (rk < rank) { rank = rk; best = k; }
-                    }
-                    if (best < 0) continue;
-                    R.cls_pair[R.ncls++] = (unsigned char)best;
-                    for (int k = 0; k < R.npair; ++k) {
-                        const int a = R.pa[k], b = R.pb[k];
-                        if (k != best && R.pi[a] + R.pi[b] == ca && R.pj[a] + R.pj[b] == cb) { omg_skip[k] = 1; R.skip_pair[R.nskip++] = (unsigned char)k; }
-                    }
-                }
-            p->omg_reduce = R.nskip > 0 ? 1 : 0;
-            if (!p->omg_reduce) std::fill(omg_skip.begin(), omg_skip.end(), 0);
-        }
         std::vector<std::pair<int, int>> partners;     // (leader pass, partner plane)
         for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) {
-            if (omg_skip[okey(a, b)]) continue;          // derived by omega_derive: no pass, no partial buffer
             if (a != b || !dual_diag) { omg_pass[okey(a, b)] = add_pass(a, b, 0, hO); continue; }
             if (a % 2 == 0 && a + 1 < p->Fij) {          // leader of the pair (a, a + 1)
                 const int lead = add_pass(a, a + 1, 0, hO);
@@ -1102,84 +1095,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             }
             if (getenv("SFFT_G1_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_g1trace, (size_t)3 * 65536)); PLAN_HIP(hipMemset(p->d_g1trace, 0, (size_t)3 * 65536 * 8)); }
             p->n_groups = (int)groups.size();
-            // (Uneven row chunks -- S - 1 long ones and a short last one, so that the long layers hold most wave slots for the whole launch
-            //  and the short waves cycle through the rest: 912 + 912 + 224 row pairs instead of 4 x 512 at 4096^2, which a slot model
-            //  prices at 0.89 of the launch -- were measured and are SLOWER: 0.44 - 0.45 ms against 0.34; config 5: 22 ms against 7.7.  Equal
-            //  chunks of 2 / 3 / 4 / 8 all take 0.34 - 0.35 ms: the launch is bound by instruction issue per SIMD,
-            //  not by how its waves fill the slots.  SFFT_G1_RPC=<rows per chunk> keeps the experiment reproducible.)
-            if (const char* ev = getenv("SFFT_G1_RPC")) {
-                const int v = atoi(ev);
-                if (p->g1_dit && N0 % 16 == 0 && v >= 16 * DF_BURST && v % (16 * DF_BURST) == 0 && v <= N0) {
-                    const int S2 = (N0 + v - 1) / v;
-                    if (S2 >= 1 && S2 <= 16) {       // the partial-sum offsets of the passes are linear in the number of chunks
-                        for (G1Pass& d : p->passes) { d.gp_off = d.gp_off / S * S2; d.gp_off2 = d.gp_off2 / S * S2; }
-                        goff = goff / S * S2;
-                        S = S2; p->S = S2; p->rows_per_chunk = v;
-                    }
-                }
-            }
             PLAN_TRY(dev_alloc(p, &p->d_groups, groups.size()));
             PLAN_HIP(hipMemcpy(p->d_groups, groups.data(), groups.size() * sizeof(G1Group), hipMemcpyHostToDevice));
-            // Blocks of up to eight groups whose planes (at most G1W_NP) are loaded once per step and shared through LDS
-            // (greek_g1_mfma4w): greedily, the next group of a block is the one that adds the fewest new planes.
-            // Measured SLOWER than one wave per group (4096^2: 0.505 vs 0.339 ms; config 3: 14.9 vs 10.3 ms; config 5: 10.7 vs 7.8 ms): the
-            // barrier per step puts all eight waves into the same phase, so nobody computes while the 56 KB of operands of a step leave
-            // LDS.  Off unless SFFT_G1_WG=1.
-            if (getenv("SFFT_G1_WG") && atoi(getenv("SFFT_G1_WG")) == 1 && !groups.empty()) {
-                std::vector<G1Blk> blks;
-                std::vector<G1Group> gw;
-                std::vector<char> taken(groups.size(), 0);
-                size_t left = groups.size();
-                int ni = 0;
-                while (left) {
-                    G1Blk b; memset(&b, 0, sizeof(b));
-                    b.g0 = (int)gw.size();
-                    auto fresh = [&](const G1Group& g) {
-                        int c = 0;
-                        for (int k = 0; k < 3; ++k) {
-                            bool in = false;
-                            for (int q = 0; q < b.np; ++q) in = in || b.plane[q] == g.plane[k];
-                            for (int q = 0; q < k; ++q) in = in || g.plane[q] == g.plane[k];
-                            if (!in) ++c;
-                        }
-                        return c;
-                    };
-                    auto add = [&](size_t gi) {
-                        const G1Group& g = groups[gi];
-                        for (int k = 0; k < 3; ++k) {
-                            bool in = false;
-                            for (int q = 0; q < b.np; ++q) in = in || b.plane[q] == g.plane[k];
-                            if (!in) b.plane[b.np++] = g.plane[k];
-                        }
-                        gw.push_back(g); taken[gi] = 1; --left; ++b.ng;
-                    };
-                    size_t first = 0;
-                    while (taken[first]) ++first;
-                    add(first);
-                    while (b.ng < 8 && left) {
-                        int best = -1, bestc = 99;
-                        for (size_t gi = 0; gi < groups.size(); ++gi) if (!taken[gi]) {
-                            const int c = fresh(groups[gi]);
-                            if (b.np + c <= G1W_NP && c < bestc) { best = (int)gi; bestc = c; }
-                        }
-                        if (best < 0) break;
-                        add((size_t)best);
-                    }
-                    ni = std::max(ni, b.np + 1);
-                    blks.push_back(b);
-                }
-                p->n_blks = (int)blks.size(); p->g1w_ni = ni; p->g1w = 1;
-                PLAN_TRY(dev_alloc(p, &p->d_groups_w, gw.size()));
-                PLAN_HIP(hipMemcpy(p->d_groups_w, gw.data(), gw.size() * sizeof(G1Group), hipMemcpyHostToDevice));
-                PLAN_TRY(dev_alloc(p, &p->d_blks, blks.size()));
-                PLAN_HIP(hipMemcpy(p->d_blks, blks.data(), blks.size() * sizeof(G1Blk), hipMemcpyHostToDevice));
-                std::vector<int> lc;
-                for (int k = 0; k < nl; ++k) lc.push_back(k);
-                if (p->theta_in_groups || p->theta_slots) for (int a = 0; a < p->n_the_fused; ++a) lc.push_back(the_pass[a]);
-                p->n_lastcol = (int)lc.size();
-                PLAN_TRY(dev_alloc(p, &p->d_lastcol, lc.size()));
-                PLAN_HIP(hipMemcpy(p->d_lastcol, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice));
-            }
         }
         PLAN_TRY(dev_alloc(p, &p->d_passes, p->passes.size()));
         PLAN_HIP(hipMemcpy(p->d_passes, p->passes.data(), p->passes.size() * sizeof(G1Pass), hipMemcpyHostToDevice));
@@ -1188,13 +1105,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_gp, (size_t)goff));
         p->hm = std::max(g1_padded(hO), g1_padded(hG)) + 1;     // padded: a launch may compute (and drop) lags beyond h
         PLAN_TRY(dev_alloc(p, &p->d_w0tab, (size_t)N0 * p->hm));
-        hipLaunchKernelGGL(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
+        SFFT_LAUNCH(build_w0tab, dim3((N0 * p->hm + 255) / 256), dim3(256), 0, 0, p->ax0.root, p->d_w0tab, N0, p->hm);
         PLAN_TRY(dev_alloc(p, &p->d_patches, (size_t)poff));
-        if (p->omg_reduce) {
-            PLAN_TRY(dev_alloc(p, &p->d_edge, (size_t)2 * hO * N0));
-            PLAN_TRY(dev_alloc(p, &p->d_strip, (size_t)PHo * PHo * 2 * hO * p->omgr.npair));      // per-line border sums
-            PLAN_HIP(hipEventCreateWithFlags(&p->ev_strip, hipEventDisableTiming));
-        }
         if (p->gamma_analytic) {
             // moment weights: cy^d (polynomial kernel: d = combined degree) or kby[j] cy^d (tabulated kernel: index j (DB + 1) + d)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1;
@@ -1239,19 +1151,9 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_w16, (size_t)nblk_b * 1024));
         if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
         if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
-        if (const char* ev = getenv("SFFT_SOL_MEMSET")) p->sol_memset = atoi(ev);
         if (const char* ev = getenv("SFFT_PANEL4")) p->panel4 = atoi(ev);
-        if (const char* ev = getenv("SFFT_SYRK4")) p->syrk4 = atoi(ev);
         PLAN_TRY(dev_alloc(p, &p->d_pq, (size_t)PANEL4_MAX_OUTER + 16));
         PLAN_HIP(hipMemset(p->d_pq, 0, ((size_t)PANEL4_MAX_OUTER + 16) * sizeof(unsigned int)));
-        // SFFT_CHOL_LA=1 (default off): look-ahead of the outer-blocked factorisation -- measured at n = 7207: 8.56 -> 8.25 ms as a graph,
-        // 8.5 -> 8.2 ms eager, 14.9 ms with the side stream at low priority: a rank-256 update workgroup lives ~145 us and holds its CU's
-        // registers, so the dependent panel launches beside it wait for slots and lose what the overlap gains
-        if (p->NEQfs >= p->chol_outer_min && getenv("SFFT_CHOL_LA") && atoi(getenv("SFFT_CHOL_LA")) == 1) {
-            PLAN_HIP(hipStreamCreateWithFlags(&p->s3, hipStreamNonBlocking));
-            PLAN_HIP(hipEventCreateWithFlags(&p->ev_la_panel, hipEventDisableTiming));
-            PLAN_HIP(hipEventCreateWithFlags(&p->ev_la_side, hipEventDisableTiming));
-        }
         if (const char* ev = getenv("SFFT_CHOL_DF_WG")) p->df_groups = std::max(1, atoi(ev));
         if (const char* ev = getenv("SFFT_FUSED_STEP")) p->fused_step = atoi(ev);
         if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
@@ -1411,20 +1313,16 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_groups_w, p->d_blks, p->d_lastcol, p->d_g1trace, p->d_edge, p->d_strip, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
     if (p->s2) { hipStreamSynchronize(p->s2); hipStreamDestroy(p->s2); }
-    if (p->s3) { hipStreamSynchronize(p->s3); hipStreamDestroy(p->s3); }
-    if (p->ev_la_panel) hipEventDestroy(p->ev_la_panel);
-    if (p->ev_la_side) hipEventDestroy(p->ev_la_side);
     if (p->ev_in) hipEventDestroy(p->ev_in);
     if (p->ev_pre) hipEventDestroy(p->ev_pre);
     if (p->ev_mom) hipEventDestroy(p->ev_mom);
     if (p->ev_gam) hipEventDestroy(p->ev_gam);
-    if (p->ev_strip) hipEventDestroy(p->ev_strip);
     delete p;
     return SFFT_OK;
 }
@@ -1470,7 +1368,13 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
     return SFFT_OK;
 }
 
-extern "C" int sfft_set_timing(sfft_plan* p, int enable) { if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan"); p->timing = enable; return SFFT_OK; }
+extern "C" int sfft_set_timing(sfft_plan* p, int enable)
+{
+    if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan");
+    p->timing = enable;
+    if (enable) for (int s = 0; s < SFFT_ST_COUNT; ++s) p->stage_kernels[s].clear();
+    return SFFT_OK;
+}
 extern "C" int sfft_set_force_lu(sfft_plan* p, int enable) { if (!p) return set_err(SFFT_ERR_INVALID_ARG, "NULL plan"); p->force_lu = enable; return SFFT_OK; }
 
 extern "C" int sfft_stage_ms(sfft_plan* p, int stage, float* ms)
@@ -1483,9 +1387,19 @@ extern "C" int sfft_stage_ms(sfft_plan* p, int stage, float* ms)
     return SFFT_OK;
 }
 
+extern "C" int sfft_stage_kernels(sfft_plan* p, int stage, char* buf, int cap)
+{
+    if (!p || !buf || cap < 1 || stage < 0 || stage >= SFFT_ST_COUNT) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
+    const std::string& L = p->stage_kernels[stage];
+    const size_t n = std::min(L.size(), (size_t)cap - 1);
+    memcpy(buf, L.data(), n);
+    buf[n] = 0;
+    return SFFT_OK;
+}
+
 struct StageTimer {
-    sfft_plan* p; int st; hipStream_t s;
-    StageTimer(sfft_plan* p_, int st_, hipStream_t s_) : p(p_), st(st_), s(s_) { if (p->timing) { hipEventRecord(p->ev[st][0], s); } }
+    sfft_plan* p; int st; hipStream_t s; KLogScope k;
+    StageTimer(sfft_plan* p_, int st_, hipStream_t s_) : p(p_), st(st_), s(s_), k(p_->timing ? &p_->stage_kernels[st_] : nullptr) { if (p->timing) { hipEventRecord(p->ev[st][0], s); } }
     ~StageTimer() { if (p->timing) { hipEventRecord(p->ev[st][1], s); p->ev_valid[st] = true; } }
 };
 
@@ -1497,8 +1411,8 @@ static bool fast_axis(const AxisHost& a) { return !a.big && !a.blue && a.M == 40
 // one pass of batched strided sub-transforms
 static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, const AxisHost& sub, const cplx* rootN, hipStream_t s)
 {
-    if (d.mode == 2 && d.len == 16 && sub.M == 16 && !sub.blue && !getenv("SFFT_NO_DFT16_REGS")) {        // 16-point first pass of a column transform: registers only
-        hipLaunchKernelGGL(strided_dft16_cols, dim3((d.nlines + 63) / 64, (d.J + 3) / 4), dim3(256), 0, s, in, out, d, rootN);
+    if (d.mode == 2 && d.len == 16 && sub.M == 16 && !sub.blue && !p->no_dft16_regs) {        // 16-point first pass of a column transform: registers only
+        SFFT_LAUNCH(strided_dft16_cols, dim3((d.nlines + 63) / 64, (d.J + 3) / 4), dim3(256), 0, s, in, out, d, rootN);
         return;
     }
     int TC, MS;
@@ -1507,20 +1421,25 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
     pick_col_tile(sub, &TC, &MS, sub.blue ? std::min((size_t)4800, (size_t)LDS_COL_ELEMS) : 0);
     if (sub.rader) {                                // RADER_TC sequences of RADER_XS + 1 elements (fft_fourstep.hpp)
         TC = RADER_TC; MS = (RADER_XS + 1 + 15) / 16 * 16 + 16 / TC;
-        if (d.mode == 2 && !d.twiddle && !d.w && sub.N == 577 && !getenv("SFFT_NO_RADER_R24")) {       // ... in registers, 24 x 24
-            hipLaunchKernelGGL(strided_rader577_r24, dim3((d.nlines + RDR_SEQ - 1) / RDR_SEQ, d.J), dim3(RDR_NT), 0, s, in, out, d, axis_dev(sub));
+        if (d.mode == 2 && !d.twiddle && !d.w && sub.N == 577 && !p->no_rader_r24) {       // ... in registers, 24 x 24
+            SFFT_LAUNCH(strided_rader577_r24, dim3((d.nlines + RDR_SEQ - 1) / RDR_SEQ, d.J), dim3(RDR_NT), 0, s, in, out, d, axis_dev(sub));
             return;
         }
         if (d.mode == 2 && !d.twiddle) {            // (the second pass of a column transform: its own kernel)
-            hipLaunchKernelGGL(strided_rader577, dim3((d.nlines + TC - 1) / TC, d.J), dim3(RADER_NT), (size_t)TC * MS * sizeof(cplx), s, in, out, d,
+            SFFT_LAUNCH(strided_rader577, dim3((d.nlines + TC - 1) / TC, d.J), dim3(RADER_NT), (size_t)TC * MS * sizeof(cplx), s, in, out, d,
                                axis_dev(sub), MS);
             return;
         }
+        // strided_dft / lds_dft have no Rader branch: a Rader sub-axis anywhere but the second pass of a column transform would be
+        // transformed as a 576-point sequence.  No caller does this today (only ax0's factor B is built with Rader); refuse rather than compute
+        set_err(SFFT_ERR_UNSUPPORTED_SIZE, "internal: Rader sub-transform requested outside the second pass of a column transform");
+        p->launch_error = SFFT_ERR_UNSUPPORTED_SIZE;
+        return;
     }
     const int nt = fft_threads(TC * (sub.rader ? sub.N : sub.M));
     const int ngroups = (d.mode == 2) ? (d.nlines + TC - 1) / TC : (d.J + TC - 1) / TC;
     const int gy = (d.mode == 2) ? d.J : d.nlines;
-    hipLaunchKernelGGL(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, ilog2(TC), MS);
+    SFFT_LAUNCH(strided_dft, dim3(ngroups, gy), dim3(nt), (size_t)TC * MS * sizeof(cplx), s, in, out, d, axis_dev(sub), rootN, TC, ilog2(TC), MS);
 }
 
 // four-step transform of `nlines` lines of length ax.N; element stride st, line stride lst (complex elements).
@@ -1555,12 +1474,12 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
     if (fast_axis(p->ax0) && !p->no_fast_fft) {
         const int npairs = (p->Nh + 1) / 2;
         const int per = (npairs + 7) / 8;
-        hipLaunchKernelGGL(cols_c2c_4096, dim3(8 * per, nplanes), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, data, p->Nh, p->Nhp,
+        SFFT_LAUNCH(cols_c2c_4096, dim3(8 * per, nplanes), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, data, p->Nh, p->Nhp,
                            p->lay, p->ax0.tw, inverse, 1.0, per);
     } else {
         const int G8 = 8 * (p->TC >= 8 ? 1 : 8 / p->TC);
         dim3 g2(((p->Nh + p->TC - 1) / p->TC + G8 - 1) / G8 * G8, nplanes);
-        hipLaunchKernelGGL(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, data, p->N0, p->Nh, p->Nhp, p->TC, ilog2(p->TC), p->MS,
+        SFFT_LAUNCH(cols_c2c, g2, dim3(p->nt_cols), p->lds_cols, s, data, p->N0, p->Nh, p->Nhp, p->TC, ilog2(p->TC), p->MS,
                            p->lay, axis_dev(p->ax0), inverse, 1.0);
     }
 }
@@ -1570,14 +1489,15 @@ static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipS
 static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* dst, hipStream_t s, int st_rows = -1, int st_cols = -1,
                           bool rows_only = false)
 {
+    std::string* const klog_outer = tl_klog;      // (the stage events below also redirect the kernel-name log)
     dim3 g1((p->N0 + 1) / 2, nplanes);
-    if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
+    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][0], s); tl_klog = &p->stage_kernels[st_rows]; }
     if (p->ax1.big) {
         const int npr = (p->N0 + 1) / 2;
         for (int k = 0; k < nplanes; ++k) {
-            hipLaunchKernelGGL(pack_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, ra.src[k], ra.wx[k], ra.wy[k], p->d_big1, p->N0, p->N1);
+            SFFT_LAUNCH(pack_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, ra.src[k], ra.wx[k], ra.wy[k], p->d_big1, p->N0, p->N1);
             big_axis_transform(p, p->ax1, p->d_big1, p->d_big2, 1, p->N1, npr, false, 0, s);
-            hipLaunchKernelGGL(untangle_rows, dim3((p->Nh + 255) / 256, npr), dim3(256), 0, s, p->d_big1, dst + (size_t)k * p->N0 * p->Nhp,
+            SFFT_LAUNCH(untangle_rows, dim3((p->Nh + 255) / 256, npr), dim3(256), 0, s, p->d_big1, dst + (size_t)k * p->N0 * p->Nhp,
                                p->N0, p->N1, p->Nh, p->Nhp, p->scale);
         }
     } else if (fast_axis(p->ax1) && !p->no_fast_fft) {
@@ -1590,7 +1510,7 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
             else { grp.first[grp.ngroups] = k; grp.count[grp.ngroups] = 1; ++grp.ngroups; }
         }
         const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
-        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, rw, grp, dst,
+        SFFT_LAUNCH(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, rw, grp, dst,
                            p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     else if (p->rows_r24) {
@@ -1598,21 +1518,21 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
         for (int k = 0; k < nplanes; ++k) { if (!rw.wx[k]) rw.wx[k] = p->d_ones; if (!rw.wy[k]) rw.wy[k] = p->d_ones; }
         const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
         if (p->rows_r24 == 16)
-            hipLaunchKernelGGL(rows_r2c_r24<16>, dim3(8 * rp_per * nplanes), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, rw, nplanes, dst,
+            SFFT_LAUNCH(rows_r2c_r24<16>, dim3(8 * rp_per * nplanes), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, rw, nplanes, dst,
                                p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
         else
-            hipLaunchKernelGGL(rows_r2c_r24<24>, dim3(8 * rp_per * nplanes), dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s, rw, nplanes, dst,
+            SFFT_LAUNCH(rows_r2c_r24<24>, dim3(8 * rp_per * nplanes), dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s, rw, nplanes, dst,
                                p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     else
-        hipLaunchKernelGGL(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
+        SFFT_LAUNCH(rows_r2c, g1, dim3(p->nt_rows), p->lds_rows, s, ra, dst, p->N0, p->N1, p->Nh, p->Nhp,
                            p->lay, axis_dev(p->ax1), p->scale);
     LAUNCH_CHECK();
-    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
+    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; tl_klog = klog_outer; }
     if (rows_only) return SFFT_OK;
-    if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
+    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][0], s); tl_klog = &p->stage_kernels[st_cols]; }
     launch_cols(p, dst, nplanes, 0, s);
-    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
+    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; tl_klog = klog_outer; }
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -1624,6 +1544,7 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
 static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const double* d_J, cplx* dst, hipStream_t s, bool with_sca,
                                        int st_rows, int st_cols)
 {
+    std::string* const klog_outer = tl_klog;      // (the stage events below also redirect the kernel-name log)
     struct Out { int plane; const double* wx; };
     struct Stage { const double* src; const double* wy; std::vector<Out> outs; };
     std::vector<Stage> stages;
@@ -1658,7 +1579,7 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             int rc = forward_planes(p, ra, n, p->d_stage + (size_t)k0 * plane_sz, s, st_rows, -1, true);
             if (rc) return rc;
         }
-        if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
+        if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][0], s); tl_klog = &p->stage_kernels[st_cols]; }
         if (p->ax0.big) {
             // four-step column axis: every output plane is the transform of its stage plane times the row factor, applied as the first
             // pass reads the stage plane (same traffic as transforming a finished plane; the row pass ran once per column factor)
@@ -1667,7 +1588,7 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                     big_axis_transform(p, p->ax0, dst + (size_t)o.plane * plane_sz, p->d_colscr, p->Nhp, 1, p->Nh, true, 0, s,
                                        p->d_stage + (size_t)k * plane_sz, o.wx == p->d_ones ? nullptr : o.wx);
             LAUNCH_CHECK();
-            if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
+            if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; tl_klog = klog_outer; }
             return SFFT_OK;
         }
         const int G = p->TC >= 8 ? 1 : 8 / p->TC;
@@ -1692,50 +1613,22 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             if (p->cols_r24) {     // register-resident 6144- / 9216-point columns, one per workgroup, 64 columns per (XCD-interleaved) column group
                 const dim3 grid(64 * g.nout * ((p->Nh + 63) / 64));
                 if (p->cols_r24 == 16)
-                    hipLaunchKernelGGL(cols_fwd_weighted_r24<16>, grid, dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s,
+                    SFFT_LAUNCH(cols_fwd_weighted_r24<16>, grid, dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s,
                                        p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
                 else
-                    hipLaunchKernelGGL(cols_fwd_weighted_r24<24>, grid, dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s,
+                    SFFT_LAUNCH(cols_fwd_weighted_r24<24>, grid, dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s,
                                        p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
                 continue;
             }
-            hipLaunchKernelGGL(cols_fwd_weighted, dim3(8 * G * g.nout * ntg), dim3(p->nt_cols), p->lds_cols, s, p->d_stage, dst, g, p->N0, p->Nh,
+            SFFT_LAUNCH(cols_fwd_weighted, dim3(8 * G * g.nout * ntg), dim3(p->nt_cols), p->lds_cols, s, p->d_stage, dst, g, p->N0, p->Nh,
                                p->Nhp, p->TC, ilog2(p->TC), p->MS, p->lay, axis_dev(p->ax0));
         }
         LAUNCH_CHECK();
-        if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
+        if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; tl_klog = klog_outer; }
         return SFFT_OK;
     }
     const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
-    if (p->stage_interleave && p->colq && p->lay.rstride == 4 && p->lay.mask == 3) {
-        // A/B (SFFT_STAGE_INTERLEAVE=1): plane at a time -- the row pass of one stage plane, then the column pass of its outputs, so that the
-        // column pass finds the 134 MB it reads in the 256 MB memory-side cache; the image is then read once per stage plane
-        if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
-        const int nquads = (p->Nh + 3) / 4;
-        bool momI = false, momJ = false;
-        for (int k = 0; k < nst; ++k) {
-            RowsArgs ra;
-            for (int u = 0; u < SFFT_MAX_PLANES; ++u) { ra.src[u] = nullptr; ra.wx[u] = p->d_ones; ra.wy[u] = p->d_ones; }
-            RowGroups grp; grp.ngroups = 1; grp.first[0] = 0; grp.count[0] = 1;
-            for (int u = 0; u < SFFT_MAX_PLANES; ++u) { grp.mom_out[u] = nullptr; grp.mom_nq[u] = 0; }
-            ra.src[0] = stages[k].src; ra.wy[0] = stages[k].wy;
-            if (p->rowmom_fused && d_J) {
-                if (stages[k].src == d_J && !momJ) { grp.mom_out[0] = p->d_rowmom; grp.mom_nq[0] = p->nby; momJ = true; }
-                else if (stages[k].src == d_I && !momI) { grp.mom_out[0] = p->d_rowmomI; grp.mom_nq[0] = p->gam_nmu; momI = true; }
-            }
-            hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, 1), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp,
-                               p->d_stage + (size_t)k * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
-            ColOuts g; memset(&g, 0, sizeof(g));
-            for (const Out& o : stages[k].outs) { g.stage_plane[g.nout] = k; g.out_plane[g.nout] = o.plane; g.wx[g.nout] = o.wx; ++g.nout; }
-            const int total = nquads * g.nout;
-            hipLaunchKernelGGL(cols_fwd_weighted_4096_q, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
-                               p->Nhp, p->lay, p->ax0.tw, nquads);
-        }
-        LAUNCH_CHECK();
-        if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
-        return SFFT_OK;
-    }
-    if (p->timing && st_rows >= 0) hipEventRecord(p->ev[st_rows][0], s);
+    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][0], s); tl_klog = &p->stage_kernels[st_rows]; }
     for (int k0 = 0; k0 < nst; k0 += SFFT_MAX_PLANES) {
         const int n = std::min(SFFT_MAX_PLANES, nst - k0);
         RowsArgs ra;
@@ -1753,12 +1646,12 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                 if (src == d_J) { grp.mom_out[gI] = p->d_rowmom; grp.mom_nq[gI] = p->nby; }
                 else if (src == d_I) { grp.mom_out[gI] = p->d_rowmomI; grp.mom_nq[gI] = p->gam_nmu; }
             }
-        hipLaunchKernelGGL(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp,
+        SFFT_LAUNCH(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp,
                            p->d_stage + (size_t)k0 * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     LAUNCH_CHECK();
-    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; }
-    if (p->timing && st_cols >= 0) hipEventRecord(p->ev[st_cols][0], s);
+    if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; tl_klog = klog_outer; }
+    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][0], s); tl_klog = &p->stage_kernels[st_cols]; }
     const int npairs = (p->Nh + 1) / 2;
     int k = 0;
     while (k < nst) {          // whole stages per launch, so that a stage tile's readers sit next to each other in the grid
@@ -1771,16 +1664,16 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
         if (p->colq && p->lay.rstride == 4 && p->lay.mask == 3) {      // four columns per workgroup: whole 64-byte pieces per lane quad
             const int nquads = (p->Nh + 3) / 4;
             const int total = nquads * g.nout;
-            hipLaunchKernelGGL(cols_fwd_weighted_4096_q, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
+            SFFT_LAUNCH(cols_fwd_weighted_4096_q, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
                                p->Nhp, p->lay, p->ax0.tw, nquads);
             continue;
         }
         const int total = npairs * g.nout;
-        hipLaunchKernelGGL(cols_fwd_weighted_4096, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
+        SFFT_LAUNCH(cols_fwd_weighted_4096, dim3(8 * ((total + 7) / 8)), dim3(512), (2 * F4K_LDS + 8) * sizeof(cplx), s, p->d_stage, dst, g,
                            p->Nh, p->Nhp, p->lay, p->ax0.tw, npairs);
     }
     LAUNCH_CHECK();
-    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; }
+    if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; tl_klog = klog_outer; }
     return SFFT_OK;
 }
 
@@ -1826,9 +1719,9 @@ static void launch_g1(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
     const bool dit = p->g1_dit && (p->N0 % 2) == 0 && (HBW % 2) == 0 && p->N0 / (2 * p->S) >= 8;
     const int rpc2 = (p->N0 / 2 + p->S - 1) / p->S;
     for (int rb = 0; rb < h || rb == 0; rb += HBW) {
-        if (dit) hipLaunchKernelGGL((greek_g1<HBW, U, true>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
+        if (dit) SFFT_LAUNCH((greek_g1<HBW, U, true>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
                                     p->Nhp, p->lay, rpc2, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
-        else hipLaunchKernelGGL((greek_g1<HBW, U>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
+        else SFFT_LAUNCH((greek_g1<HBW, U>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
                                 p->Nhp, p->lay, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
     }
 }
@@ -1855,7 +1748,7 @@ static int g1_padded(int h) { const int b = g1_band(h); return ((std::max(h, 1) 
 static bool g1_decimated(const sfft_plan* p)
 {
     // whole 8-row steps of x' in every chunk, the (possibly shorter) last one included
-    return p->g1_mfma >= 3 && p->d_groups && p->g1_dit && (p->N0 % (16 * DF_BURST)) == 0 && (p->rows_per_chunk % (16 * DF_BURST)) == 0;
+    return p->g1_mfma >= 3 && p->d_groups && p->g1_dit && (p->N0 % 16) == 0 && (p->rows_per_chunk % 16) == 0;
 }
 
 static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t s, bool planes_only = false)
@@ -1871,57 +1764,24 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
         if (grouped) {
             const int ncb16 = (p->Nh + 15) / 16;
             const int totg = ncb16 * p->S * p->n_groups;
-            const bool whole = (p->rows_per_chunk % (8 * DF_BURST)) == 0 && (p->N0 % p->rows_per_chunk) == 0;      // no step runs past its chunk
+            const bool whole = (p->rows_per_chunk % 8) == 0 && (p->N0 % p->rows_per_chunk) == 0;      // no step runs past its chunk
             const bool dit = g1_decimated(p);
             // lag half-widths beyond 16 (KerHW 9 .. 16): the 16 lags lag0 + 1 .. lag0 + 16 per launch (the planes are read once per launch)
             for (int lag0 = 0; lag0 < h; lag0 += 16) {
             // (Theta passes as slots of their own groups: in the first launch only, behind the Omega groups)
             const int ngl = (lag0 == 0 || !p->theta_slots) ? p->n_groups : p->n_groups_omg;
             const int totl = ncb16 * p->S * ngl;
-            if (dit && p->g1w) {
-                // workgroups of eight waves, the planes of a block shared through LDS (greek_g1_mfma4w); the last spectrum column on its own
-                // when it would be a tile by itself
-                const bool lastcol = p->Nh > 16 && (p->Nh - 1) % 16 == 0;
-                const int ncbw = lastcol ? (p->Nh - 1) / 16 : ncb16;
-                const int ntiles = ncbw * p->S;
-                const int cux = std::max(1, p->num_cu / 8);
-                int tpr = 0, rounds = 0, nwg;
-                if (p->n_blks > 1) {
-                    tpr = std::max(1, cux / p->n_blks);
-                    rounds = ((ntiles + 7) / 8 + tpr - 1) / tpr;
-                    nwg = 8 * tpr * p->n_blks;
-                } else nwg = 8 * ((ntiles * p->n_blks + 7) / 8);
-                const size_t ldsb = (size_t)2 * p->g1w_ni * 2048;
-                if (lastcol && lag0 == 0)
-                    hipLaunchKernelGGL(greek_g1_lastcol, dim3(p->n_lastcol, p->S), dim3(256), 0, s, p->d_spec, p->d_passes, p->d_lastcol, p->d_gp, p->N0, p->Nh,
-                                       p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm);
-                const bool halfl = lag0 > 0 && h - lag0 <= 8, two = p->g1w_ni > 8;
-                auto KW = halfl ? (two ? greek_g1_mfma4w<true, true> : greek_g1_mfma4w<true, false>)
-                                : (two ? greek_g1_mfma4w<false, true> : greek_g1_mfma4w<false, false>);
-                hipLaunchKernelGGL(KW, dim3(nwg), dim3(512), ldsb, s, p->d_spec, p->d_passes, p->d_groups_w, p->d_blks, p->n_blks, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncbw, p->S, lag0, tpr, rounds, p->g1w_ni);
-            } else
-            if (dit && p->g1_quad) {
-                // four waves per workgroup, one workgroup per CU (see greek_g1_mfma4g, QUAD)
-                const int nwgq = 8 * ((totl + 31) / 32);
-                if (lag0 > 0 && h - lag0 <= 8)
-                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
-                                       p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
-                else
-                    hipLaunchKernelGGL((greek_g1_mfma4g<false, true, false, true>), dim3(nwgq), dim3(256), G1_QUAD_LDS, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
-                                       p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
-            } else
             if (dit && lag0 > 0 && h - lag0 <= 8)
-                hipLaunchKernelGGL((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
+                SFFT_LAUNCH((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else if (dit)
-                hipLaunchKernelGGL((greek_g1_mfma4g<false, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
+                SFFT_LAUNCH((greek_g1_mfma4g<false, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else if (whole)
-                hipLaunchKernelGGL(greek_g1_mfma4g<false>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
+                SFFT_LAUNCH(greek_g1_mfma4g<false>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else
-                hipLaunchKernelGGL(greek_g1_mfma4g<true>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
+                SFFT_LAUNCH(greek_g1_mfma4g<true>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
                                    p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             }
             if (p->d_g1trace) {     // development aid (SFFT_G1_TRACE=file): dump the wave stamps of this launch
@@ -1930,11 +1790,8 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
                 if (hipMemcpy(h.data(), p->d_g1trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
                     if (FILE* f = fopen(getenv("SFFT_G1_TRACE"), "w")) { for (size_t k = 0; k + 2 < h.size(); k += 3) fprintf(f, "%llu %llu %llu\n", h[k], h[k + 1], h[k + 2]); fclose(f); }
             }
-        } else if (p->g1_mfma == 1)        // (SFFT_G1_MFMA=1: the 16 x 16 x 4 instruction, for A/B runs)
-            hipLaunchKernelGGL((greek_g1_mfma<2, false>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
-                               p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
-        else
-            hipLaunchKernelGGL((greek_g1_mfma4<2>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
+        } else
+            SFFT_LAUNCH((greek_g1_mfma4<2>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
                                p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
         LAUNCH_CHECK();
         return SFFT_OK;
@@ -1953,7 +1810,7 @@ static int run_fill(sfft_plan* p, hipStream_t s, bool lower_only)
 {
     const int n = p->NEQfs;
     dim3 g((n + 1 + 15) / 16, (n + 1 + 15) / 16);
-    hipLaunchKernelGGL(fill_system, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->d_idx, n, p->NEQ,
+    SFFT_LAUNCH(fill_system, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->d_idx, n, p->NEQ,
                        p->d_A, p->ld, (double*)nullptr, lower_only ? 1 : 0);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -1972,84 +1829,66 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
     const int n = p->NEQfs;
     const int nbc = (n + CB - 1) / CB;
     unsigned int* d_queue = p->d_tflags + (size_t)nbc * (nbc + 1);
-    hipLaunchKernelGGL(chol_begin, dim3(1), dim3(PANEL4_MAX_OUTER), 0, s, p->d_epoch, d_queue, p->d_pq);
+    SFFT_LAUNCH(chol_begin, dim3(1), dim3(PANEL4_MAX_OUTER), 0, s, p->d_epoch, d_queue, p->d_pq);
     const bool dataflow = p->dataflow && n < p->chol_outer_min;
     if (dataflow) {
         // the whole factorisation as one launch of persistent workgroups (see chol_dataflow)
         const int ntask = 2 + (nbc - 1) * (nbc + 2) / 2;
-        hipLaunchKernelGGL(chol_dataflow, dim3(std::min(p->df_groups, ntask)), dim3(256), 0, s, p->d_A, p->ld, n, p->d_tflags, d_queue,
+        SFFT_LAUNCH(chol_dataflow, dim3(std::min(p->df_groups, ntask)), dim3(256), 0, s, p->d_A, p->ld, n, p->d_tflags, d_queue,
                            p->d_epoch, p->d_status, p->d_rd, p->d_w16, p->d_winv, p->d_trace);
     } else
-    hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
+    SFFT_LAUNCH(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
     int step = 0;
     int kb = dataflow ? n : 0;  // first column not yet factored
     if (p->fused_step && n >= p->chol_outer_min) {
         // outer blocks of 256 columns (see chol_syrk): the inner steps stay inside the block, one rank-256 update per block
         const int OB = 4 * CB;
-        bool side_pending = false;
-        auto SYRK_K = p->syrk4 ? chol_syrk<true> : chol_syrk<false>;       // (SFFT_SYRK4=0: the 16 x 16 x 4 matrix instruction)
         int outer = 0;
         while (n - kb >= OB + CB) {
             const int ntile4 = (n + 1 - kb + CB - 1) / CB;       // 64-row tiles of this block column (border row included)
             if (p->panel4 && p->d_pq && ntile4 <= p->ncu && outer < PANEL4_MAX_OUTER) {
                 // the four panel steps as one launch of co-resident workgroups (chol_panel4)
-                hipLaunchKernelGGL(chol_panel4, dim3(ntile4), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_pq + PANEL4_MAX_OUTER, p->d_pq, p->d_epoch,
+                SFFT_LAUNCH(chol_panel4, dim3(ntile4), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_pq + PANEL4_MAX_OUTER, p->d_pq, p->d_epoch,
                                    (unsigned)outer, p->d_status, p->d_rd, p->d_w16, nbc);
             } else {
-            hipLaunchKernelGGL(chol_panel, dim3(1 + (n + 1 - kb - CB + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
+            SFFT_LAUNCH(chol_panel, dim3(1 + (n + 1 - kb - CB + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
             for (int st = 1; st < 4; ++st) {
                 const int k = kb + st * CB;
                 const int ntile = (n + 1 - k + CB - 1) / CB;
-                hipLaunchKernelGGL(chol_step, dim3(4 - st, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
+                SFFT_LAUNCH(chol_step, dim3(4 - st, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
                                    p->d_bflags + p->n_bflags - 1, p->d_epoch, (unsigned)((k / CB) % 255), p->d_status, p->d_rd);
             }
             }
             ++outer;
             const int r0 = kb + OB;
             const int nt = (n + 1 - r0 + SYRK_T - 1) / SYRK_T;
-            const int NA = OB / SYRK_T;         // tile columns of the NEXT outer block
-            if (p->s3 && nt > NA) {
-                // Look-ahead: the rank-256 update of the next outer block's columns stays on this stream and the panel steps of that
-                // block follow it at once; the update of everything to the right runs on the plan's solver side stream beside them.
-                // Dependencies: the side update needs this block's panel; the next near update needs the previous side update.
-                HIPCHK(hipEventRecord(p->ev_la_panel, s));
-                if (side_pending) HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0));
-                hipLaunchKernelGGL(SYRK_K, dim3(NA, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
-                HIPCHK(hipStreamWaitEvent(p->s3, p->ev_la_panel, 0));
-                hipLaunchKernelGGL(SYRK_K, dim3(nt - NA, nt), dim3(256), 0, p->s3, p->d_A, p->ld, n, kb, OB, r0, NA);
-                HIPCHK(hipEventRecord(p->ev_la_side, p->s3));
-                side_pending = true;
-            } else {
-                if (side_pending) { HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0)); side_pending = false; }
-                hipLaunchKernelGGL(SYRK_K, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
-            }
+            SFFT_LAUNCH(chol_syrk, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
             kb = r0;
             // chol_panel takes its diagonal block from the hand-over buffer, chol_panel4 from the matrix itself: the copy is only needed
             // when the next panel is a chol_panel launch (the last outer block's successor, or a block column too tall for chol_panel4)
             const bool next_p4 = (n - kb >= OB + CB) && p->panel4 && p->d_pq && (n + 1 - kb + CB - 1) / CB <= p->ncu && outer < PANEL4_MAX_OUTER;
             if (!next_p4)
-                hipLaunchKernelGGL(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A + (size_t)kb * p->ld + kb, p->ld, std::min(CB, n - kb), p->d_dbuf);
+                SFFT_LAUNCH(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A + (size_t)kb * p->ld + kb, p->ld, std::min(CB, n - kb), p->d_dbuf);
         }
-        if (side_pending) HIPCHK(hipStreamWaitEvent(s, p->ev_la_side, 0));       // join: the remaining steps touch every column
     }
     int k_start = kb;
     if (p->fused_step && n - kb >= 2 * CB) {
         // first panel only; steps with a full block: one fused launch each (update with the previous panel + this panel)
         {
             const int rows_below = n + 1 - kb - CB;
-            hipLaunchKernelGGL(chol_panel, dim3(1 + (rows_below + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
+            SFFT_LAUNCH(chol_panel, dim3(1 + (rows_below + CB - 1) / CB), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_dbuf, p->d_status, p->d_rd);
         }
         int k = kb + CB;
         for (; n - k >= CB; k += CB) {
             const int ntile = (n + 1 - k + CB - 1) / CB;
-            hipLaunchKernelGGL(chol_step, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
+            SFFT_LAUNCH(chol_step, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf + (size_t)2 * CB * CB,
                                p->d_bflags + p->n_bflags - 1, p->d_epoch, (unsigned)((k / CB) % 255), p->d_status, p->d_rd);
         }
         // what is left: the update with the last full panel (it also hands over the raw diagonal block) and the partial block
         if (k < n) {
             const int rows_below = n + 1 - k;
             const int ntile = (rows_below + CB - 1) / CB;
-            hipLaunchKernelGGL(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf);
+            SFFT_LAUNCH(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k - CB, p->d_dbuf);
         }
         k_start = k;
         step = 0;
@@ -2060,30 +1899,29 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
         const int nblk = 1 + (rows_below + CB - 1) / CB;
         double* Dcur = p->d_dbuf + (size_t)(step & 1) * CB * CB;
         double* Dnxt = p->d_dbuf + (size_t)((step + 1) & 1) * CB * CB;
-        hipLaunchKernelGGL(chol_panel, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, k, Dcur, p->d_status, p->d_rd);
+        SFFT_LAUNCH(chol_panel, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, k, Dcur, p->d_status, p->d_rd);
         const int ntile = (rows_below + CB - 1) / CB;
         if (ntile > 0 && k + nb < n)
-            hipLaunchKernelGGL(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k, Dnxt);
+            SFFT_LAUNCH(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k, Dnxt);
     }
     LAUNCH_CHECK();
     // Extend_Solution's zeros (removed unknowns stay exactly 0).  A kernel, not hipMemsetAsync: captured into the plan's hipGraph a
     // memset node was seen to leave these entries unwritten now and then when several plans replay their graphs from different
     // host threads at once (bench.py --pairs: 5 forbidden entries of a pair's Solution holding stale bytes); SFFT_SOL_MEMSET=1 restores it
-    if (p->sol_memset) HIPCHK(hipMemsetAsync(d_solution, 0, (size_t)p->NEQ * sizeof(double), s));
-    else hipLaunchKernelGGL(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, p->NEQ);
+    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, p->NEQ);
     const int nblk = (n + CB - 1) / CB;
     if (p->back_variant == 1) {
         if (!dataflow)      // (chol_dataflow leaves the inverses of the diagonal blocks behind itself)
-            hipLaunchKernelGGL(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
-        hipLaunchKernelGGL(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->d_epoch, p->d_status);
+            SFFT_LAUNCH(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
+        SFFT_LAUNCH(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->d_epoch, p->d_status);
     } else
     for (int b = nblk - 1; b >= 0; --b) {
         const int kb = b * CB, nb = std::min(CB, n - kb);
         const int rows_below = n - (kb + nb);
         const int nslice = rows_below > 0 ? std::min(BACK_SLICES, (rows_below + CB - 1) / CB) : 1;
-        hipLaunchKernelGGL(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter, p->d_rd);
+        SFFT_LAUNCH(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter, p->d_rd);
     }
-    hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
+    SFFT_LAUNCH(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
                        p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -2102,7 +1940,8 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
             p->use_graph = 0;
             return run_cholesky_launches(p, d_solution, s);
         }
-        const int rc = run_cholesky_launches(p, d_solution, s);
+        int rc;
+        { KLogScope cap(&p->graph_kernels); p->graph_kernels.clear(); rc = run_cholesky_launches(p, d_solution, s); }
         const hipError_t e = hipStreamEndCapture(s, &graph);
         hipError_t e2 = hipSuccess;
         if (rc == SFFT_OK && e == hipSuccess && graph) e2 = hipGraphInstantiate(&p->chol_exec, graph, nullptr, nullptr, 0);
@@ -2114,6 +1953,7 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
             return run_cholesky_launches(p, d_solution, s);
         }
     }
+    if (tl_klog) note_kernels(p->graph_kernels);
     HIPCHK(hipGraphLaunch(p->chol_exec, s));
     return SFFT_OK;
 }
@@ -2122,16 +1962,16 @@ static int run_lu(sfft_plan* p, double* d_solution, hipStream_t s)
 {
     const int n = p->NEQfs;
     for (int k = 0; k < n; ++k) {
-        hipLaunchKernelGGL(lu_pivot, dim3(1), dim3(1024), 0, s, p->d_A, p->ld, n, k, p->d_status);
+        SFFT_LAUNCH(lu_pivot, dim3(1), dim3(1024), 0, s, p->d_A, p->ld, n, k, p->d_status);
         const int rem = n - k - 1;
         if (rem > 0)
-            hipLaunchKernelGGL(lu_rank1, dim3((rem + 1 + 63) / 64, (rem + 15) / 16), dim3(256), 0, s, p->d_A, p->ld, n, k);
+            SFFT_LAUNCH(lu_rank1, dim3((rem + 1 + 63) / 64, (rem + 15) / 16), dim3(256), 0, s, p->d_A, p->ld, n, k);
     }
     LAUNCH_CHECK();
     const size_t lds = (size_t)(n + 2) * 8;
-    hipLaunchKernelGGL(lu_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_xv);
-    hipLaunchKernelGGL(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, p->NEQ);
-    hipLaunchKernelGGL(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
+    SFFT_LAUNCH(lu_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_xv);
+    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, p->NEQ);
+    SFFT_LAUNCH(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
                        p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -2146,7 +1986,7 @@ static int solve_attempt(sfft_plan* p, bool use_lu, double* d_solution, hipStrea
     int rc;
     {
         StageTimer t(p, SFFT_ST_FILL, s);
-        hipLaunchKernelGGL(set_i32, dim3(1), dim3(1), 0, s, p->d_status, 0);     // (a kernel like zero_f64, not a runtime memset)
+        SFFT_LAUNCH(set_i32, dim3(1), dim3(1), 0, s, p->d_status, 0);     // (a kernel like zero_f64, not a runtime memset)
         if ((rc = run_fill(p, s, !use_lu))) return rc;
     }
     {
@@ -2154,7 +1994,7 @@ static int solve_attempt(sfft_plan* p, bool use_lu, double* d_solution, hipStrea
         if (use_lu) { if ((rc = run_lu(p, p->d_sol, s))) return rc; }
         else { if ((rc = run_cholesky(p, p->d_sol, s))) return rc; }
     }
-    if (!use_lu && p->test_fail_chol) HIPCHK(hipMemsetAsync(p->d_status, 1, sizeof(int), s));      // test hook: pretend a pivot failed
+    if (!use_lu && p->test_fail_chol) SFFT_LAUNCH(set_i32, dim3(1), dim3(1), 0, s, p->d_status, 1);      // test hook: pretend a pivot failed
     HIPCHK(hipMemcpyAsync(p->h_status, p->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(d_solution, p->d_sol, (size_t)p->NEQ * sizeof(double), hipMemcpyDeviceToDevice, s));
     p->attempt_lu = use_lu;
@@ -2204,74 +2044,55 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
         if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS))) return rc;
-#define ROWMOM_J(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby)
+#define ROWMOM_J(NQT) SFFT_LAUNCH(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby)
         if (p->rowmom_fused) { /* written by rows_r2c_4096 */ }
         else if (p->nby == 1) ROWMOM_J(1); else if (p->nby == 2) ROWMOM_J(2); else if (p->nby == 3) ROWMOM_J(3); else if (p->nby == 4) ROWMOM_J(4);
 #undef ROWMOM_J
-        else hipLaunchKernelGGL(row_moments<SFFT_MAX_BQ>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
-        hipLaunchKernelGGL(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
+        else SFFT_LAUNCH(row_moments<SFFT_MAX_BQ>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby);
+        SFFT_LAUNCH(delta_finish, dim3(p->Fpq), dim3(256), 0, s, p->d_rowmom, p->d_delta, p->N0, p->bk, p->scale);
         LAUNCH_CHECK();
     }
     // The real-space Gamma block (two small kernels on the row moments) does not depend on the spectra: when the moments came out of
     // the row pass it runs on the plan's second stream, beside the Omega launch, and joins before the system is filled
-    const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !getenv("SFFT_NO_GAMMA_ASIDE");
+    const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !p->no_gamma_aside;
     if (gamma_aside) {
         const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
         HIPCHK(hipEventRecord(p->ev_mom, s));
         HIPCHK(hipStreamWaitEvent(p->s2, p->ev_mom, 0));
-        hipLaunchKernelGGL(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, p->s2, d_I, p->d_rowmomI, p->d_tby,
+        SFFT_LAUNCH(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, p->s2, d_I, p->d_rowmomI, p->d_tby,
                            p->gam_tab ? p->d_kby : (const double*)nullptr, nd, p->gam_db, p->w, p->N0, p->N1, p->d_gamR);
-        hipLaunchKernelGGL(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, p->s2, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, NQB,
+        SFFT_LAUNCH(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, p->s2, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, NQB,
                            p->N0, p->d_patches + p->fa.gam_off, p->scale * p->scale);
         LAUNCH_CHECK();
         HIPCHK(hipEventRecord(p->ev_gam, p->s2));
     }
-    // border sums of the derived Omega passes (two small real-space kernels on the masked image): beside the Omega launch when the plan
-    // has its second stream, else in line
-    if (p->omg_reduce) {
-        const bool aside = p->s2 && !p->no_overlap && s != nullptr;
-        hipStream_t ss = aside ? p->s2 : s;
-        const int PHo = 2 * p->omgr.h + 1;
-        if (aside && !gamma_aside) { HIPCHK(hipEventRecord(p->ev_mom, s)); HIPCHK(hipStreamWaitEvent(p->s2, p->ev_mom, 0)); }
-        hipLaunchKernelGGL(edge_cols, dim3((p->N0 + 255) / 256, 2 * p->omgr.h), dim3(256), 0, ss, d_I, p->d_edge, p->N0, p->N1, p->omgr.h);
-        if (p->DK == 2) hipLaunchKernelGGL(omega_strips<2>, dim3(PHo * PHo, 2 * p->omgr.h), dim3(256), 0, ss, d_I, p->d_edge, p->N0, p->N1, p->omgr.h, p->d_strip);
-        else hipLaunchKernelGGL(omega_strips<3>, dim3(PHo * PHo, 2 * p->omgr.h), dim3(256), 0, ss, d_I, p->d_edge, p->N0, p->N1, p->omgr.h, p->d_strip);
-        LAUNCH_CHECK();
-        if (aside) HIPCHK(hipEventRecord(p->ev_strip, p->s2));
-    }
-    bool theta_with_omega = false;
     {
         StageTimer t(p, SFFT_ST_GREEK_G1, s);
-        // With the Gamma block taken out of the spectra (gamma_analytic) the short passes are the Fij Theta passes alone; they read
-        // the same kernel planes as the Omega passes and can ride in the same matrix-core launch (their lags beyond w are
-        // computed and dropped) when SFFT_THETA_MFMA=1: one launch, the planes shared through L2, 0.24 ms of vector passes for 0.13 ms more here
-        theta_with_omega = p->theta_mfma && p->gamma_analytic && p->g1_mfma && 2 * p->w >= 9 && 2 * p->w <= 16 && p->n_dense_w == p->n_the &&
-                           p->n_omg_launch == p->n_omg;
-        if ((rc = greek_g1_group(p, 0, theta_with_omega ? p->n_omg + p->n_dense_w : p->n_omg_launch, 2 * p->w, s, true))) return rc;
+        if ((rc = greek_g1_group(p, 0, p->n_omg_launch, 2 * p->w, s, true))) return rc;
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
-        if (!theta_with_omega) {
+        {
             const int fused = ((p->theta_in_groups || p->theta_slots) && p->g1_mfma >= 3) ? p->n_the_fused : 0;      // (the rest: a vector launch of their own)
             if (fused < p->n_dense_w && (rc = greek_g1_group(p, p->n_omg + fused, p->n_dense_w - fused, p->w, s))) return rc;
         }
         if (p->gamma_analytic && !gamma_aside) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
-#define ROWMOM_I(NQT) hipLaunchKernelGGL(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
+#define ROWMOM_I(NQT) SFFT_LAUNCH(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
             if (!p->rowmom_fused)
             switch (nd) {           // exactly nd table values per column (a larger template bound re-reads clamped copies)
                 case 1: ROWMOM_I(1); break; case 2: ROWMOM_I(2); break; case 3: ROWMOM_I(3); break; case 4: ROWMOM_I(4); break;
                 case 5: ROWMOM_I(5); break; case 6: ROWMOM_I(6); break; case 7: ROWMOM_I(7); break; default: ROWMOM_I(SFFT_MAX_BQ); break;
             }
 #undef ROWMOM_I
-            hipLaunchKernelGGL(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, s, d_I, p->d_rowmomI, p->d_tby,
+            SFFT_LAUNCH(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, s, d_I, p->d_rowmomI, p->d_tby,
                                p->gam_tab ? p->d_kby : (const double*)nullptr, nd, p->gam_db, p->w, p->N0, p->N1, p->d_gamR);
-            hipLaunchKernelGGL(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, s, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, NQB,
+            SFFT_LAUNCH(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, s, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, NQB,
                                p->N0, p->d_patches + p->fa.gam_off, p->scale * p->scale);
             LAUNCH_CHECK();
         }
         if (p->n_row0 > 0) {
-            hipLaunchKernelGGL(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_row0), dim3(256), 0, s, p->d_spec, p->d_passes,
+            SFFT_LAUNCH(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_row0), dim3(256), 0, s, p->d_spec, p->d_passes,
                                p->n_omg + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->lay, p->S);
             LAUNCH_CHECK();
         }
@@ -2281,17 +2102,11 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         // one launch for all patch jobs: the grid is as tall as the widest patch (4 w + 1 rows), the workgroups past a narrower
         // job's 2 w + 1 rows return at once (two launches ran one after the other, each far from filling the chip)
         if (p->S <= 4)
-            hipLaunchKernelGGL(greek_g2<4>, dim3(4 * p->w + 1, (int)p->jobs.size()), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
+            SFFT_LAUNCH(greek_g2<4>, dim3(4 * p->w + 1, (int)p->jobs.size()), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
                                p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
         else
-            hipLaunchKernelGGL(greek_g2<8>, dim3(4 * p->w + 1, (int)p->jobs.size()), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
+            SFFT_LAUNCH(greek_g2<8>, dim3(4 * p->w + 1, (int)p->jobs.size()), dim3(256), 0, s, p->d_gp, p->d_passes, p->d_jobs, 0, p->d_patches,
                                p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
-        if (p->omg_reduce) {
-            if (p->s2 && !p->no_overlap && s != nullptr) HIPCHK(hipStreamWaitEvent(s, p->ev_strip, 0));
-            const int PHo = 2 * p->omgr.h + 1;
-            hipLaunchKernelGGL(omega_derive, dim3(PHo * PHo), dim3(64), 0, s, p->d_patches + p->fa.omg_off, p->d_strip, p->omgr,
-                               p->N0, p->N1, p->scale * p->scale * p->scale);
-        }
         LAUNCH_CHECK();
     }
     if (gamma_aside) HIPCHK(hipStreamWaitEvent(s, p->ev_gam, 0));
@@ -2305,6 +2120,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         HIPCHK(hipEventRecord(p->ev_pre, p->s2));
     }
     if ((rc = solve_attempt(p, p->force_lu != 0, d_solution, s))) return rc;
+    if (p->launch_error) return p->launch_error;
     if (defer_check) return SFFT_OK;
     HIPCHK(hipStreamSynchronize(s));
     return solve_check(p, d_solution, s, nullptr);
@@ -2337,7 +2153,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         // `FI` is then the stage buffer holding S_j = row-DFT(I cy^j), j = 0 .. DK, in its first DK + 1 planes
         StageTimer t(p, SFFT_ST_CONSTRUCT, s);
         const int LT = 2 * p->vw + 1;
-        hipLaunchKernelGGL(kernel_ctab_mixed, dim3((p->Nhp + 255) / 256, p->Fij * LT), dim3(256), 0, s, d_solution, p->d_ctabm, p->L, p->L, p->w,
+        SFFT_LAUNCH(kernel_ctab_mixed, dim3((p->Nhp + 255) / 256, p->Fij * LT), dim3(256), 0, s, d_solution, p->d_ctabm, p->L, p->L, p->w,
                            p->w, p->vw, p->Nh, p->Nhp, p->N1, p->ax1.root, (double)p->N0 * p->scale);
         if (p->vtensor) {
             // tensor basis: 8-column tiles, 8 streams per wave; stream length from the same cost model (workgroups per CU x steps per stream)
@@ -2359,7 +2175,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
             cplx* trash = p->d_ctabm + (size_t)p->Fij * LT * p->Nhp;
 #define VT_LAUNCH(NN, WT) do { \
             HIPCHK(hipFuncSetAttribute((const void*)vconv_tensor<NN, NN, WT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            hipLaunchKernelGGL((vconv_tensor<NN, NN, WT, CT>), gt, dim3(256), ldst, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, trash, Rt); } while (0)
+            SFFT_LAUNCH((vconv_tensor<NN, NN, WT, CT>), gt, dim3(256), ldst, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, trash, Rt); } while (0)
 #define VT_W(NN) do { if (p->vw == 4) VT_LAUNCH(NN, 4); else VT_LAUNCH(NN, 8); } while (0)
             switch (p->vtensor) { case 4: VT_W(4); break; case 5: VT_W(5); break; default: VT_W(6); break; }
 #undef VT_W
@@ -2370,7 +2186,7 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         int R = KS * LT - 2 * p->vw, Rrt = 0, ntile = (p->Nh + 15) / 16, m_direct = p->Nh;
         // the two-row walk (vconv_mixed2) for KerHW 9 .. 12 as well (two workgroups per CU there: 64 KB of weights for 10 terms x 25 taps):
         // config 5 construct 3.2 -> 1.8 ms; SFFT_VCONV2_W12=0 restores the one-row walk (vconv_mixed) for those widths
-        const int vw2max = (getenv("SFFT_VCONV2_W12") && atoi(getenv("SFFT_VCONV2_W12")) == 0) ? 8 : 12;
+        const int vw2max = p->vconv2_w12 ? 12 : 8;
         if (p->vconv_rp == 2 && p->vw <= vw2max && p->vconv_r != 0) {
             // the walk is fp64-VALU bound and a workgroup puts one wave on each SIMD of its CU, so the launch takes
             // (workgroups per CU, rounded up) x (steps per stream): pick the stream length that minimises it.  A last tile of one or
@@ -2395,32 +2211,14 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         dim3 g(ntile, (nstreams + 15) / 16);
         const size_t lds = (size_t)p->Fij * LT * 16 * sizeof(cplx);
 #define VCONV_LAUNCH(DKT, WT) do { \
-        if (p->vconv_rp == 3 && WT <= 8 && ((DKT + 1) * (DKT + 2) / 2) * ((2 * WT + 3) / 3) <= 40) { \
-        /* register-stationary taps: R output rows per wave, chosen so that the launch is a whole number of resident rounds */ \
-        int R3 = p->vconv3_r; \
-        const int ctiles = (p->Nh + 19) / 20; \
-        if (R3 <= 0) { \
-            const int slots = 2 * p->num_cu;                     /* workgroups resident at 2 waves per SIMD */ \
-            int best = 0; double bestc = 1e30; \
-            for (int cand = 48; cand <= 512; ++cand) { \
-                const int wgs = ctiles * ((((p->N0 + cand - 1) / cand) + 3) / 4); \
-                const int rounds = (wgs + slots - 1) / slots; \
-                const double cost = (double)rounds * (cand + (2 * WT + 3) / 3 - 1 + 12); \
-                if (cost < bestc) { bestc = cost; best = cand; } \
-            } \
-            R3 = best; \
-        } \
-        dim3 g3(ctiles, ((p->N0 + R3 - 1) / R3 + 3) / 4); \
-        hipLaunchKernelGGL((vconv_mixed3<(DKT <= 2 || WT <= 4 ? DKT : 2), (WT <= 8 ? WT : 8)>), g3, dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
-                           p->Nhp, p->lay, R3); } else \
         if (p->vconv_rp >= 2 && WT <= vw2max) { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed2<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        if (m_direct < p->Nh && p->vconv_direct_launch) hipLaunchKernelGGL((vconv_direct<DKT, WT>), dim3((p->N0 + 255) / 256, p->Nh - m_direct), \
+        if (m_direct < p->Nh && p->vconv_direct_launch) SFFT_LAUNCH((vconv_direct<DKT, WT>), dim3((p->N0 + 255) / 256, p->Nh - m_direct), \
                                                  dim3(256), 0, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, m_direct); \
-        hipLaunchKernelGGL((vconv_mixed2<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
+        SFFT_LAUNCH((vconv_mixed2<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
                            p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp, Rrt, p->vconv_direct_launch ? p->Nh : m_direct); } else { \
         HIPCHK(hipFuncSetAttribute((const void*)vconv_mixed<DKT, WT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((vconv_mixed<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
+        SFFT_LAUNCH((vconv_mixed<DKT, WT, KS>), g, dim3(256), lds, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, \
                            p->Nhp, p->lay, p->d_ctabm + (size_t)p->Fij * LT * p->Nhp); } } while (0)
 #define VCONV_DK(WT) switch (p->DK) { case 0: VCONV_LAUNCH(0, WT); break; case 1: VCONV_LAUNCH(1, WT); break; case 2: VCONV_LAUNCH(2, WT); break; default: VCONV_LAUNCH(3, WT); }
         if (p->vw == 4) { VCONV_DK(4) } else if (p->vw == 8) { VCONV_DK(8) } else { VCONV_DK(12) }
@@ -2430,11 +2228,11 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         }
     } else {
         StageTimer t(p, SFFT_ST_CONSTRUCT, s);
-        hipLaunchKernelGGL(kernel_rtab, dim3((p->N0 + 255) / 256, p->w + 1, p->Fij), dim3(256), 0, s, d_solution, p->d_rtab, p->Fij,
+        SFFT_LAUNCH(kernel_rtab, dim3((p->N0 + 255) / 256, p->w + 1, p->Fij), dim3(256), 0, s, d_solution, p->d_rtab, p->Fij,
                            p->L, p->L, p->w, p->w, p->N0, 1 + 2 * p->wpad, p->ax0.root, p->mode == 3 ? 1 : 0);
         const int rpw = 32;             // rows per wave: 33 x 128 waves at 4096^2; fewer, longer waves measured slower
         dim3 g((p->Nh + 63) / 64, (p->N0 + rpw - 1) / rpw);
-#define CONSTRUCT_LAUNCH(W, U, G) hipLaunchKernelGGL((construct_fd<W, U, G>), g, dim3(64), 0, s, FI, FD, p->d_rtab, p->ax1.root, \
+#define CONSTRUCT_LAUNCH(W, U, G) SFFT_LAUNCH((construct_fd<W, U, G>), g, dim3(64), 0, s, FI, FD, p->d_rtab, p->ax1.root, \
                                                      p->N0, p->N1, p->Nh, p->Nhp, p->lay, p->Fij, rpw, p->scale)
         switch (p->wpad) {
             case 4: CONSTRUCT_LAUNCH(4, 2, 3); break;
@@ -2452,39 +2250,39 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
         if (!p->use_vconv) launch_cols(p, FD, 1, 1, s);         // (the mixed-domain kernel already left the column-inverse in FD)
         if (p->ax1.big) {
             const int npr = (p->N0 + 1) / 2;
-            hipLaunchKernelGGL(retangle_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, FD, p->d_big1, p->N0, p->N1, p->Nh, p->Nhp);
+            SFFT_LAUNCH(retangle_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, FD, p->d_big1, p->N0, p->N1, p->Nh, p->Nhp);
             big_axis_transform(p, p->ax1, p->d_big1, p->d_big2, 1, p->N1, npr, false, 0, s);
-            hipLaunchKernelGGL(finish_diff, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, p->d_big1, d_J, d_solution + p->Fijab, p->bk,
+            SFFT_LAUNCH(finish_diff, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, p->d_big1, d_J, d_solution + p->Fijab, p->bk,
                                d_diff, p->N0, p->N1);
         } else if (fast_axis(p->ax1) && !p->no_fast_fft)
         {
             if (p->nby <= 4)
-                hipLaunchKernelGGL(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
+                SFFT_LAUNCH(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
             else
-                hipLaunchKernelGGL(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
+                SFFT_LAUNCH(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
         }
-        else if (p->rows_r24 && p->nby <= 4 && getenv("SFFT_INV_R24") && atoi(getenv("SFFT_INV_R24")) == 1) {
+        else if (p->rows_r24 && p->nby <= 4 && p->inv_r24 == 1) {
             // 6144- / 9216-point rows: the register-resident inverse pass (fft_r24.hpp), OFF by default.  Alone it is faster (config 3
             // inverse 0.48 -> 0.29 ms, config 5 1.15 -> 1.00 ms) but with two pairs in flight the configs lose throughput (config 3: 44.0 ->
             // 43.3 pairs/s, config 5: 34.4 -> 33.9): its 246 registers x 384 threads fill a CU's register file, where the generic pass
             // (168 registers, one workgroup per CU) leaves room for the other pair's Omega waves.  Latency switch: SFFT_INV_R24=1.
             if (p->rows_r24 == 16)
-                hipLaunchKernelGGL((rows_c2r_diff_r24<16, 4>), dim3((p->N0 + 1) / 2), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, FD, d_J,
+                SFFT_LAUNCH((rows_c2r_diff_r24<16, 4>), dim3((p->N0 + 1) / 2), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
             else
-                hipLaunchKernelGGL((rows_c2r_diff_r24<24, 4>), dim3((p->N0 + 1) / 2), dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s, FD, d_J,
+                SFFT_LAUNCH((rows_c2r_diff_r24<24, 4>), dim3((p->N0 + 1) / 2), dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
         }
         else if (p->nby <= 4)
-            hipLaunchKernelGGL(rows_c2r_diff<4>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
+            SFFT_LAUNCH(rows_c2r_diff<4>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
                                d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, p->lay, axis_dev(p->ax1));
         else
-            hipLaunchKernelGGL(rows_c2r_diff<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
+            SFFT_LAUNCH(rows_c2r_diff<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, d_J,
                                d_solution + p->Fijab, p->bk, d_diff, p->N0, p->N1, p->Nh, p->Nhp, p->lay, axis_dev(p->ax1));
         if (p->mode == 3)
-            hipLaunchKernelGGL(scaling_term, dim3((p->N1 + 255) / 256, p->N0), dim3(256), 0, s, d_I, d_solution, p->sa, d_diff,
+            SFFT_LAUNCH(scaling_term, dim3((p->N1 + 255) / 256, p->N0), dim3(256), 0, s, d_I, d_solution, p->sa, d_diff,
                                p->N0, p->N1, p->scale);
         LAUNCH_CHECK();
     }
@@ -2499,7 +2297,8 @@ extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, co
     ON_DEVICE(p->dev);
     int rc;
     if ((rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
-    return apply_finish(p, p->use_vconv ? p->d_stage_a : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s);
+    if ((rc = apply_finish(p, p->use_vconv ? p->d_stage_a : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
+    return p->launch_error;
 }
 
 // GSS: the forward transforms of the full pair do not depend on the solution, and the dense solve leaves most
@@ -2563,7 +2362,7 @@ extern "C" int sfft_get_system(sfft_plan* p, double* d_LHMAT, double* d_RHb, voi
     hipStream_t s = (hipStream_t)stream;
     ON_DEVICE(p->dev);
     dim3 g((p->NEQ + 15) / 16, (p->NEQ + 15) / 16);
-    hipLaunchKernelGGL(fill_plain, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->NEQ, d_LHMAT, d_RHb);
+    SFFT_LAUNCH(fill_plain, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->NEQ, d_LHMAT, d_RHb);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;
@@ -2584,9 +2383,9 @@ extern "C" int sfft_get_solver_system(sfft_plan* p, double* d_bordered, int* d_i
     const int n = p->NEQfs;
     dim3 g((n + 1 + 15) / 16, (n + 1 + 15) / 16);
     // the launch of run_fill with the caller's buffer (leading dimension n + 1) in place of the solver's workspace, both triangles
-    hipLaunchKernelGGL(fill_system, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->d_idx, n, p->NEQ,
+    SFFT_LAUNCH(fill_system, g, dim3(256), 0, s, p->d_patches, p->d_phi, p->d_delta, p->fa, p->d_idx, n, p->NEQ,
                        d_bordered, n + 1, (double*)nullptr, 0);
-    if (d_index) hipLaunchKernelGGL(iota_or_copy, dim3((n + 255) / 256), dim3(256), 0, s, p->d_idx, n, d_index);
+    if (d_index) SFFT_LAUNCH(iota_or_copy, dim3((n + 255) / 256), dim3(256), 0, s, p->d_idx, n, d_index);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;
@@ -2609,7 +2408,7 @@ extern "C" int sfft_fft2_r2c(sfft_plan* p, const double* d_real, double* d_spec,
     ra.src[0] = d_real;
     int rc = forward_planes(p, ra, 1, p->d_spec, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec, p->N0, p->Nh,
+    SFFT_LAUNCH(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec, p->N0, p->Nh,
                        p->lay, rowmajor_layout(p->Nh), scale / p->scale);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -2625,30 +2424,30 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
     int rc;
     if (!p->d_zero) {
         if ((rc = dev_alloc(p, &p->d_zero, (size_t)p->N0 * p->N1))) return rc;
-        HIPCHK(hipMemsetAsync(p->d_zero, 0, (size_t)p->N0 * p->N1 * sizeof(double), s));
+        SFFT_LAUNCH(zero_f64, dim3((p->N0 * p->N1 + 255) / 256), dim3(256), 0, s, p->d_zero, p->N0 * p->N1);
         if ((rc = dev_alloc(p, &p->d_zsol, (size_t)p->NEQ))) return rc;
-        HIPCHK(hipMemsetAsync(p->d_zsol, 0, (size_t)p->NEQ * sizeof(double), s));
+        SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, p->d_zsol, p->NEQ);
     }
     cplx* FD = p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp;
-    hipLaunchKernelGGL(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, (const cplx*)d_spec, FD, p->N0, p->Nh,
+    SFFT_LAUNCH(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, (const cplx*)d_spec, FD, p->N0, p->Nh,
                        rowmajor_layout(p->Nh), p->lay, 1.0);
     LAUNCH_CHECK();
     // reuse the inverse path of the subtraction: with J = 0 and b = 0 it returns -IDFT2(FD)
     launch_cols(p, FD, 1, 1, s);
     if (p->ax1.big) {
         const int npr = (p->N0 + 1) / 2;
-        hipLaunchKernelGGL(retangle_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, FD, p->d_big1, p->N0, p->N1, p->Nh, p->Nhp);
+        SFFT_LAUNCH(retangle_rows, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, FD, p->d_big1, p->N0, p->N1, p->Nh, p->Nhp);
         big_axis_transform(p, p->ax1, p->d_big1, p->d_big2, 1, p->N1, npr, false, 0, s);
-        hipLaunchKernelGGL(finish_diff, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, p->d_big1, p->d_zero, p->d_zsol + p->Fijab, p->bk,
+        SFFT_LAUNCH(finish_diff, dim3((p->N1 + 255) / 256, npr), dim3(256), 0, s, p->d_big1, p->d_zero, p->d_zsol + p->Fijab, p->bk,
                            d_real, p->N0, p->N1);
     } else if (fast_axis(p->ax1) && !p->no_fast_fft)
-        hipLaunchKernelGGL(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, p->d_zero,
+        SFFT_LAUNCH(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, p->d_zero,
                            p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->lay, p->ax1.tw);
     else
-        hipLaunchKernelGGL(rows_c2r_diff<4>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, p->d_zero,
+        SFFT_LAUNCH(rows_c2r_diff<4>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, p->d_zero,
                            p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->N1, p->Nh, p->Nhp, p->lay, axis_dev(p->ax1));
     const size_t n = (size_t)p->N0 * p->N1;
-    hipLaunchKernelGGL(scale_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_real, -scale, n);
+    SFFT_LAUNCH(scale_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_real, -scale, n);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -2658,7 +2457,7 @@ extern "C" int sfft_spec_abs2_accumulate(const double* d_a, const double* d_b, d
 {
     if (!d_a || !d_acc || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
     ON_DEVICE(stream_device((hipStream_t)stream));
-    hipLaunchKernelGGL(spec_abs2_acc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a, (const cplx*)d_b,
+    SFFT_LAUNCH(spec_abs2_acc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a, (const cplx*)d_b,
                        coeff, d_acc, (size_t)n);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -2669,7 +2468,7 @@ extern "C" int sfft_real_rsqrt(const double* d_acc, double* d_out, long long n, 
 {
     if (!d_acc || !d_out || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
     ON_DEVICE(stream_device((hipStream_t)stream));
-    hipLaunchKernelGGL(real_rsqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_acc, d_out, (size_t)n);
+    SFFT_LAUNCH(real_rsqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_acc, d_out, (size_t)n);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -2679,7 +2478,7 @@ extern "C" int sfft_spec_multiply(const double* d_a, const double* d_b, int b_is
 {
     if (!d_a || !d_b || !d_out || n < 0) return set_err(SFFT_ERR_INVALID_ARG, "bad argument");
     ON_DEVICE(stream_device((hipStream_t)stream));
-    hipLaunchKernelGGL(spec_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a,
+    SFFT_LAUNCH(spec_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cplx*)d_a,
                        b_is_real ? (const cplx*)nullptr : (const cplx*)d_b, b_is_real ? d_b : (const double*)nullptr, (cplx*)d_out, (size_t)n);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -2690,7 +2489,7 @@ extern "C" int sfft_half_to_full_real(const double* d_half, double* d_full, int 
 {
     if (!d_half || !d_full) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
     ON_DEVICE(stream_device((hipStream_t)stream));
-    hipLaunchKernelGGL(half_to_full_real, dim3((N1 + 255) / 256, N0), dim3(256), 0, (hipStream_t)stream, d_half, d_full, N0, N1, N1 / 2 + 1);
+    SFFT_LAUNCH(half_to_full_real, dim3((N1 + 255) / 256, N0), dim3(256), 0, (hipStream_t)stream, d_half, d_full, N0, N1, N1 / 2 + 1);
     LAUNCH_CHECK();
     return SFFT_OK;
 }
@@ -2710,7 +2509,7 @@ extern "C" int sfft_grid_convolve(const double* d_in, const int* d_labels, const
     const size_t lds = (size_t)(16 + A - 1) * row_bytes;
     ON_DEVICE(device);
     HIPCHK(hipFuncSetAttribute((const void*)grid_convolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(grid_convolve, dim3((N1 + 15) / 16, (N0 + 15) / 16), dim3(256), lds, (hipStream_t)stream, d_in, d_labels, d_kerstack,
+    SFFT_LAUNCH(grid_convolve, dim3((N1 + 15) / 16, (N0 + 15) / 16), dim3(256), lds, (hipStream_t)stream, d_in, d_labels, d_kerstack,
                        N0, N1, Nseg, L0, L1, (int)A, d_out);
     LAUNCH_CHECK();
     return SFFT_OK;
@@ -2727,7 +2526,7 @@ extern "C" int sfft_dbg_forward_spectrum(sfft_plan* p, const double* d_I, int i,
     ra.src[0] = d_I; ra.wx[0] = p->d_kbx + (size_t)i * p->N0; ra.wy[0] = p->d_kby + (size_t)j * p->N1;
     int rc = forward_planes(p, ra, 1, p->d_spec, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(copy_spectrum, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec_out, p->N0, p->Nh, p->lay);
+    SFFT_LAUNCH(copy_spectrum, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, p->d_spec, (cplx*)d_spec_out, p->N0, p->Nh, p->lay);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(s));
     return SFFT_OK;

@@ -29,31 +29,12 @@ __global__ void __launch_bounds__(256) chol_copy_diag(const double* __restrict__
 
 typedef double d4s __attribute__((ext_vector_type(4)));
 
-// A 16 x 16 x 4 fp64 tile product, optionally (-DSFFT_CHOL_M4=1) as FOUR v_mfma_f64_4x4x4_4b_f64: the 16 x 16 x 4 instruction occupies the
-// matrix pipe for ~93 cycles, the four 4 x 4 x 4 ones for ~60 (profiles/r02_mfma_f64_peak.txt: 47 vs 74 TFLOP/s sustained).  Same B
-// operand (lane 16 k + n holds B[k][n]) and the same accumulator layout (component bi of lane 16 i + n holds C[4 bi + i][n]);
-// instruction bi wants A[4 bi + (lane & 3)][k] in lane 16 k + 4 blk + (lane & 3), i.e. the 16 x 16 x 4 form's A operand gathered from
-// lane 16 k + 4 bi + (lane & 3): one ds_swizzle per half of the double.  MEASURED SLOWER in these latency chains (one wave per SIMD:
-// update of the next diagonal tile, triangular solves, rank-4 updates of the diagonal factorisation): solve 0.975 - 0.99 ms against
-// 0.88 - 0.93 at n = 1735, 7.89 against 7.70 ms at n = 7207 -- eight swizzles and four instructions per product cost a lone wave more
-// issue time than the shorter pipe occupancy gives back.  Default 0.  (chol_syrk has its own 4 x 4 x 4 form, template M4, also off.)
-#ifndef SFFT_CHOL_M4
-#define SFFT_CHOL_M4 0
-#endif
+// A 16 x 16 x 4 fp64 tile product.  (The same product as four v_mfma_f64_4x4x4_4b_f64 with swizzled A operands was measured slower
+// in these latency chains -- 0.98 vs 0.90 ms at n = 1735, 7.89 vs 7.70 ms at n = 7207: a lone wave pays more for the eight swizzles
+// and four instructions than the shorter pipe occupancy gives back; docs/LOG.md.)
 __device__ __forceinline__ d4s mfma16(double av, double bv, d4s acc)
 {
-#if SFFT_CHOL_M4
-#define SFFT_SWZ4(G) __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(av), 0x13 | ((4 * (G)) << 5)), \
-                                      __builtin_amdgcn_ds_swizzle(__double2loint(av), 0x13 | ((4 * (G)) << 5)))
-    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(0), bv, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(1), bv, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(2), bv, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(SFFT_SWZ4(3), bv, acc[3], 0, 0, 0);
-#undef SFFT_SWZ4
-    return acc;
-#else
     return __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-#endif
 }
 
 // 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no IEEE division / sqrt sequences on the
@@ -1148,13 +1129,7 @@ __global__ void __launch_bounds__(256) chol_panel4(double* __restrict__ A, int l
 #define SYRK_T 128
 #define SYRK_KC 16
 #define SYRK_S (SYRK_KC + 4)
-// tj0: first tile column of this launch (the look-ahead splits the update into the next panel's two tile columns and the rest)
-// M4 = true: the products run on v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction; a loop of nothing else
-// sustains 74 TFLOP/s against 47 for the 16 x 16 x 4 form, profiles/r02_mfma_f64_peak.txt).  A 16 x 16 x 4 tile product is four of
-// them: instruction bi takes A rows 4 bi .. 4 bi + 3 (the same in all four blocks: lane 16 k + 4 blk + i holds A[4 bi + i][k]) and
-// the B operand of the 16 x 16 x 4 form unchanged (lane 16 k + n holds B[k][n], block blk = columns 4 blk .. 4 blk + 3); lane
-// 16 i + n of the result holds C[4 bi + i][n].  Same accumulator count, 20 instead of 8 LDS reads per 64 k-products.
-template <bool M4>
+// tj0: first tile column of this launch
 __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int ld, int n, int K0, int KB, int r0, int tj0)
 {
     const int ti = blockIdx.y, tj = blockIdx.x + tj0;
@@ -1200,21 +1175,10 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
                 a[t] = Li[64 * wr + 16 * t + ln][4 * ks + lk];
                 b[t] = Lj[64 * wc + 16 * t + ln][4 * ks + lk];
             }
-            if constexpr (M4) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-#pragma unroll
-                    for (int bi = 0; bi < 4; ++bi) {
-                        const double a4 = Li[64 * wr + 16 * it + 4 * bi + (lane & 3)][4 * ks + lk];
-#pragma unroll
-                        for (int jt = 0; jt < 4; ++jt) c[it][jt][bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, b[jt], c[it][jt][bi], 0, 0, 0);
-                    }
-            } else {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) c[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], c[it][jt], 0, 0, 0);
-            }
         }
     }
     // read-modify-write of the tile, 16 elements at a time: all 16 loads first (written as `A[..] -= c` the compiler orders
@@ -1226,14 +1190,14 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + 64 * wr + 16 * it + (M4 ? 4 * q + lk : lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
+                const int i = i0 + 64 * wr + 16 * it + (lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
                 oldv[jt][q] = (i <= n && j < n && j <= i) ? A[(size_t)i * ld + j] : 0.0;
             }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + 64 * wr + 16 * it + (M4 ? 4 * q + lk : lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
+                const int i = i0 + 64 * wr + 16 * it + (lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
                 if (i <= n && j < n && j <= i) A[(size_t)i * ld + j] = oldv[jt][q] - c[it][jt][q];
             }
     }

@@ -160,6 +160,16 @@ class Plan:
             out[name] = float(v.value)
         return out
 
+    @_locked
+    def stage_kernels(self):
+        """{stage: [kernel names]} -- the HIP kernels each stage has launched since set_timing(True) (sfft_stage_kernels)."""
+        out = {}
+        buf = ctypes.create_string_buffer(4096)
+        for k, name in enumerate(_lib.STAGES):
+            _lib.check(_lib.lib().sfft_stage_kernels(self._h, k, buf, len(buf)))
+            out[name] = [n for n in buf.value.decode().split(";") if n]
+        return out
+
     def close(self):
         with self.lock:
             if self._h:

@@ -1121,7 +1121,7 @@ def test_mixed_domain_apply_variants_agree(dev, shape, w, DK):
     """The mixed-domain apply kernels against each other and against the Fourier-domain apply, on shapes whose last 16-column
     tile holds 2 / 0 / 1 / 2 / 2 / 1 / 1 columns (1 or 2: taken point by point, inside the main launch or by vconv_direct): the default (vconv_mixed2 with the stream
     length balanced against the CU count), the round-1 stream length, one source row per table read (vconv_mixed), the
-    register-stationary taps (vconv_mixed3; order 3 at KerHW 8 falls back to vconv_mixed2) and construct_fd."""
+    Fourier-domain apply (construct_fd)."""
     from sfft_amd.plan import Plan
     from sfft_amd.utils.synthetic import make_pair
     pair = make_pair(*shape, seed=11 + w, mask=True)
@@ -1129,7 +1129,7 @@ def test_mixed_domain_apply_variants_agree(dev, shape, w, DK):
     rng = np.random.default_rng(9)
     outs = {}
     for name, env in [("default", {}), ("r1_len", {"SFFT_VCONV_R": "0"}), ("one_row", {"SFFT_VCONV_RP": "1"}),
-                      ("stationary", {"SFFT_VCONV_RP": "3"}), ("short", {"SFFT_VCONV_R": "17"}), ("own_launch", {"SFFT_VCONV_DIRECT": "1"}), ("fourier", {"SFFT_NO_VCONV": "1"})]:
+                      ("short", {"SFFT_VCONV_R": "17"}), ("own_launch", {"SFFT_VCONV_DIRECT": "1"}), ("fourier", {"SFFT_NO_VCONV": "1"})]:
         for k, v in env.items():
             os.environ[k] = v
         try:
@@ -1247,44 +1247,16 @@ def test_r24_axis_kernels_agree_with_generic_passes(dev, shape):
     assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
 
 
-@pytest.mark.parametrize("shape,w,DK", [((320, 288), 8, 2), ((4096, 4096), 8, 2), ((512, 384), 5, 3)])
-def test_derived_omega_patches_equal_transformed_ones(dev, shape, w, DK):
-    """SFFT_OMG_REDUCE=1 (off by default: no net gain measured): Omega products I_a conj(I_b) whose polynomial degrees add up to
-    the same total are shifted moments of each other, so one per class is transformed and the others come from the interior
-    moments plus exact border sums (omega_strips / omega_derive).  Same linear system to rounding."""
-    from sfft_amd.plan import Plan
-    from sfft_amd.utils.synthetic import make_pair
-    pair = make_pair(*shape, seed=77 + w, mask=True)
-    os.environ["SFFT_OMG_REDUCE"] = "1"
-    try:
-        probe = Plan(shape[0], shape[1], w, DK, 1, True, device=dev.index)
-    finally:
-        os.environ.pop("SFFT_OMG_REDUCE", None)
-    Fij = (DK + 1) * (DK + 2) // 2
-    n_tr = probe.query("OMG_OFFDIAG") + probe.query("OMG_DIAG")
-    probe.close()
-    assert n_tr == (15 if DK == 2 else 28) and n_tr < Fij * (Fij + 1) // 2     # one product per pair of total degrees (i + i', j + j')
-    full = _subtract_with_env(dev, {}, shape, w, DK, 1, pair)
-    red = _subtract_with_env(dev, {"SFFT_OMG_REDUCE": "1"}, shape, w, DK, 1, pair)
-    assert np.max(np.abs(red[2] - full[2])) <= 1e-11 * np.max(np.abs(full[2]))
-    assert np.array_equal(red[3], full[3])
-    assert rms(red[1] - full[1]) <= 1e-7 * rms(full[1])
-
-
 @pytest.mark.parametrize("shape,w,DK", [((256, 288), 8, 2), ((320, 4096), 8, 2), ((512, 384), 5, 3), ((384, 96), 12, 3)])
 def test_omega_launch_variants_agree(dev, shape, w, DK):
-    """The Omega + Theta launch in its off-by-default forms against the default (one wave per pass group, four equal row chunks):
-    SFFT_G1_WG=1 (greek_g1_mfma4w: workgroups of eight waves share a block's planes through LDS, the last spectrum column through
-    greek_g1_lastcol when it would be a tile of its own -- N1 = 288 and 4096 here -- and the persistent form when a tile has more
-    than one block -- order 3), SFFT_G1_RPC (uneven row chunks), SFFT_G1_QUAD (four-wave workgroups, one per CU) -- all measured slower or
-    no faster -- and SFFT_THETA_SLOTS=0 (KerHW 9 .. 16: the Theta passes in a launch of their own instead of slots
-    of the first Omega launch; the KerHW 12 case here) and SFFT_VCONV2_W12=0 (KerHW 9 .. 12: the one-row tap walk of the apply pass).
-    Same system, same difference image."""
+    """Regression guard for the two remaining switches of the Omega + Theta launch and the apply pass (self-comparisons, not parity
+    evidence): SFFT_G1_S=2 (two row chunks), SFFT_THETA_SLOTS=0 (KerHW 9 .. 16: the Theta passes in a launch of their own instead of
+    slots of the first Omega launch; the KerHW 12 case here) and SFFT_VCONV2_W12=0 (KerHW 9 .. 12: the one-row tap walk of the apply
+    pass).  Same system, same difference image."""
     from sfft_amd.utils.synthetic import make_pair
     pair = make_pair(*shape, seed=5 + w, mask=True, density=400.0)
     ref = _subtract_with_env(dev, {}, shape, w, DK, 1, pair)
-    for env in ({"SFFT_G1_WG": "1"}, {"SFFT_G1_RPC": "%d" % (16 * max(1, (3 * shape[0] // 8) // 16))}, {"SFFT_G1_WG": "1", "SFFT_G1_S": "2"},
-                {"SFFT_G1_QUAD": "1"}, {"SFFT_THETA_SLOTS": "0"}, {"SFFT_VCONV2_W12": "0"}):
+    for env in ({"SFFT_G1_S": "2"}, {"SFFT_THETA_SLOTS": "0"}, {"SFFT_VCONV2_W12": "0"}):
         alt = _subtract_with_env(dev, env, shape, w, DK, 1, pair)
         assert np.max(np.abs(alt[2] - ref[2])) <= 1e-11 * np.max(np.abs(ref[2])), env
         assert np.max(np.abs(alt[3] - ref[3])) <= 1e-11 * np.max(np.abs(ref[3])), env
@@ -1411,3 +1383,41 @@ def test_pccp_accepts_host_tensors_with_nans(dev):
                                                 KerPolyOrder=m["DK"], BGPolyOrder=m["DB"], ConstPhotRatio=bool(m["CPR"]),
                                                 CUDA_DEVICE_4SUBTRACT=str(dev.index), VERBOSE_LEVEL=0)
     assert diff.is_cuda and rel_rms_err(diff.cpu().numpy(), g["DIFF"]) <= 1e-6
+
+
+def test_removed_unknowns_stay_zero_under_concurrent_graph_replays(dev):
+    """Regression guard for a runtime fault found in round 3: with the Solution zeroed by a memset NODE of the captured solver graph,
+    several plans replaying their graphs from different host threads now and then left the removed unknowns ij00[1:] (which
+    Extend_Solution leaves at exactly 0, sfft/sfftcore/SFFTConfigure.py:716-732) holding stale bytes.  They are zeroed by a kernel node
+    now; this test runs four plans / streams / threads over NaN-prefilled outputs and asserts exact zeros every time."""
+    import threading
+    from sfft_amd.plan import Plan
+    from sfft_amd.utils.synthetic import make_pair
+    N0 = N1 = 1024
+    w, S, REPS = 4, 4, 12
+    pair = make_pair(N0, N1, seed=3, mask=True)
+    g = {k: _to(dev, v) for k, v in pair.items()}
+    plans = [Plan(N0, N1, w, 2, 2, True, device=dev.index) for _ in range(S)]
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    NEQ, Fab = plans[0].NEQ, (2 * w + 1) ** 2
+    forb = [ij * Fab + w * (2 * w + 1) + w for ij in range(1, 6)]
+    bad, sols = [0] * S, [None] * S
+
+    def worker(wi):
+        torch.cuda.set_device(dev.index)
+        with torch.cuda.stream(streams[wi]):
+            for _ in range(REPS):
+                sol = torch.full((NEQ,), float("nan"), dtype=torch.float64, device=dev)
+                diff = torch.empty((N0, N1), dtype=torch.float64, device=dev)
+                plans[wi].subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"], out_solution=sol, out_diff=diff)
+                v = sol.cpu().numpy()
+                if not np.all(v[forb] == 0.0) or not np.isfinite(v).all():
+                    bad[wi] += 1
+                sols[wi] = v
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for pl in plans:
+        pl.close()
+    assert bad == [0] * S, bad
+    assert all(np.array_equal(sols[0], v) for v in sols[1:])          # every plan, every thread: the same bits
