@@ -67,8 +67,8 @@ __global__ void chol_begin(unsigned int* epoch_ctr, unsigned int* queue, unsigne
 struct PanelLds {
     double Dl[CB][CB + 1];     // factor of the diagonal block
     double rdiag[CB];          // 1 / L[j][j]
-    double Rw[CB][4];          // raw column block published in step 1
-    double Fw[CB][4];          // final column block published in step 3
+    double Rw[2][CB][4];       // raw column block of a round (ping-pong: round jq writes the block of round jq + 1)
+    double Fw[2][CB][4];       // final column block of a round (ping-pong: read by the NEXT round's deferred trailing update)
 };
 
 // Factor the CB x CB diagonal block held as a[q] = D[i][cg + 4 q] by thread (i = tid >> 2, cg = tid & 3) (identity padding
@@ -84,24 +84,58 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
                                                  double (*Vd)[4] = nullptr)
 {
     const int i = MF ? 16 * (tid >> 6) + (tid & 15) : tid >> 2, cg = MF ? (tid >> 4) & 3 : tid & 3;
-    double (&Rw)[CB][4] = L.Rw;
-    double (&Fw)[CB][4] = L.Fw;
     double (&rdiag)[CB] = L.rdiag;
-    // Four columns per step (16 steps, two barriers each).  Step jq eliminates columns 4 jq .. 4 jq + 3:
-    //   1. every thread publishes its raw element of that column block (the quad of a row holds the four of them);
-    //   2. all threads factor the 4x4 pivot block T redundantly (four reciprocal square roots in sequence);
-    //   3. thread (i, cg) forward-substitutes its row through T up to column cg -> final L[i][4 jq + cg], published;
-    //   4. rank-4 update of the columns to the right from the published finals.
+    // Four columns per round, 16 rounds, ONE barrier per round (round 4: was two -- publish raw / barrier / factor / publish final /
+    // barrier / update, 13 us of every 28 us block step of chol_dataflow).  Round jq eliminates columns 4 jq .. 4 jq + 3:
+    //   barrier: the raw column block jq of every row (and the final block jq - 1) is visible;
+    //   a. deferred trailing update: the finals of round jq - 1 go into the columns right of block jq (off the critical path:
+    //      block jq itself received them through the look-ahead of round jq - 1);
+    //   b. all threads factor the 4 x 4 pivot block T redundantly (four reciprocal square roots in sequence);
+    //   c. thread (i, cg) forward-substitutes its own row through T -> finals L[i][4 jq .. 4 jq + 3] -- and, redundantly, the row
+    //      4 (jq + 1) + cg of the NEXT pivot block, which is what its column cg + 4 (jq + 1) needs from this round;
+    //   d. look-ahead: its element of column block jq + 1 receives this round's rank-4 update at once and is published as the raw
+    //      block of round jq + 1 (ping-pong buffers); the final L[i][4 jq + cg] is published for the next round's step a.
+    double pl = 0.0;                                     // own final of the previous round (MF: B operand of the deferred update)
+    double pf0 = 0.0, pf1 = 0.0, pf2 = 0.0, pf3 = 0.0;   // own finals of the previous round, all four columns (vector form of the deferred update)
+    L.Rw[0][i][cg] = a[0];
 #pragma unroll
     for (int jq = 0; jq < 16; ++jq) {
-        Rw[i][cg] = a[jq];
+        double (&Rw)[CB][4] = L.Rw[jq & 1];
+        double (&Fw)[CB][4] = L.Fw[jq & 1];
         __syncthreads();
         const int j0 = 4 * jq;
+        // a. deferred update with the finals of round jq - 1 (buffer (jq - 1) & 1), columns right of block jq
+        if (jq >= 1 && jq < 15) {
+            double (&Fp)[CB][4] = L.Fw[(jq - 1) & 1];
+            if (MF) {
+                const int wvm = tid >> 6, l15 = tid & 15;
+#pragma unroll
+                for (int t = (jq + 1) / 4; t < 4; ++t) {
+                    if (t <= wvm) {                  // (wave uniform) tiles right of the wave's diagonal tile are never read
+                        const int col = 16 * t + l15;
+                        const double fc = Fp[col][cg];
+                        const double aop = (col > j0 + 3) ? -fc : 0.0;
+                        d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+                        acc = mfma16(aop, pl, acc);
+                        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = jq + 1; q < 16; ++q) {
+                    const int c = cg + 4 * q;
+                    a[q] = fma(-pf3, Fp[c][3], fma(-pf2, Fp[c][2], fma(-pf1, Fp[c][1], fma(-pf0, Fp[c][0], a[q]))));
+                }
+            }
+        }
+        // b. the pivot block
         const double r00 = Rw[j0][0];
         const double r10 = Rw[j0 + 1][0], r11 = Rw[j0 + 1][1];
         const double r20 = Rw[j0 + 2][0], r21 = Rw[j0 + 2][1], r22 = Rw[j0 + 2][2];
         const double r30 = Rw[j0 + 3][0], r31 = Rw[j0 + 3][1], r32 = Rw[j0 + 3][2], r33 = Rw[j0 + 3][3];
         const double x0 = Rw[i][0], x1 = Rw[i][1], x2 = Rw[i][2], x3 = Rw[i][3];
+        const int nr = min(j0 + 4 + cg, CB - 1);         // row of the next pivot block this thread's look-ahead column needs (jq = 15: unused)
+        const double y0 = Rw[nr][0], y1 = Rw[nr][1], y2 = Rw[nr][2], y3 = Rw[nr][3];
         const double rs0 = rsqrt_nr(r00);
         const double t10 = r10 * rs0, t20 = r20 * rs0, t30 = r30 * rs0;
         const double d1 = fma(-t10, t10, r11);
@@ -113,13 +147,24 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         const double d3 = fma(-t32, t32, fma(-t31, t31, fma(-t30, t30, r33)));
         const double rs3 = rsqrt_nr(d3);
         if (tid == 0 && report && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
+        // c. own row and the look-ahead row through T
         const double l0 = x0 * rs0;
+        const double m0 = y0 * rs0;
         const double l1 = fma(-l0, t10, x1) * rs1;
+        const double m1 = fma(-m0, t10, y1) * rs1;
         const double l2 = fma(-l1, t21, fma(-l0, t20, x2)) * rs2;
+        const double m2 = fma(-m1, t21, fma(-m0, t20, y2)) * rs2;
         const double l3 = fma(-l2, t32, fma(-l1, t31, fma(-l0, t30, x3))) * rs3;
+        const double m3 = fma(-m2, t32, fma(-m1, t31, fma(-m0, t30, y3))) * rs3;
         const double lf = (cg == 0) ? l0 : (cg == 1) ? l1 : (cg == 2) ? l2 : l3;
+        // d. look-ahead: column cg + 4 (jq + 1) of this row, then publish it as the next round's raw block
+        if (jq < 15) {
+            a[jq + 1] = fma(-l3, m3, fma(-l2, m2, fma(-l1, m1, fma(-l0, m0, a[jq + 1]))));
+            L.Rw[(jq + 1) & 1][i][cg] = a[jq + 1];
+        }
         a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
         Fw[i][cg] = lf;
+        pl = lf; pf0 = l0; pf1 = l1; pf2 = l2; pf3 = l3;
         if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
         if (!MF && Vd && (tid >> 4) == 4) {         // sixteen lanes of wave 1 (off the stores above): element (k, c) of the inverse of the pivot block
             // [[1/rs0], [t10, 1/rs1], [t20, t21, 1/rs2], [t30, t31, t32, 1/rs3]]
@@ -133,32 +178,8 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
             const double r3v = (c == 0) ? v30 : (c == 1) ? v31 : (c == 2) ? v32 : rs3;
             Vd[j0 + k][c] = (k == 0) ? r0v : (k == 1) ? r1v : (k == 2) ? r2v : r3v;
         }
-        __syncthreads();
-        if (MF) {
-            if (jq < 15) {
-                const int wvm = tid >> 6, l15 = tid & 15;
-#pragma unroll
-                for (int t = (jq + 1) / 4; t < 4; ++t) {
-                    if (t <= wvm) {                  // (wave uniform) tiles right of the wave's diagonal tile are never read
-                        const int col = 16 * t + l15;
-                        const double fc = Fw[col][cg];
-                        const double aop = (col > j0 + 3) ? -fc : 0.0;
-                        d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-                        acc = mfma16(aop, lf, acc);
-                        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-                    }
-                }
-            }
-        } else
-        if (jq < 15) {
-            const double f0 = Fw[i][0], f1 = Fw[i][1], f2 = Fw[i][2], f3 = Fw[i][3];
-#pragma unroll
-            for (int q = jq + 1; q < 16; ++q) {
-                const int c = cg + 4 * q;
-                a[q] = fma(-f3, Fw[c][3], fma(-f2, Fw[c][2], fma(-f1, Fw[c][1], fma(-f0, Fw[c][0], a[q]))));
-            }
-        }
     }
+    __syncthreads();                                     // (rdiag of the last round)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = cg + 4 * q;
@@ -413,7 +434,7 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
     // stamp of this hand-off: (solve counter, step) -- the counter lives in device memory and is bumped by chol_begin at the
     // start of every solve, so that the whole chain of launches has constant arguments and replays as one hipGraph
     const unsigned int epoch = (*epoch_ctr << 8) | step_id;
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16];
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // later: the updated tile T
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // later: start of the PanelLds
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
@@ -758,15 +779,15 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
                                                      const unsigned int* __restrict__ epoch_ctr, int* __restrict__ status,
                                                      double* __restrict__ rd, double* __restrict__ w16, double* __restrict__ winv, unsigned long long* __restrict__ trace)
 {
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB + 4 * 16 * W16_LD];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB + 4 * 16 * W16_LD];
     __shared__ int s_task;
 #define DF_TRACE(slot) do { if (trace && tid == 0) trace[(size_t)bj * 16 + (slot)] = wall_clock64(); } while (0)
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // operand tile / the accumulated tile T
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // operand tile / start of the PanelLds
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
-    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
-    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD);
-    double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB);
+    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16);
+    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD);
+    double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB);
     const unsigned int epoch = (*epoch_ctr << 8) | DF_EPOCH_TAG;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int ti = 16 * wv + ln, cg = lk;                    // element ownership of chol_factor_diag<true>
@@ -1000,13 +1021,13 @@ __global__ void __launch_bounds__(256) chol_panel4(double* __restrict__ A, int l
                                                    unsigned int outer_id, int* __restrict__ status, double* __restrict__ rd,
                                                    double* __restrict__ w16, int nbc)
 {
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
     __shared__ int s_role;
     double (*T)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                        // this step's tile / X
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // another role's X tile / start of the PanelLds
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
-    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
-    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD);
+    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16);
+    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD);
     const unsigned int epoch = (*epoch_ctr << 8) | (outer_id & 0xFFu);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int ti = 16 * wv + ln, cg = lk;                    // element ownership of chol_factor_diag<true>
