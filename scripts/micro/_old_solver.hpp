@@ -67,8 +67,8 @@ __global__ void chol_begin(unsigned int* epoch_ctr, unsigned int* queue, unsigne
 struct PanelLds {
     double Dl[CB][CB + 1];     // factor of the diagonal block
     double rdiag[CB];          // 1 / L[j][j]
-    double Rw[2][CB][4];       // raw column block of a round (ping-pong: round jq writes the block of round jq + 1)
-    double Fw[2][CB][4];       // final column block of a round (ping-pong: read by the NEXT round's deferred trailing update)
+    double Rw[CB][4];          // raw column block published in step 1
+    double Fw[CB][4];          // final column block published in step 3
 };
 
 // Factor the CB x CB diagonal block held as a[q] = D[i][cg + 4 q] by thread (i = tid >> 2, cg = tid & 3) (identity padding
@@ -84,58 +84,24 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
                                                  double (*Vd)[4] = nullptr)
 {
     const int i = MF ? 16 * (tid >> 6) + (tid & 15) : tid >> 2, cg = MF ? (tid >> 4) & 3 : tid & 3;
+    double (&Rw)[CB][4] = L.Rw;
+    double (&Fw)[CB][4] = L.Fw;
     double (&rdiag)[CB] = L.rdiag;
-    // Four columns per round, 16 rounds, ONE barrier per round (round 4: was two -- publish raw / barrier / factor / publish final /
-    // barrier / update, 13 us of every 28 us block step of chol_dataflow).  Round jq eliminates columns 4 jq .. 4 jq + 3:
-    //   barrier: the raw column block jq of every row (and the final block jq - 1) is visible;
-    //   a. deferred trailing update: the finals of round jq - 1 go into the columns right of block jq (off the critical path:
-    //      block jq itself received them through the look-ahead of round jq - 1);
-    //   b. all threads factor the 4 x 4 pivot block T redundantly (four reciprocal square roots in sequence);
-    //   c. thread (i, cg) forward-substitutes its own row through T -> finals L[i][4 jq .. 4 jq + 3] -- and, redundantly, the row
-    //      4 (jq + 1) + cg of the NEXT pivot block, which is what its column cg + 4 (jq + 1) needs from this round;
-    //   d. look-ahead: its element of column block jq + 1 receives this round's rank-4 update at once and is published as the raw
-    //      block of round jq + 1 (ping-pong buffers); the final L[i][4 jq + cg] is published for the next round's step a.
-    double pl = 0.0;                                     // own final of the previous round (MF: B operand of the deferred update)
-    double pf0 = 0.0, pf1 = 0.0, pf2 = 0.0, pf3 = 0.0;   // own finals of the previous round, all four columns (vector form of the deferred update)
-    L.Rw[0][i][cg] = a[0];
+    // Four columns per step (16 steps, two barriers each).  Step jq eliminates columns 4 jq .. 4 jq + 3:
+    //   1. every thread publishes its raw element of that column block (the quad of a row holds the four of them);
+    //   2. all threads factor the 4x4 pivot block T redundantly (four reciprocal square roots in sequence);
+    //   3. thread (i, cg) forward-substitutes its row through T up to column cg -> final L[i][4 jq + cg], published;
+    //   4. rank-4 update of the columns to the right from the published finals.
 #pragma unroll
     for (int jq = 0; jq < 16; ++jq) {
-        double (&Rw)[CB][4] = L.Rw[jq & 1];
-        double (&Fw)[CB][4] = L.Fw[jq & 1];
+        Rw[i][cg] = a[jq];
         __syncthreads();
         const int j0 = 4 * jq;
-        // a. deferred update with the finals of round jq - 1 (buffer (jq - 1) & 1), columns right of block jq
-        if (jq >= 1 && jq < 15) {
-            double (&Fp)[CB][4] = L.Fw[(jq - 1) & 1];
-            if (MF) {
-                const int wvm = tid >> 6, l15 = tid & 15;
-#pragma unroll
-                for (int t = (jq + 1) / 4; t < 4; ++t) {
-                    if (t <= wvm) {                  // (wave uniform) tiles right of the wave's diagonal tile are never read
-                        const int col = 16 * t + l15;
-                        const double fc = Fp[col][cg];
-                        const double aop = (col > j0 + 3) ? -fc : 0.0;
-                        d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-                        acc = mfma16(aop, pl, acc);
-                        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int q = jq + 1; q < 16; ++q) {
-                    const int c = cg + 4 * q;
-                    a[q] = fma(-pf3, Fp[c][3], fma(-pf2, Fp[c][2], fma(-pf1, Fp[c][1], fma(-pf0, Fp[c][0], a[q]))));
-                }
-            }
-        }
-        // b. the pivot block
         const double r00 = Rw[j0][0];
         const double r10 = Rw[j0 + 1][0], r11 = Rw[j0 + 1][1];
         const double r20 = Rw[j0 + 2][0], r21 = Rw[j0 + 2][1], r22 = Rw[j0 + 2][2];
         const double r30 = Rw[j0 + 3][0], r31 = Rw[j0 + 3][1], r32 = Rw[j0 + 3][2], r33 = Rw[j0 + 3][3];
         const double x0 = Rw[i][0], x1 = Rw[i][1], x2 = Rw[i][2], x3 = Rw[i][3];
-        const int nr = min(j0 + 4 + cg, CB - 1);         // row of the next pivot block this thread's look-ahead column needs (jq = 15: unused)
-        const double y0 = Rw[nr][0], y1 = Rw[nr][1], y2 = Rw[nr][2], y3 = Rw[nr][3];
         const double rs0 = rsqrt_nr(r00);
         const double t10 = r10 * rs0, t20 = r20 * rs0, t30 = r30 * rs0;
         const double d1 = fma(-t10, t10, r11);
@@ -147,24 +113,13 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         const double d3 = fma(-t32, t32, fma(-t31, t31, fma(-t30, t30, r33)));
         const double rs3 = rsqrt_nr(d3);
         if (tid == 0 && report && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
-        // c. own row and the look-ahead row through T
         const double l0 = x0 * rs0;
-        const double m0 = y0 * rs0;
         const double l1 = fma(-l0, t10, x1) * rs1;
-        const double m1 = fma(-m0, t10, y1) * rs1;
         const double l2 = fma(-l1, t21, fma(-l0, t20, x2)) * rs2;
-        const double m2 = fma(-m1, t21, fma(-m0, t20, y2)) * rs2;
         const double l3 = fma(-l2, t32, fma(-l1, t31, fma(-l0, t30, x3))) * rs3;
-        const double m3 = fma(-m2, t32, fma(-m1, t31, fma(-m0, t30, y3))) * rs3;
         const double lf = (cg == 0) ? l0 : (cg == 1) ? l1 : (cg == 2) ? l2 : l3;
-        // d. look-ahead: column cg + 4 (jq + 1) of this row, then publish it as the next round's raw block
-        if (jq < 15) {
-            a[jq + 1] = fma(-l3, m3, fma(-l2, m2, fma(-l1, m1, fma(-l0, m0, a[jq + 1]))));
-            L.Rw[(jq + 1) & 1][i][cg] = a[jq + 1];
-        }
         a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
         Fw[i][cg] = lf;
-        pl = lf; pf0 = l0; pf1 = l1; pf2 = l2; pf3 = l3;
         if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
         if (!MF && Vd && (tid >> 4) == 4) {         // sixteen lanes of wave 1 (off the stores above): element (k, c) of the inverse of the pivot block
             // [[1/rs0], [t10, 1/rs1], [t20, t21, 1/rs2], [t30, t31, t32, 1/rs3]]
@@ -178,8 +133,32 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
             const double r3v = (c == 0) ? v30 : (c == 1) ? v31 : (c == 2) ? v32 : rs3;
             Vd[j0 + k][c] = (k == 0) ? r0v : (k == 1) ? r1v : (k == 2) ? r2v : r3v;
         }
+        __syncthreads();
+        if (MF) {
+            if (jq < 15) {
+                const int wvm = tid >> 6, l15 = tid & 15;
+#pragma unroll
+                for (int t = (jq + 1) / 4; t < 4; ++t) {
+                    if (t <= wvm) {                  // (wave uniform) tiles right of the wave's diagonal tile are never read
+                        const int col = 16 * t + l15;
+                        const double fc = Fw[col][cg];
+                        const double aop = (col > j0 + 3) ? -fc : 0.0;
+                        d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+                        acc = mfma16(aop, lf, acc);
+                        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+                    }
+                }
+            }
+        } else
+        if (jq < 15) {
+            const double f0 = Fw[i][0], f1 = Fw[i][1], f2 = Fw[i][2], f3 = Fw[i][3];
+#pragma unroll
+            for (int q = jq + 1; q < 16; ++q) {
+                const int c = cg + 4 * q;
+                a[q] = fma(-f3, Fw[c][3], fma(-f2, Fw[c][2], fma(-f1, Fw[c][1], fma(-f0, Fw[c][0], a[q]))));
+            }
+        }
     }
-    __syncthreads();                                     // (rdiag of the last round)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = cg + 4 * q;
@@ -434,7 +413,7 @@ __global__ void __launch_bounds__(256) chol_step(double* __restrict__ A, int ld,
     // stamp of this hand-off: (solve counter, step) -- the counter lives in device memory and is bumped by chol_begin at the
     // start of every solve, so that the whole chain of launches has constant arguments and replays as one hipGraph
     const unsigned int epoch = (*epoch_ctr << 8) | step_id;
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16];
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // later: the updated tile T
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // later: start of the PanelLds
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
@@ -779,15 +758,15 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
                                                      const unsigned int* __restrict__ epoch_ctr, int* __restrict__ status,
                                                      double* __restrict__ rd, double* __restrict__ w16, double* __restrict__ winv, unsigned long long* __restrict__ trace)
 {
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB + 4 * 16 * W16_LD];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB + 4 * 16 * W16_LD];
     __shared__ int s_task;
 #define DF_TRACE(slot) do { if (trace && tid == 0) trace[(size_t)bj * 16 + (slot)] = wall_clock64(); } while (0)
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // operand tile / the accumulated tile T
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // operand tile / start of the PanelLds
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
-    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16);
-    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD);
-    double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB);
+    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
+    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD);
+    double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB);
     const unsigned int epoch = (*epoch_ctr << 8) | DF_EPOCH_TAG;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int ti = 16 * wv + ln, cg = lk;                    // element ownership of chol_factor_diag<true>
@@ -796,34 +775,26 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
     const int nbc = g.nbc;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((size_t)(n + 1) * ld * sizeof(double)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)w16, 0, (int)((size_t)nbc * 1024 * sizeof(double)), 0x00020000);
-    // The diagonal chain PT(0), PT(1), ... is the critical path.  It has DEDICATED workgroups -- the first npt of the grid, PT(j) on
-    // workgroup j mod npt -- so that PT(j) starts accumulating its look-ahead products npt - 1 steps before it is due, however busy
-    // the pool is.  (Round 3 handed PT tasks out through the same queue as the TR tasks: the per-step stamps of SFFT_DF_TRACE showed
-    // 8 of 28 steps at n = 1735 starting 6 - 20 us late because their PT task had been picked up too late -- 690 us for 28 steps of
-    // 21 us.)  A PT task's accumulation is (j - 1) x 128 matrix instructions, ~7 us per k: npt = 2 + nbc / 3 gives every PT(j) the
-    // lead it needs (3 workers: 1264 us, the accumulation becomes the chain).  Every other workgroup pulls TR tasks from the queue; a PT
-    // workgroup joins them when its diagonal tasks are done.  Progress: block indices are dispatched in order, so the PT workgroups
-    // are resident before any TR workgroup; a TR task only waits for PT tasks and for TR tasks earlier in the queue, all of which have
-    // been taken by running workgroups.
-    const int npt = max(1, min(2 + nbc / 3, (int)gridDim.x - 1));
-    int pt_next = ((int)blockIdx.x < npt) ? (int)blockIdx.x : nbc;
     for (;;) {
         __syncthreads();                    // s_task (and the LDS tiles) of the previous task are no longer read
+        if (tid == 0) s_task = (int)atomicAdd(queue, 1u);
+        __syncthreads();
+        int t = s_task;
+        // ---- decode: group 0 = {PT(0)}, group j (1 <= j < nbc) = {PT(j), TR(j+1..nbc-1, j-1), TR(border, j-1)}, last = {TR(border, nbc-1)}
         int kind = -1, bi = 0, bj = 0;      // kind 0: PT(bj); kind 1: TR(bi, bj)
-        if (pt_next < nbc) { kind = 0; bj = pt_next; pt_next += npt; }      // (workgroup uniform)
+        if (t == 0) { kind = 0; bj = 0; }
         else {
-            if (tid == 0) s_task = (int)atomicAdd(queue, 1u);
-            __syncthreads();
-            int t = s_task;
-            // ---- decode: group j (1 <= j < nbc) = {TR(j+1..nbc-1, j-1), TR(border, j-1)}, last = {TR(border, nbc-1)}
+            t -= 1;
             int j = 1;
             for (; j < nbc; ++j) {
-                const int cnt = nbc - j;
+                const int cnt = nbc - j + 1;
                 if (t < cnt) break;
                 t -= cnt;
             }
-            if (j < nbc) { kind = 1; bj = j - 1; bi = j + 1 + t; }           // t = 0 .. nbc-j-1: rows j+1 .. nbc-1, then nbc (= border)
-            else if (t == 0) { kind = 1; bj = nbc - 1; bi = nbc; }
+            if (j < nbc) {
+                if (t == 0) { kind = 0; bj = j; }
+                else { kind = 1; bj = j - 1; bi = j + t; }       // t = 1 .. nbc-j: rows j+1 .. nbc-1, then nbc (= border)
+            } else if (t == 0) { kind = 1; bj = nbc - 1; bi = nbc; }
         }
         if (kind < 0) return;               // queue exhausted
 
@@ -954,16 +925,15 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
             DF_TRACE(4);
             __syncthreads();
             df_store_tile(rsrc, ld, d0, nbd, x0, T, tid);
+            df_publish(flags, df_flag_id(g, j, j - 1), epoch, tid);
             DF_TRACE(5);
-            // (the X tile's stores drain while the matrix instructions of D -= X X^T issue; its flag goes out after them: the consumers
-            //  of X -- accumulations of later tasks -- have more than a block step of slack, the chain has none)
 #pragma unroll 4
             for (int ks = 0; ks < CB / 4; ++ks) {
                 const double av = -T[16 * wv + ln][4 * ks + lk];
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) cd[jt] = mfma16(av, T[16 * jt + ln][4 * ks + lk], cd[jt]);
             }
-            df_publish(flags, df_flag_id(g, j, j - 1), epoch, tid);      // (its barrier also ends the reads of T)
+            __syncthreads();
         }
         // ---- factor D ----
 #pragma unroll
@@ -1030,13 +1000,13 @@ __global__ void __launch_bounds__(256) chol_panel4(double* __restrict__ A, int l
                                                    unsigned int outer_id, int* __restrict__ status, double* __restrict__ rd,
                                                    double* __restrict__ w16, int nbc)
 {
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
     __shared__ int s_role;
     double (*T)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                        // this step's tile / X
     double (*Lj)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem + CB * (CB + 1));       // another role's X tile / start of the PanelLds
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
-    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16);
-    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD);
+    double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16);
+    double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 8 * CB + 16 + 4 * 16 * W16_LD);
     const unsigned int epoch = (*epoch_ctr << 8) | (outer_id & 0xFFu);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int ti = 16 * wv + ln, cg = lk;                    // element ownership of chol_factor_diag<true>

@@ -16,7 +16,11 @@ typedef double2 cplx;
 #define HIPCHK(x) (x)
 #include "../../sfft_amd/csrc/device_common.hpp"
 #include "../../sfft_amd/csrc/fft_generic.hpp"
+#ifdef OLD_SOLVER
+#include "_old_solver.hpp"
+#else
 #include "../../sfft_amd/csrc/solver.hpp"
+#endif
 
 template <bool MF>
 __global__ void __launch_bounds__(256) factor_loop(const double* __restrict__ A, double* __restrict__ out, int reps, int* status)
@@ -35,6 +39,9 @@ __global__ void __launch_bounds__(256) factor_loop(const double* __restrict__ A,
         __syncthreads();
     }
     out[blockIdx.x * 256 + tid] = acc;
+    if (blockIdx.x == 0) {      // the factor of the last repetition, for the check against the host
+        for (int e = tid; e < CB * CB; e += 256) out[256 * 64 + e] = L.Dl[e / CB][e % CB];
+    }
 }
 
 int main()
@@ -42,7 +49,7 @@ int main()
     std::vector<double> h(CB * CB);
     for (int i = 0; i < CB; ++i) for (int j = 0; j < CB; ++j) h[i * CB + j] = (i == j ? 80.0 : 0.0) + 1.0 / (1.0 + abs(i - j));
     double *dA, *dO; int* dS;
-    hipMalloc(&dA, sizeof(double) * CB * CB); hipMalloc(&dO, sizeof(double) * 256 * 64); hipMalloc(&dS, 4);
+    hipMalloc(&dA, sizeof(double) * CB * CB); hipMalloc(&dO, sizeof(double) * (256 * 64 + CB * CB)); hipMalloc(&dS, 4);
     hipMemcpy(dA, h.data(), sizeof(double) * CB * CB, hipMemcpyHostToDevice); hipMemset(dS, 0, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 200;
@@ -54,7 +61,21 @@ int main()
                 else hipLaunchKernelGGL(factor_loop<false>, dim3(nwg), dim3(256), 0, 0, dA, dO, reps, dS);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-                if (it) printf("chol_factor_diag<%s>: %d workgroup(s), %.2f us per 64 x 64 factorisation\n", mf ? "true (MFMA update)" : "false", nwg, ms * 1e3 / reps);
+                if (it) {
+                    // host Cholesky of the last repetition's matrix (A + 1e-9 (reps - 1) on the lower triangle)
+                    std::vector<double> Lh(CB * CB, 0.0), M(CB * CB), got(CB * CB);
+                    for (int i = 0; i < CB; ++i) for (int j = 0; j <= i; ++j) M[i * CB + j] = h[i * CB + j] + 1e-9 * (reps - 1);
+                    for (int j = 0; j < CB; ++j) {
+                        double d = M[j * CB + j];
+                        for (int k = 0; k < j; ++k) d -= Lh[j * CB + k] * Lh[j * CB + k];
+                        Lh[j * CB + j] = sqrt(d);
+                        for (int i = j + 1; i < CB; ++i) { double v = M[i * CB + j]; for (int k = 0; k < j; ++k) v -= Lh[i * CB + k] * Lh[j * CB + k]; Lh[i * CB + j] = v / Lh[j * CB + j]; }
+                    }
+                    hipMemcpy(got.data(), dO + 256 * 64, sizeof(double) * CB * CB, hipMemcpyDeviceToHost);
+                    double err = 0.0;
+                    for (int e = 0; e < CB * CB; ++e) err = std::max(err, fabs(got[e] - Lh[e]));
+                    printf("chol_factor_diag<%s>: %d workgroup(s), %.2f us per 64 x 64 factorisation, max |L - L_host| = %.2e\n", mf ? "true (MFMA update)" : "false", nwg, ms * 1e3 / reps, err);
+                }
             }
         }
     }

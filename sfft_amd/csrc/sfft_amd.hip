@@ -1834,7 +1834,7 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
     if (dataflow) {
         // the whole factorisation as one launch of persistent workgroups (see chol_dataflow)
         const int ntask = 2 + (nbc - 1) * (nbc + 2) / 2;
-        SFFT_LAUNCH(chol_dataflow, dim3(std::min(p->df_groups, ntask)), dim3(256), 0, s, p->d_A, p->ld, n, p->d_tflags, d_queue,
+        SFFT_LAUNCH(chol_dataflow, dim3(std::max(2, std::min(p->df_groups, ntask))), dim3(256), 0, s, p->d_A, p->ld, n, p->d_tflags, d_queue,
                            p->d_epoch, p->d_status, p->d_rd, p->d_w16, p->d_winv, p->d_trace);
     } else
     SFFT_LAUNCH(chol_copy_diag, dim3(1), dim3(256), 0, s, p->d_A, p->ld, std::min(CB, n), p->d_dbuf);
