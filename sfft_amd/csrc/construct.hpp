@@ -452,23 +452,43 @@ __global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ 
     for (int q = 0; q <= L; ++q) acc[q] = make_double2(0.0, 0.0);
     int y = x0 - W;
     if (y < 0) y += N0;
+    // the two source rows of a step (and their row factors) are fetched ONE STEP AHEAD, as in vconv_mixed2: at two waves per SIMD a trip
+    // to HBM at the top of every step is not hidden (round 4: 1.9 ms at config 3 with the loads at the top of the step)
+    cplx S0[NJ], S1[NJ], T0[NJ], T1[NJ];
+    double f0[NI], f1[NI], g0[NI], g1[NI];
+    {
+        const int y1 = (y + 1 == N0) ? 0 : y + 1;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            T0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            T1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
+        }
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+            g0[ii] = kbx[(size_t)ii * N0 + y];
+            g1[ii] = kbx[(size_t)ii * N0 + y1];
+        }
+        y = (y1 + 1 == N0) ? 0 : y1 + 1;
+    }
 #pragma unroll 1
     for (int sI = 0; sI < NSRC; sI += 2) {
         int opq;
         asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
         const cplx* __restrict__ ct = ctab + cl + opq;
         const int y1 = (y + 1 == N0) ? 0 : y + 1;
-        cplx S0[NJ], S1[NJ];
-        double f0[NI], f1[NI];
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            S0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
-            S1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
+        for (int jj = 0; jj < NJ; ++jj) { S0[jj] = T0[jj]; S1[jj] = T1[jj]; }
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) { f0[ii] = g0[ii]; f1[ii] = g1[ii]; }
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {       // (the rows after the last step's are read and dropped: any row index is valid)
+            T0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
+            T1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
         }
 #pragma unroll
         for (int ii = 0; ii < NI; ++ii) {
-            f0[ii] = kbx[(size_t)ii * N0 + y];
-            f1[ii] = kbx[(size_t)ii * N0 + y1];
+            g0[ii] = kbx[(size_t)ii * N0 + y];
+            g1[ii] = kbx[(size_t)ii * N0 + y1];
         }
 #pragma unroll
         for (int q = 0; q < L; ++q) {           // tap a = q - W
