@@ -1786,7 +1786,7 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             }
             if (p->d_g1trace) {     // development aid (SFFT_G1_TRACE=file): dump the wave stamps of this launch
                 hipStreamSynchronize(s);
-                std::vector<unsigned long long> h((size_t)3 * 8 * ((totg + 7) / 8));
+                std::vector<unsigned long long> h((size_t)3 * std::min(65536, 8 * ((totg + 7) / 8)));      // (the trace buffer holds 65536 waves: larger launches are truncated)
                 if (hipMemcpy(h.data(), p->d_g1trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
                     if (FILE* f = fopen(getenv("SFFT_G1_TRACE"), "w")) { for (size_t k = 0; k + 2 < h.size(); k += 3) fprintf(f, "%llu %llu %llu\n", h[k], h[k + 1], h[k + 2]); fclose(f); }
             }
