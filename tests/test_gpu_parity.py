@@ -1421,3 +1421,31 @@ def test_removed_unknowns_stay_zero_under_concurrent_graph_replays(dev):
         pl.close()
     assert bad == [0] * S, bad
     assert all(np.array_equal(sols[0], v) for v in sols[1:])          # every plan, every thread: the same bits
+
+
+def test_stage_timing_names_the_kernels_that_ran(dev):
+    """sfft_set_timing / sfft_stage_ms / sfft_stage_kernels: with timing on, every stage of a GSS reports a duration and the HIP kernels it
+    launched, as written at the launch sites -- the names bench.py puts into its roofline objects and scripts/make_pmc_traffic.py uses to
+    map PMC counters to stages.  Checked on two plans that take different kernels (polynomial at a generic shape; 4096-point fast path
+    columns) and through the solver graph's replay (second call)."""
+    from sfft_amd.plan import Plan
+    from sfft_amd.utils.synthetic import make_pair
+    for shape, expect in (((192, 160), {"fwd_rows": "rows_r2c", "greek_g2": "greek_g2", "fill": "fill_system", "solve": "chol_dataflow",
+                                        "construct": "vconv_mixed", "inverse": "rows_c2r_diff"}),
+                          ((64, 4096), {"fwd_rows": "rows_r2c_4096", "solve": "chol_dataflow", "inverse": "rows_c2r_diff_4096"})):
+        pair = make_pair(*shape, seed=5, mask=True, density=400.0)
+        g = {k: _to(dev, v) for k, v in pair.items()}
+        plan = Plan(shape[0], shape[1], 3, 2, 1, True, device=dev.index)
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            plan.subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"])          # (captures the solver graph)
+            plan.set_timing(True)
+            plan.subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"])          # (replays it)
+            ms, names = plan.stage_ms(), plan.stage_kernels()
+        plan.set_timing(False)
+        for st, frag in expect.items():
+            assert ms[st] > 0.0, (shape, st)
+            assert any(frag in k for k in names[st]), (shape, st, names[st])
+        assert any("chol_back" in k or "scatter_solution" in k for k in names["solve"]), names["solve"]
+        assert all(len(set(v)) == len(v) for v in names.values())            # each kernel once per stage
+        plan.close()
