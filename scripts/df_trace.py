@@ -5,7 +5,7 @@ if len(sys.argv) < 2:
     out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
     rows = [list(map(int, m.group(1).split())) for m in re.finditer(r"df_trace j=\d+ ([-\d ]+)", out.stderr)]
     rows = rows[-28:]
-    names = ["acc_done", "diag_seen", "acquired", "diag_loaded", "trsm", "X_published", "ready2factor", "factored", "D_published", "chol_done"]
+    names = ["acc_done", "diag_seen", "acquired", "diag_loaded", "trsm", "X_published", "ready2factor", "factored", "D_published", "chol_done", "border_out", "k_start", "k_end"]
     print(out.stdout[-300:])
     print("j   " + " ".join("%12s" % n for n in names) + "   step_us")
     prev = None

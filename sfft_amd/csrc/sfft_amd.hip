@@ -2015,7 +2015,7 @@ static int solve_check(sfft_plan* p, double* d_solution, hipStream_t s, bool* re
             const unsigned long long t0 = h[8];
             for (int j = 0; j < nbc; ++j) {
                 fprintf(stderr, "df_trace j=%d", j);
-                for (int k = 0; k < 10; ++k) fprintf(stderr, " %lld", h[(size_t)j * 16 + k] ? (long long)(h[(size_t)j * 16 + k] - t0) : -1LL);
+                for (int k = 0; k < 13; ++k) fprintf(stderr, " %lld", h[(size_t)j * 16 + k] ? (long long)(h[(size_t)j * 16 + k] - t0) : -1LL);
                 fprintf(stderr, "\n");
             }
         }

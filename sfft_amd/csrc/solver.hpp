@@ -805,27 +805,36 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
     // workgroup joins them when its diagonal tasks are done.  Progress: block indices are dispatched in order, so the PT workgroups
     // are resident before any TR workgroup; a TR task only waits for PT tasks and for TR tasks earlier in the queue, all of which have
     // been taken by running workgroups.
+    if (trace && tid == 0 && blockIdx.x == 0) trace[11] = wall_clock64();                       // (row 0, slot 11: kernel start)
     const int npt = max(1, min(2 + nbc / 3, (int)gridDim.x - 1));
+    const int nbw = 0;      // (dedicated workgroups for the border-row chain TR(border, j) were measured too: the kernel ends 6 us after the last
+                            //  diagonal block either way -- 575 us alone, 680 us beside the apply pass's transforms -- so they stay in the queue)
     int pt_next = ((int)blockIdx.x < npt) ? (int)blockIdx.x : nbc;
+    int bd_next = ((int)blockIdx.x >= npt && (int)blockIdx.x < npt + nbw) ? (int)blockIdx.x - npt : nbc;
     for (;;) {
         __syncthreads();                    // s_task (and the LDS tiles) of the previous task are no longer read
         int kind = -1, bi = 0, bj = 0;      // kind 0: PT(bj); kind 1: TR(bi, bj)
         if (pt_next < nbc) { kind = 0; bj = pt_next; pt_next += npt; }      // (workgroup uniform)
+        else if (bd_next < nbc) { kind = 1; bi = nbc; bj = bd_next; bd_next += nbw; }
         else {
             if (tid == 0) s_task = (int)atomicAdd(queue, 1u);
             __syncthreads();
             int t = s_task;
-            // ---- decode: group j (1 <= j < nbc) = {TR(j+1..nbc-1, j-1), TR(border, j-1)}, last = {TR(border, nbc-1)}
+            // ---- decode: group j (1 <= j < nbc) = {TR(j+1..nbc-1, j-1)} (+ TR(border, j-1) when there are no border workgroups), last = {TR(border, nbc-1)}
+            const int wb = nbw > 0 ? 0 : 1;
             int j = 1;
             for (; j < nbc; ++j) {
-                const int cnt = nbc - j;
+                const int cnt = nbc - j - 1 + wb;
                 if (t < cnt) break;
                 t -= cnt;
             }
-            if (j < nbc) { kind = 1; bj = j - 1; bi = j + 1 + t; }           // t = 0 .. nbc-j-1: rows j+1 .. nbc-1, then nbc (= border)
-            else if (t == 0) { kind = 1; bj = nbc - 1; bi = nbc; }
+            if (j < nbc) { kind = 1; bj = j - 1; bi = j + 1 + t; }           // t = 0 .. : rows j+1 .. nbc-1, then nbc (= border) if it is in the queue
+            else if (t == 0 && wb) { kind = 1; bj = nbc - 1; bi = nbc; }
         }
-        if (kind < 0) return;               // queue exhausted
+        if (kind < 0) {                     // queue exhausted
+            if (trace && tid == 0) atomicMax(&trace[12], wall_clock64());                           // (row 0, slot 12: the last workgroup's exit)
+            return;
+        }
 
         if (kind == 1) {
             // ================= TR(bi, bj): C = A(bi,bj) - sum_k L(bi,k) L(bj,k)^T;  X L(bj,bj)^T = C =================
@@ -884,6 +893,7 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
             __syncthreads();
             df_store_tile(rsrc, ld, r0, ni, c0, T, tid);
             df_publish(flags, df_flag_id(g, bi, bj), epoch, tid);
+            if (trace && tid == 0 && bi == nbc) trace[(size_t)bj * 16 + 10] = wall_clock64();       // (slot 10: border tile of column bj published)
             continue;
         }
 
