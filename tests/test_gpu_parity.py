@@ -558,12 +558,14 @@ def test_config3_bspline_6144(dev):
     clear_plan_cache()
 
 
-@pytest.mark.parametrize("shape", [(6144, 96), (96, 6144)], ids=["cols6144", "rows6144"])
+@pytest.mark.parametrize("shape", [(6144, 96), (96, 6144), (768, 768), (1536, 1536)], ids=["cols6144", "rows6144", "square768", "square1536"])
 def test_config3_bspline_strip_matches_oracle(dev, shape):
     """6144 x 96 strip with config 3's basis: the same 7231-unknown system as the full frame (outer-blocked Cholesky, 325 Omega
     passes, tied scaling), small enough for the oracle: LHMAT / RHb <= 1e-11, apply-only DIFF <= 1e-10 RMS(J), end to end <= 1e-6.
     The transposed strip (96 x 6144) runs the full-width 6144-point ROW passes (forward r2c of the B-spline stage planes, inverse c2r
-    with the DIFF epilogue) with the config's own basis tables."""
+    with the DIFF epilogue) with the config's own basis tables.  The 768 x 768 and 1536 x 1536 squares (round 4) are sizes at which the GROUP SCHEDULING
+    of the 25-plane Omega launch matters -- 25 (49) column tiles x 113 pass groups x several row chunks in one grid, as at 6144^2 -- and are
+    still within the oracle's reach."""
     from oracle import bspline_oracle as BO
     from sfft_amd.plan import clear_plan_cache
     from sfft_amd.BSplineSFFT import GeneralSFFTSubtract as BGSS, ElementalSFFTSubtract as BESS
