@@ -151,6 +151,8 @@ def compact(full):
             out[k] = _pick(full[k], ROOF_KEYS)
     if "single_pair" in full:
         out["single_pair_ms"] = full["single_pair"]["ms"]
+    if "prelim_apply_alone" in full:      # [alone, beside the solve] (ms): the apply pass's forward transforms
+        out["prelim_apply_ms"] = [full["prelim_apply_alone"]["ms"], full["prelim_apply_alone"]["ms_beside_the_solve"]]
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
         out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "seconds_per_pair", "spread_s", "protocol", "cpu_model", "physical_cores",
@@ -171,6 +173,7 @@ def compact(full):
         dom = leg.get("roofline", {})
         legs[cid] = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"), "timed_region_s": leg.get("config", {}).get("timed_region_s"),
                      "single_pair_ms": leg.get("single_pair", {}).get("ms"), "pairs_per_step": leg.get("config", {}).get("pairs_per_step"),
+                     "prelim_apply_ms": [leg.get("prelim_apply_alone", {}).get("ms"), leg.get("prelim_apply_alone", {}).get("ms_beside_the_solve")],
                      "dominant": _pick(dom, ("kernel", "bound", "frac", "avg_ms", "traffic")),
                      "bitwise_equal": leg.get("post_check", {}).get("bitwise_equal"),
                      "gathered_pairs": leg.get("gathered_pairs"), "failed_pairs": leg.get("failed_pairs")}
@@ -423,6 +426,15 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
                                                                  "pipelined": sols[k][fresh_s != sols[k]][:8].tolist()})
             assert bool(torch.isfinite(fresh_d).all()), "non-finite DIFF"
         n_iso = len(iso_ms)
+        # In a GSS the apply pass's forward transforms (stage prelim_apply) run on the plan's second stream BESIDE the dense solve: the
+        # duration above is a contended one.  An apply call alone (sfft_apply: the same launches on the caller's stream, nothing beside
+        # them) gives what the kernels can do on their own; both are printed.
+        apply_alone = {}
+        for _ in range(2):
+            g = pairs[check_ids[0]]
+            plans[0].apply(g["REF"], g["SCI"], fresh_s)
+            torch.cuda.synchronize(dev)
+            apply_alone = plans[0].stage_ms()
     plans[0].set_timing(False)
     assert post["bitwise_equal"] or post["max_rel_diff"] <= 1e-12, "pipelined result differs from the single-stream result: %r" % post
 
@@ -585,6 +597,10 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             "roofline_solve": dict(roof_solve(iso_stage), measured="same events, same launches"),
             "hbm_stages": {k: {"GBs": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9, "frac": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "ms": iso_stage[k], "alg_bytes": ab[k], "kernel": KERNEL_OF.get(k, k)} for k in HBM_STAGES},
+            "prelim_apply_alone": {"ms": apply_alone.get("prelim_apply", 0.0), "ms_beside_the_solve": iso_stage.get("prelim_apply", 0.0),
+                                   "frac": ab["prelim_apply"] / (max(apply_alone.get("prelim_apply", 0.0), 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "the apply pass's forward transforms timed by an sfft_apply call of their own (nothing beside them) and, in hbm_stages, "
+                                           "as they run inside a GSS: on the plan's second stream beside the dense solve"},
             "single_pair": {"ms": float(np.median(iso_ms)), "pairs_per_s": 1e3 / float(np.median(iso_ms)), "stage_ms": iso_stage,
                             "note": "one pair in flight: latency of one GSS and per-stage times without interleaving"},
             "post_check": dict(post, note="after the timed region each listed pair is subtracted again alone (one pair in flight, fresh "
