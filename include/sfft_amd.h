@@ -56,6 +56,8 @@ enum {
     SFFT_Q_CHOL_DATAFLOW,           /* 1: the Cholesky factorisation of this plan is the single-launch dataflow kernel, 0: the launch chain */
     SFFT_Q_SOLVER_N,                /* unknowns of the system the factorisation receives (NEQ when nothing is removed or tied; NEQ_FSFREE is the
                                        reference's dictionary entry, defined whether or not the stripes are removed) */
+    SFFT_Q_OMG_SPARSE,              /* Omega products of this plan that are summed in real space (tabulated bases: terms with disjoint supports
+                                       along one axis), not through the transforms; of FOMG / Fab^2 = Fij (Fij + 1) / 2 products */
     SFFT_Q_COUNT
 };
 

@@ -9,7 +9,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 [ -n "$kexpr" ] && timeout 1500 python -m pytest tests -m gpu -x -q -k "$kexpr" 2>&1 | tail -3
 common="--config $cfg --no-cpu --no-host-arrays --no-other-configs"
 run() {
-  env "$@" python bench.py $common --streams 1 --batch 4 --steps 3 --warmup 1 > /tmp/ab1.out 2>&1; cp profiles/bench_last_full.json /tmp/ab1.json
+  rm -f profiles/bench_last_full.json /tmp/ab1.json /tmp/ab4.json; env "$@" python bench.py $common --streams 1 --batch 4 --steps 3 --warmup 1 > /tmp/ab1.out 2>&1; cp profiles/bench_last_full.json /tmp/ab1.json; rm -f profiles/bench_last_full.json
   env "$@" python bench.py $common --steps 6 --warmup 2 > /tmp/ab4.out 2>&1; cp profiles/bench_last_full.json /tmp/ab4.json
   python - "$*" <<PY
 import json, sys

@@ -639,6 +639,169 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (trace && lane == 0 && blockIdx.x < 65536u) { trace[3 * (size_t)blockIdx.x] = t_start; trace[3 * (size_t)blockIdx.x + 1] = wall_clock64(); trace[3 * (size_t)blockIdx.x + 2] = (unsigned long long)logical; }
 }
 
+// ---- Omega products of basis terms with (nearly) DISJOINT supports, in real space (round 4) ---------------------------------------
+// PreOMG[(a),(b)](r, e) = SCALE^3 sum_x I_a(x) I_b(x + (r, e))  (circular), I_a = I * kbx[ia][x0] * kby[ja][x1].
+// For a B-spline basis most pairs of terms have supports that overlap in neither axis or in one only: of the 325 products of a 5 x 5
+// basis 132 have row (or column) factors whose supports are disjoint, so that kbx[ia][x0] kbx[ib][x0 + r] is nonzero only for the few
+// rows within |r| <= h of a shared knot or of the image edge (the circular wrap) -- ~270 (row, lag) pairs instead of 6144 x 33.  Such a
+// product does not go through the transforms at all (no Omega pass, no partial sums, no stage-2 job): its patch is a handful of 1-D
+// correlations between image rows (x mode) or image columns (y mode: from a transposed copy of the few columns involved).
+// One workgroup per ITEM (product, lag u along the sparse axis): it walks the lines c of the product whose weight wA[c] wB[c + u] does
+// not vanish (listed per lag by the host: scanning a candidate list on the device cost two dependent global loads per candidate,
+// 3.3 ms at config 3) and, of each line, only the span [t0, t1) on which the in-line factors can meet (the support of fA, cut by the
+// support of fB widened by h when that does not wrap).  A line is cut into STEPS of OSP_CH positions; a step keeps its own positions
+// (times in-line factor and weight) in registers, the partner line's window in LDS with HP positions of circular halo, and accumulates
+// the 2 h + 1 lags along the line.  The loop is software-pipelined: the global loads of step s + 1 are in flight while step s is
+// computed, the partner windows alternate between two LDS buffers (one barrier per step).  One block reduction at the end writes a row
+// (x mode) or a column (y mode) of the patch.  Deterministic: no atomics.
+// The host orders the items by (mode, cross factors) -- items that read the same few image rows -- and deals contiguous runs of that
+// order to the eight XCDs (workgroup b runs on XCD b & 7), so that an XCD's L2 holds the rows its items share (a run's rows are a few
+// MB; dealt round-robin every XCD pulled every row through the fabric: 1.56 ms at config 3 for 0.13 ms of multiply-adds).
+struct SparseProd {
+    int fa_cross, fb_cross;   // factor tables (rows of `cross`) whose product along the SPARSE axis gives the weight
+    int fa_line, fb_line;     // factor tables (rows of `inl`) along the line
+    int patch_off;            // doubles, into patches
+    int t0, t1;               // span of line positions to visit (multiples of 4; empty: the patch is zero)
+    int ustart[2 * 16 + 2];   // lines[ustart[u + h] .. ustart[u + h + 1]): the line pairs of lag u
+    int ymode;                // 0: lines are image rows (sparse axis = rows); 1: lines are image columns (from the transposed strip)
+};
+// one line pair of an item: position c on the sparse axis with weight w = wA[c] wB[c + u] != 0 (the tables are plan constants: the host
+// multiplies them); the offsets of line c and of its partner c + u (circular) in the image (x mode) or in the strip (y mode)
+struct SparseLine { long long a_off, b_off; double w; };
+
+// strip[c][x0] = I[x0][cols[c]]: the columns the y-mode products touch, transposed (coalesced along c)
+__global__ void __launch_bounds__(256) gather_cols(const double* __restrict__ I, const int* __restrict__ cols, int ncols, double* __restrict__ strip, int N0, int N1)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), x0 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c < ncols && x0 < N0) strip[(size_t)c * N0 + x0] = I[(size_t)x0 * N1 + cols[c]];
+}
+
+#define OSP_NT 256                      // threads per workgroup
+#define OSP_SW 2                        // sweeps per step: a thread owns four consecutive positions per sweep
+#define OSP_HP 16                       // lag half width, padded
+#define OSP_NG (OSP_NT * OSP_SW)        // groups of four window positions per step = one buffer's groups (two per thread)
+#define OSP_CH (4 * OSP_NG - 2 * OSP_HP - 8)       // line positions per step (2008): its window with both halos fills the OSP_NG groups
+#define OSP_PL (OSP_NG + (2 * OSP_HP + 8) / 4)     // slots per plane: masked threads' windows reach past the groups (zeros, written once)
+struct __attribute__((aligned(8))) OspD4 { double v[4]; };     // (image rows of a caller's array: 8-byte alignment is all that is promised)
+
+__global__ void __launch_bounds__(OSP_NT, 2) omega_sparse(const double* __restrict__ I, const double* __restrict__ strip,
+                                                    const SparseProd* __restrict__ prods, const SparseLine* __restrict__ lines, const int2* __restrict__ items,
+                                                    const double* __restrict__ kbx, const double* __restrict__ kby,
+                                                    int N0, int N1, int h, double scale3, double* __restrict__ patches)
+{
+    constexpr int HP = OSP_HP;
+    // the partner window in FOUR interleaved planes -- window position p sits at plane p & 3, slot p >> 2 -- so that the lanes of a wave,
+    // whose windows start four positions apart, read consecutive slots of one plane (with the window stored contiguously every read was
+    // an eight-way bank conflict)
+    __shared__ double Bl[2][4][OSP_PL];
+    __shared__ double red[OSP_NT / 64][2 * HP + 1];
+    const int2 item = items[(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)];      // (product, lag); XCD b & 7 walks its own run
+    if (item.x < 0) return;
+    const SparseProd& P = prods[item.x];                        // (read in place: a local copy of its per-lag table would sit in scratch)
+    const int u = item.y;                                       // lag along the sparse axis
+    const int tid = threadIdx.x;
+    const int NL = P.ymode ? N0 : N1;                           // line length (>= 2 HP + 8, a multiple of 4: the host's conditions)
+    const double* __restrict__ src = P.ymode ? strip : I;
+    const double* __restrict__ inl = P.ymode ? kbx : kby;       // factors along the line
+    const double* __restrict__ fA = inl + (size_t)P.fa_line * NL;
+    const double* __restrict__ fB = inl + (size_t)P.fb_line * NL;
+    const int t0 = P.t0, t1 = P.t1;
+    const int nch = (t1 - t0 + OSP_CH - 1) / OSP_CH;            // steps per line
+    const int k0 = P.ustart[u + h], k1 = P.ustart[u + h + 1];
+    const int nsteps = t1 > t0 ? (k1 - k0) * nch : 0;
+    double acc[2 * HP + 1];
+#pragma unroll
+    for (int e = 0; e <= 2 * HP; ++e) acc[e] = 0.0;
+    if (tid < 2 * 4 * (OSP_PL - OSP_NG)) {                      // the slots behind the groups, once
+        const int bp = tid / (OSP_PL - OSP_NG), sl = tid - bp * (OSP_PL - OSP_NG);
+        Bl[bp >> 2][bp & 3][OSP_NG + sl] = 0.0;
+    }
+    // the raw operands of one step: own positions (line a, factor fA, weight) and the partner window (line b, factor fB)
+    OspD4 rA[OSP_SW], rF[OSP_SW], rB[OSP_SW], rG[OSP_SW];
+    double rw[OSP_SW];
+    bool rv[OSP_SW];
+    auto fetch = [&](int kk, int chn) {            // line kk of the item's list, step chn of the line
+        const SparseLine L = lines[k0 + kk];
+        const double w = L.w;
+        const double* __restrict__ la = src + L.a_off;
+        const double* __restrict__ lb = src + L.b_off;
+        const int base = t0 + chn * OSP_CH, len = min(OSP_CH, t1 - base);
+#pragma unroll
+        for (int ch = 0; ch < OSP_SW; ++ch) {       // (clamped, loaded unconditionally, masked: `cond ? ptr[i] : 0` is a branch with a full wait per load)
+            const int g = OSP_NT * ch + tid;
+            const int t = base + min(4 * g, len - 4);
+            rA[ch] = *reinterpret_cast<const OspD4*>(la + t);
+            rF[ch] = *reinterpret_cast<const OspD4*>(fA + t);
+            rw[ch] = 4 * g < len ? w : 0.0;
+            int q = base - HP + min(4 * g, len + 2 * HP - 4);      // window group g: line positions q .. q + 3 (NL and every offset here are multiples of 4: a group never straddles the wrap)
+            q += q < 0 ? NL : 0; q -= q >= NL ? NL : 0;
+            rB[ch] = *reinterpret_cast<const OspD4*>(lb + q);
+            rG[ch] = *reinterpret_cast<const OspD4*>(fB + q);
+            rv[ch] = 4 * g < len + 2 * HP;          // (zeros behind the halo: the last windows reach past it)
+        }
+    };
+    double areg[OSP_SW][4];
+    auto settle = [&](int buf) {                   // raw operands -> this step's registers and window
+#pragma unroll
+        for (int ch = 0; ch < OSP_SW; ++ch)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                areg[ch][v] = rA[ch].v[v] * rF[ch].v[v] * rw[ch];
+                const double b = rB[ch].v[v] * rG[ch].v[v];
+                Bl[buf][v][OSP_NT * ch + tid] = rv[ch] ? b : 0.0;
+            }
+    };
+    if (nsteps > 0) { fetch(0, 0); settle(0); }
+    __syncthreads();
+    int fk = 0, fc = 0;                             // the step being fetched
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps && ++fc == nch) { fc = 0; ++fk; }
+        fetch(fk, fc);                              // in flight during the multiply-adds below (the last step's is a harmless repeat)
+        const int buf = s & 1;
+        // a thread keeps the partners of its four positions in registers, the lags in two halves (a window of HP + 4 values at a time):
+        // 20 8-byte LDS reads per 68 / 64 multiply-adds (one read per multiply-add made the kernel LDS-bound)
+#pragma unroll
+        for (int ch = 0; ch < OSP_SW; ++ch) {
+            const int g = OSP_NT * ch + tid;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                __builtin_amdgcn_sched_barrier(0);  // (one window live at a time)
+                constexpr int NE0 = HP + 1;         // lags [0, HP] then [HP + 1, 2 HP]
+                const int e0 = half ? NE0 : 0, ne = half ? HP : NE0;
+                double bl[HP + 4];
+#pragma unroll
+                for (int j = 0; j < HP + 4; ++j) bl[j] = (j < ne + 3) ? Bl[buf][(e0 + j) & 3][g + ((e0 + j) >> 2)] : 0.0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int e = 0; e < NE0; ++e) if (e < ne) acc[e0 + e] = fma(areg[ch][v], bl[v + e], acc[e0 + e]);       // lag e0 + e - HP
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        settle(buf ^ 1);                            // (unconditional -- after the last step a repeat nobody reads: behind a branch the compiler sank every multiply-add of the step below it, past the sched_barriers)
+        __syncthreads();
+    }
+    // block reduction of the 2 HP + 1 sums
+#pragma unroll
+    for (int e = 0; e <= 2 * HP; ++e) {
+        double v = acc[e];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][e] = v;
+    }
+    __syncthreads();
+    const int PH = 2 * h + 1;
+    if (tid < PH) {
+        const int e = tid - h + HP;                              // line lag tid - h
+        double v = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < OSP_NT / 64; ++wv) v += red[wv][e];
+        v *= scale3;
+        // x mode: u = row lag r, the line lag = column lag e;  y mode: u = column lag e, the line lag = row lag r
+        double* out = patches + P.patch_off;
+        if (P.ymode) out[(size_t)tid * PH + (u + h)] = v; else out[(size_t)(u + h) * PH + tid] = v;
+    }
+}
+
 // W0tab[l][r] = root0[(l r) mod N0], r = 0 .. HM-1 (column 0 is the constant 1: lag 0)
 __global__ void __launch_bounds__(256) build_w0tab(const cplx* __restrict__ root0, cplx* __restrict__ W0tab, int N0, int HM)
 {

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -176,6 +177,7 @@ struct sfft_plan {
     std::vector<G1Pass> passes;         // order: Omega (i'j' <= ij), Theta (i'j'), Gamma dense (i'j', p >= 1), Gamma p = 0
     std::vector<PatchJob> jobs;         // order: Omega, Gamma (i'j', pq), Theta  (= patch layout read by fill_system)
     int n_omg = 0, n_gam = 0, n_the = 0, n_gamp = 0, n_gam0 = 0;
+    int n_omg_rec = 0;                  // Omega pass RECORDS (launched + dual partners; products done by omega_sparse have none): the short passes follow them
     int n_omg_off = 0, n_omg_diag = 0;  // Omega products that are transformed (off-diagonal / diagonal)
     int n_omg_launch = 0;               // Omega pass records that are launched (the rest are partners of dual diagonal passes)
     // polynomial plans: the Gamma block straight from row moments of I (gamma_patches) instead of column-factor passes
@@ -258,6 +260,9 @@ struct sfft_plan {
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     // A/B switches of the launch paths, read ONCE at plan creation (never getenv on a hot path)
     int no_dft16_regs = 0, no_rader_r24 = 0, no_gamma_aside = 0, vconv2_w12 = 1, inv_r24 = 0;
+    // Omega products of basis terms with (nearly) disjoint supports: computed in real space by omega_sparse, no transform pass
+    std::vector<SparseProd> sprods; SparseProd* d_sprods = nullptr; SparseLine* d_slines = nullptr; int* d_scols = nullptr;
+    double* d_strip = nullptr; int n_scols = 0; int2* d_sitems = nullptr; int n_sitems = 0;      // (items: eight runs of n_sitems / 8, one per XCD)
     int launch_error = 0;               // a launch path met a case it does not serve (set by launch_pass; reported by the entry points)
     int timing = 0;
     std::string stage_kernels[SFFT_ST_COUNT];      // kernels each stage launched in the most recent timed call (sfft_stage_kernels)
@@ -905,7 +910,64 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         omg_pass.assign((size_t)p->Fij * (p->Fij + 1) / 2, -1);
         auto okey = [&](int a, int b) { return a * p->Fij - (a * (a - 1)) / 2 + (b - a); };      // (a <= b) -> k, the job / patch order
         std::vector<std::pair<int, int>> partners;     // (leader pass, partner plane)
+        // Products of terms whose row (or column) factors have (nearly) disjoint supports -- B-spline bases -- are not transformed: their
+        // patches are a few 1-D correlations in real space (omega_sparse, greek.hpp).  A product qualifies when at most 6 h positions of
+        // the sparse axis can carry a nonzero weight for some lag |u| <= h.  Tabulated bases without scaling planes, h <= 16.
+        std::vector<char> omg_sparse(omg_pass.size(), 0);
+        std::vector<int> slists;              // per (product, lag): the positions on the sparse axis whose weight is nonzero
+        if (DK < 0 && p->mode != 3 && hO >= 1 && hO <= OSP_HP && N0 % 4 == 0 && N1 % 4 == 0 && N0 >= 64 && N1 >= 64 && !getenv("SFFT_NO_OMG_SPARSE")) {
+            auto hull = [](const double* t, int N, int* lo, int* hi) { *lo = 0; *hi = N; while (*lo < N && t[*lo] == 0.0) ++*lo; while (*hi > *lo && t[*hi - 1] == 0.0) --*hi; };
+            auto candidates = [&](const double* ta, const double* tb, int N, std::vector<int>& out) {
+                int la, ha, lb, hb;
+                hull(ta, N, &la, &ha); hull(tb, N, &lb, &hb);
+                out.clear();
+                if (ha - la > N / 2 + 2 * hO && hb - lb > N / 2 + 2 * hO) return false;        // (both wide: dense for sure)
+                for (int c = la; c < ha; ++c) {
+                    bool any = false;
+                    for (int u = -hO; u <= hO && !any; ++u) { int cb = c + u; cb = cb < 0 ? cb + N : (cb >= N ? cb - N : cb); any = cb >= lb && cb < hb; }
+                    if (any) { out.push_back(c); if ((int)out.size() > 6 * hO) return false; }
+                }
+                return true;
+            };
+            std::vector<int> cand;
+            for (int a = 0; a < p->Fij; ++a) for (int b = a + 1; b < p->Fij; ++b) {
+                if (dual_diag && a % 2 == 0 && b == a + 1) continue;      // the edge of a dual-diagonal group: its wave carries two Theta passes, keep it
+                const int ia = BS.kpair[2 * a], ja = BS.kpair[2 * a + 1], ib = BS.kpair[2 * b], jb = BS.kpair[2 * b + 1];
+                SparseProd sp; memset(&sp, 0, sizeof(sp));
+                bool ok = candidates(BS.kbx.data() + (size_t)ia * N0, BS.kbx.data() + (size_t)ib * N0, N0, cand);
+                if (ok) { sp.ymode = 0; sp.fa_cross = ia; sp.fb_cross = ib; sp.fa_line = ja; sp.fb_line = jb; }
+                else {
+                    ok = candidates(BS.kby.data() + (size_t)ja * N1, BS.kby.data() + (size_t)jb * N1, N1, cand);
+                    if (ok) { sp.ymode = 1; sp.fa_cross = ja; sp.fb_cross = jb; sp.fa_line = ia; sp.fb_line = ib; }
+                }
+                if (!ok) continue;
+                {   // per lag u: the candidates whose weight is nonzero
+                    const int NSx = sp.ymode ? N1 : N0;
+                    const double* ta = (sp.ymode ? BS.kby.data() : BS.kbx.data()) + (size_t)sp.fa_cross * NSx;
+                    const double* tb = (sp.ymode ? BS.kby.data() : BS.kbx.data()) + (size_t)sp.fb_cross * NSx;
+                    for (int u = -hO; u <= hO; ++u) {
+                        sp.ustart[u + hO] = (int)slists.size();
+                        for (int c : cand) { int cb = c + u; cb = cb < 0 ? cb + NSx : (cb >= NSx ? cb - NSx : cb); if (ta[c] != 0.0 && tb[cb] != 0.0) slists.push_back(c); }
+                    }
+                    sp.ustart[2 * hO + 1] = (int)slists.size();
+                    // the span of a line worth visiting: the support of fA, cut by the support of fB widened by h when that does not wrap
+                    const int NLx = sp.ymode ? N0 : N1;
+                    const double* fa = (sp.ymode ? BS.kbx.data() : BS.kby.data()) + (size_t)sp.fa_line * NLx;
+                    const double* fb = (sp.ymode ? BS.kbx.data() : BS.kby.data()) + (size_t)sp.fb_line * NLx;
+                    int la, ha, lb, hb;
+                    hull(fa, NLx, &la, &ha); hull(fb, NLx, &lb, &hb);
+                    sp.t0 = la & ~3; sp.t1 = std::min(NLx, (ha + 3) & ~3);
+                    if (hb <= lb) sp.t1 = sp.t0;
+                    else if (lb - hO >= 0 && hb + hO <= NLx) { sp.t0 = std::max(sp.t0, (lb - hO) & ~3); sp.t1 = std::min(sp.t1, (hb + hO + 3) & ~3); }
+                    if (sp.t1 < sp.t0) sp.t1 = sp.t0;
+                }
+                sp.patch_off = okey(a, b);                  // (product index for now: turned into the patch offset once the jobs exist)
+                p->sprods.push_back(sp);
+                omg_sparse[okey(a, b)] = 1;
+            }
+        }
         for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) {
+            if (omg_sparse[okey(a, b)]) continue;        // no pass, no partial buffer, no stage-2 job
             if (a != b || !dual_diag) { omg_pass[okey(a, b)] = add_pass(a, b, 0, hO); continue; }
             if (a % 2 == 0 && a + 1 < p->Fij) {          // leader of the pair (a, a + 1)
                 const int lead = add_pass(a, a + 1, 0, hO);
@@ -924,6 +986,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         for (int a = 0; a < p->Fij; ++a) for (int b = a; b < p->Fij; ++b) if (omg_pass[okey(a, b)] >= 0) ++(a == b ? p->n_omg_diag : p->n_omg_off);
         // passes of half width w through greek_g1: Theta, dense Gamma column factors, then the scaling planes' passes
         const int dense0 = (int)p->passes.size();
+        p->n_omg_rec = dense0;
         for (int a = 0; a < p->Fij; ++a) the_pass.push_back(add_pass(a, JP, 0, hG));
         p->n_the = p->Fij;
         p->n_gamp = 0; p->n_gam0 = 0;
@@ -968,6 +1031,67 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         p->fa.sv = (p->mode == 3) ? 1 : 0; p->fa.nsca = nsca;
         p->fa.reg_coef = 0.0; p->fa.ireg = nullptr; p->fa.sst = p->fa.csst = p->fa.dsst = nullptr;
         p->n_patches = poff;
+        if (!p->sprods.empty()) {
+            // y-mode products read image COLUMNS: the few columns involved (candidates and their lag partners) go through a transposed strip
+            std::vector<int> colidx((size_t)N1, -1), cols;
+            for (SparseProd& sp : p->sprods) {
+                sp.patch_off = p->jobs[sp.patch_off].patch_off;
+                if (!sp.ymode) continue;
+                for (int u = -hO; u <= hO; ++u)
+                    for (int k = sp.ustart[u + hO]; k < sp.ustart[u + hO + 1]; ++k)
+                        for (int c0 : {slists[k], slists[k] + u}) {
+                            const int c = c0 < 0 ? c0 + N1 : (c0 >= N1 ? c0 - N1 : c0);
+                            if (colidx[c] < 0) { colidx[c] = (int)cols.size(); cols.push_back(c); }
+                        }
+            }
+            p->n_scols = (int)cols.size();
+            PLAN_TRY(dev_alloc(p, &p->d_sprods, p->sprods.size()));
+            PLAN_HIP(hipMemcpy(p->d_sprods, p->sprods.data(), p->sprods.size() * sizeof(SparseProd), hipMemcpyHostToDevice));
+            std::vector<SparseLine> slines(slists.size());
+            for (const SparseProd& sp : p->sprods) {
+                const int NSx = sp.ymode ? N1 : N0;
+                const double* ta = (sp.ymode ? BS.kby.data() : BS.kbx.data()) + (size_t)sp.fa_cross * NSx;
+                const double* tb = (sp.ymode ? BS.kby.data() : BS.kbx.data()) + (size_t)sp.fb_cross * NSx;
+                for (int u = -hO; u <= hO; ++u)
+                    for (int k = sp.ustart[u + hO]; k < sp.ustart[u + hO + 1]; ++k) {
+                        const int c = slists[k], c1 = c + u, cb = c1 < 0 ? c1 + NSx : (c1 >= NSx ? c1 - NSx : c1);
+                        slines[k].w = ta[c] * tb[cb];
+                        slines[k].a_off = sp.ymode ? (long long)colidx[c] * N0 : (long long)c * N1;
+                        slines[k].b_off = sp.ymode ? (long long)colidx[cb] * N0 : (long long)cb * N1;
+                    }
+            }
+            PLAN_TRY(dev_alloc(p, &p->d_slines, slines.size()));
+            PLAN_HIP(hipMemcpy(p->d_slines, slines.data(), slines.size() * sizeof(SparseLine), hipMemcpyHostToDevice));
+            if (p->n_scols) {
+                PLAN_TRY(dev_alloc(p, &p->d_scols, cols.size()));
+                PLAN_HIP(hipMemcpy(p->d_scols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
+                PLAN_TRY(dev_alloc(p, &p->d_strip, (size_t)p->n_scols * N0));
+            }
+            // The items (product, lag), ordered so that those sharing image rows -- same mode and cross factors -- are neighbours, dealt to the
+            // eight XCDs in contiguous runs of equal cost (lines x span); within a run the costly items first.  Items without lines stay
+            // in (they write the zeros of their patch row).
+            struct Item { int prod, u; long long cost; };
+            std::vector<Item> its;
+            for (size_t i = 0; i < p->sprods.size(); ++i) {
+                const SparseProd& sp = p->sprods[i];
+                for (int u = -hO; u <= hO; ++u) its.push_back({(int)i, u, (long long)(sp.ustart[u + hO + 1] - sp.ustart[u + hO]) * (sp.t1 - sp.t0)});
+            }
+            std::stable_sort(its.begin(), its.end(), [&](const Item& x, const Item& y) {
+                const SparseProd& a = p->sprods[x.prod]; const SparseProd& b = p->sprods[y.prod];
+                return std::make_tuple(a.ymode, a.fa_cross, a.fb_cross) < std::make_tuple(b.ymode, b.fa_cross, b.fb_cross);
+            });
+            long long total = 0;
+            for (const Item& it : its) total += it.cost + 1;
+            std::vector<std::vector<Item>> runs(8);
+            { long long run = 0; for (const Item& it : its) { runs[std::min<long long>(7, run * 8 / total)].push_back(it); run += it.cost + 1; } }
+            size_t per = 0;
+            for (auto& r : runs) { std::stable_sort(r.begin(), r.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; }); per = std::max(per, r.size()); }
+            std::vector<int2> items(8 * per, make_int2(-1, 0));
+            for (int x = 0; x < 8; ++x) for (size_t i = 0; i < runs[x].size(); ++i) items[x * per + i] = make_int2(runs[x][i].prod, runs[x][i].u);
+            p->n_sitems = (int)items.size();
+            PLAN_TRY(dev_alloc(p, &p->d_sitems, items.size()));
+            PLAN_HIP(hipMemcpy(p->d_sitems, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice));
+        }
         (void)PHo; (void)PHg;
         if (p->g1_mfma >= 3 && hO >= 9 && hO <= 32) {
             // Pass groups of the Omega launch (greek_g1_mfma4g): an edge (x, y) with the dual-diagonal pass of the same two planes;
@@ -1313,7 +1437,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -1363,6 +1487,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_G1_MFMA: *v = (p->g1_mfma && 2 * p->w >= 9 && (2 * p->w <= 16 || (2 * p->w <= 32 && p->g1_mfma >= 3 && p->d_groups))) ? 1 : 0; break;
         case SFFT_Q_CHOL_DATAFLOW: *v = (p->dataflow && p->NEQfs < p->chol_outer_min) ? 1 : 0; break;
         case SFFT_Q_SOLVER_N: *v = p->NEQfs; break;
+        case SFFT_Q_OMG_SPARSE: *v = (long long)p->sprods.size(); break;
         default: return set_err(SFFT_ERR_INVALID_ARG, "unknown query field");
     }
     return SFFT_OK;
@@ -2072,9 +2197,16 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     }
     {
         StageTimer t(p, SFFT_ST_GREEK_G1B, s);
+        if (!p->sprods.empty()) {      // Omega products of (nearly) disjoint basis terms: real-space correlations of a few image rows / columns
+            const int hO = 2 * p->w;
+            if (p->n_scols) SFFT_LAUNCH(gather_cols, dim3((p->n_scols + 63) / 64, (p->N0 + 3) / 4), dim3(256), 0, s, d_I, p->d_scols, p->n_scols, p->d_strip, p->N0, p->N1);
+            SFFT_LAUNCH(omega_sparse, dim3((unsigned)p->n_sitems), dim3(OSP_NT), 0, s, d_I, p->d_strip, p->d_sprods, p->d_slines, p->d_sitems,
+                        p->d_kbx, p->d_kby, p->N0, p->N1, hO, p->scale * p->scale * p->scale, p->d_patches);
+            LAUNCH_CHECK();
+        }
         {
             const int fused = ((p->theta_in_groups || p->theta_slots) && p->g1_mfma >= 3) ? p->n_the_fused : 0;      // (the rest: a vector launch of their own)
-            if (fused < p->n_dense_w && (rc = greek_g1_group(p, p->n_omg + fused, p->n_dense_w - fused, p->w, s))) return rc;
+            if (fused < p->n_dense_w && (rc = greek_g1_group(p, p->n_omg_rec + fused, p->n_dense_w - fused, p->w, s))) return rc;
         }
         if (p->gamma_analytic && !gamma_aside) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
@@ -2093,7 +2225,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         }
         if (p->n_row0 > 0) {
             SFFT_LAUNCH(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_row0), dim3(256), 0, s, p->d_spec, p->d_passes,
-                               p->n_omg + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->lay, p->S);
+                               p->n_omg_rec + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->lay, p->S);
             LAUNCH_CHECK();
         }
     }

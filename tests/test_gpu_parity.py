@@ -798,6 +798,48 @@ def test_bspline_mixed_domain_apply_equals_fourier_apply(dev, shape, w, deg, nk,
     assert rms(ga - gb) <= 1e-11 * rms(pair["SCI"])
 
 
+@pytest.mark.parametrize("shape,w,deg,nk", [((256, 200), 4, 2, 2), ((320, 264), 8, 2, 3), ((1024, 2560), 8, 2, 2), ((2304, 512), 6, 1, 3), ((128, 64), 3, 3, 4)])
+def test_bspline_sparse_omega_equals_transformed_omega(dev, shape, w, deg, nk):
+    """Omega products of B-spline terms whose row (or column) factors have disjoint supports are summed in real space (omega_sparse:
+    a few 1-D correlations of image rows / columns, greek.hpp) instead of through the transforms.  Same linear system to rounding and
+    the same result as with every product transformed (SFFT_NO_OMG_SPARSE=1); the plan reports how many products took the short
+    cut.  Shapes: one step per line, lines of several steps (2560 > OSP_CH = 2008), many knots, a line barely longer than the halo."""
+    import sfft_amd.BSplineSFFT as B
+    from sfft_amd.utils.synthetic import make_pair
+    N0, N1 = shape
+    pair = make_pair(N0, N1, seed=11 + w, mask=True)
+    kx = [N0 * (k + 1) / (nk + 1) + 0.5 for k in range(nk)]
+    ky = [N1 * (k + 1) / (nk + 1) + 0.5 for k in range(nk)]
+    outs = []
+    for dense in (False, True):
+        B._PLANS.clear()
+        if dense:
+            os.environ["SFFT_NO_OMG_SPARSE"] = "1"
+        try:
+            cfg = B.SingleSFFTConfigure.SSC(NX=N0, NY=N1, KerHW=w, KerSpType="B-Spline", KerSpDegree=deg, KerIntKnotX=kx, KerIntKnotY=ky,
+                                            SEPARATE_SCALING=True, ScaSpDegree=0, BkgSpType="Polynomial", BkgSpDegree=1, VERBOSE_LEVEL=0,
+                                            CUDA_DEVICE_4SUBTRACT=dev.index)
+            plan = next(iter(B._PLANS.values()))
+            nsp = plan.query("OMG_SPARSE")
+            try:
+                d2 = np.asarray(B.GeneralSFFTSubtract.GSS(pair["REF"], pair["SCI"], pair["mREF"], pair["mSCI"], cfg, VERBOSE_LEVEL=0)[1])
+            except np.linalg.LinAlgError:       # (many knots on a small masked image: a term without unmasked support; the systems are still compared)
+                d2 = None
+                assert nk >= 3
+            LH, rhs = plan.get_system()
+        finally:
+            os.environ.pop("SFFT_NO_OMG_SPARSE", None)
+        outs.append((d2, LH.cpu().numpy(), rhs.cpu().numpy(), nsp))
+    B._PLANS.clear()
+    (da, La, ra, na), (db, Lb, rb, nb) = outs
+    assert nb == 0 and na > 0, (na, nb)
+    assert np.max(np.abs(La - Lb)) <= 1e-11 * np.max(np.abs(Lb))
+    assert np.max(np.abs(ra - rb)) <= 1e-11 * np.max(np.abs(rb))
+    assert (da is None) == (db is None)
+    if da is not None:
+        assert rms(da - db) <= 1e-7 * rms(pair["SCI"])
+
+
 # ------------------------------------------------------------------------------------------------
 # (e2) separately varying scaling + kernel regularisation (BSplineSFFT.py SCALING_MODE 'SEPARATE-VARYING', REGULARIZE_KERNEL).
 # The reference has no CPU code for these: the comparison is oracle/bspline_sv_oracle.py (pinned by the reference's NIRCam golden for the
