@@ -1986,8 +1986,8 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
             }
             ++outer;
             const int r0 = kb + OB;
-            const int nt = (n + 1 - r0 + SYRK_T - 1) / SYRK_T;
-            SFFT_LAUNCH(chol_syrk, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
+            const int nt = (n + 1 - r0 + 63) / 64;
+            SFFT_LAUNCH(chol_syrk<64>, dim3(nt, nt), dim3(256), 0, s, p->d_A, p->ld, n, kb, OB, r0, 0);
             kb = r0;
             // chol_panel takes its diagonal block from the hand-over buffer, chol_panel4 from the matrix itself: the copy is only needed
             // when the next panel is a chol_panel launch (the last outer block's successor, or a block column too tall for chol_panel4)

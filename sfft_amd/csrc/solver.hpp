@@ -1164,27 +1164,32 @@ __global__ void __launch_bounds__(256) chol_panel4(double* __restrict__ A, int l
 // With rank-64 updates every step reads and writes the whole trailing matrix: n^3 / 24 bytes in total (31 GB at n = 7231,
 // 12 ms).  For large n the factorisation therefore works on outer blocks of 256 columns: the four inner steps only update
 // the columns of their own outer block, and the rest of the trailing matrix receives all four panels at once from this
-// kernel: C -= L_K L_K^T with K = 256, 128 x 128 tiles on the matrix cores (one 64 x 64 quadrant per wave, sixteen 16 x 16
+// kernel: C -= L_K L_K^T with K = 256, 64 x 64 tiles on the matrix cores (one 32 x 32 quadrant per wave, four 16 x 16
 // accumulators per lane), the panels staged through LDS sixteen columns at a time with the next chunk's loads in flight.
-#define SYRK_T 128
 #define SYRK_KC 16
 #define SYRK_S (SYRK_KC + 4)
-// tj0: first tile column of this launch
+// tj0: first tile column of this launch.  TS = tile side.  Rounds 2 - 3 ran 128 x 128 tiles (half the LDS reads per matrix
+// instruction): such a tile alone on a CU takes 62 us however few of them a launch has, two sharing a CU 90 us, and only two fit.
+// 64 x 64 tiles (20 KB of LDS, eight workgroups per CU) are faster for EVERY outer block of configs 3 and 5: solve 7.42 -> 6.29 ms at
+// n = 7207, 6.18 -> 5.42 ms at n = 6251 (round 4; thresholds in between were in between).
+template <int TS>
 __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int ld, int n, int K0, int KB, int r0, int tj0)
 {
+    constexpr int NQ = TS / 32;             // 16 x 16 accumulators per wave and dimension (the wave's quadrant is TS / 2 square)
+    constexpr int NU = TS / 32;             // staging rows per thread
     const int ti = blockIdx.y, tj = blockIdx.x + tj0;
     if (tj > ti) return;
-    __shared__ double Li[SYRK_T][SYRK_S];
-    __shared__ double Lj[SYRK_T][SYRK_S];
+    __shared__ double Li[TS][SYRK_S];
+    __shared__ double Lj[TS][SYRK_S];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int wr = wv >> 1, wc = wv & 1;
-    const int i0 = r0 + ti * SYRK_T, j0 = r0 + tj * SYRK_T;
-    // staging: thread loads rows (tid >> 3) + 32 u, u < 4, columns 2 (tid & 7) .. + 1 of the chunk, for both panels
+    const int i0 = r0 + ti * TS, j0 = r0 + tj * TS;
+    // staging: thread loads rows (tid >> 3) + 32 u, u < NU, columns 2 (tid & 7) .. + 1 of the chunk, for both panels
     const int sr = tid >> 3, sc = 2 * (tid & 7);
-    double2 pi[4], pj[4];
+    double2 pi[NU], pj[NU];
     auto fetch = [&](int kc) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int ri = i0 + sr + 32 * u, rj = j0 + sr + 32 * u;
             const double2 qi = *reinterpret_cast<const double2*>(A + (size_t)min(ri, n) * ld + K0 + kc + sc);      // (clamped, then masked)
             const double2 qj = *reinterpret_cast<const double2*>(A + (size_t)min(rj, n) * ld + K0 + kc + sc);
@@ -1192,16 +1197,16 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
             pj[u] = (rj < n) ? qj : make_double2(0.0, 0.0);
         }
     };
-    d4s c[4][4];
+    d4s c[NQ][NQ];
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < NQ; ++it)
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) c[it][jt] = (d4s){0.0, 0.0, 0.0, 0.0};
+        for (int jt = 0; jt < NQ; ++jt) c[it][jt] = (d4s){0.0, 0.0, 0.0, 0.0};
     fetch(0);
     for (int kc = 0; kc < KB; kc += SYRK_KC) {
         __syncthreads();                    // the previous chunk has been consumed
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             Li[sr + 32 * u][sc] = pi[u].x; Li[sr + 32 * u][sc + 1] = pi[u].y;
             Lj[sr + 32 * u][sc] = pj[u].x; Lj[sr + 32 * u][sc + 1] = pj[u].y;
         }
@@ -1209,35 +1214,35 @@ __global__ void __launch_bounds__(256, 2) chol_syrk(double* __restrict__ A, int 
         if (kc + SYRK_KC < KB) fetch(kc + SYRK_KC);
 #pragma unroll
         for (int ks = 0; ks < SYRK_KC / 4; ++ks) {
-            double a[4], b[4];
+            double a[NQ], b[NQ];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = Li[64 * wr + 16 * t + ln][4 * ks + lk];
-                b[t] = Lj[64 * wc + 16 * t + ln][4 * ks + lk];
+            for (int t = 0; t < NQ; ++t) {
+                a[t] = Li[(TS / 2) * wr + 16 * t + ln][4 * ks + lk];
+                b[t] = Lj[(TS / 2) * wc + 16 * t + ln][4 * ks + lk];
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
+            for (int it = 0; it < NQ; ++it)
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) c[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], c[it][jt], 0, 0, 0);
+                for (int jt = 0; jt < NQ; ++jt) c[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], c[it][jt], 0, 0, 0);
         }
     }
-    // read-modify-write of the tile, 16 elements at a time: all 16 loads first (written as `A[..] -= c` the compiler orders
+    // read-modify-write of the tile, 4 NQ elements at a time: all loads first (written as `A[..] -= c` the compiler orders
     // every load behind the previous store -- 64 dependent round trips per thread)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        double oldv[4][4];
+    for (int it = 0; it < NQ; ++it) {
+        double oldv[NQ][4];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < NQ; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + 64 * wr + 16 * it + (lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
+                const int i = i0 + (TS / 2) * wr + 16 * it + (lk + 4 * q), j = j0 + (TS / 2) * wc + 16 * jt + ln;
                 oldv[jt][q] = (i <= n && j < n && j <= i) ? A[(size_t)i * ld + j] : 0.0;
             }
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < NQ; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + 64 * wr + 16 * it + (lk + 4 * q), j = j0 + 64 * wc + 16 * jt + ln;
+                const int i = i0 + (TS / 2) * wr + 16 * it + (lk + 4 * q), j = j0 + (TS / 2) * wc + 16 * jt + ln;
                 if (i <= n && j < n && j <= i) A[(size_t)i * ld + j] = oldv[jt][q] - c[it][jt][q];
             }
     }
