@@ -425,11 +425,15 @@ __global__ void __launch_bounds__(256, ((DK <= 2 || W > 8) ? 2 : 3)) vconv_mixed
 // kernel).  Same walk as vconv_mixed2 -- two source rows per table read, a sliding window of L + 1 accumulators -- with
 // E_jj = sum_ii bx_ii[y] C'_(ii,jj)[a] over all NI row factors (no factor is identically one here).  A wave is CT columns x 64 / CT
 // row streams; CT = 8 keeps the NI NJ L CT table of a workgroup at 54 KB for 5 x 5 terms (two workgroups per CU).
-template <int NI, int NJ, int W, int CT>
+// NA < NI: at most NA CONSECUTIVE row factors are nonzero on any row (B-splines of degree NA - 1), the first of them listed per row in
+// `ibase`: the sum over ii runs over those only -- 3 x 4 + 8 instead of 5 x 4 + 8 multiply-adds per (tap, column factor, row pair) for
+// the 5 x 5 quadratic basis of config 3.  The two rows of a step have a base each (they differ at a knot).
+template <int NI, int NJ, int W, int CT, int NA = NI>
 __global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ stage, cplx* __restrict__ D, const cplx* __restrict__ Ctab,
-                                                       const double* __restrict__ kbx, int N0, int Nh, int Nhp, SpecLayout lay,
-                                                       cplx* __restrict__ trash, int R)
+                                                       const double* __restrict__ kbx, const int* __restrict__ ibase, int N0, int Nh, int Nhp,
+                                                       SpecLayout lay, cplx* __restrict__ trash, int R)
 {
+    constexpr bool SPARSE = NA < NI;
     constexpr int L = 2 * W + 1, FIJ = NI * NJ, SPW = 64 / CT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* ctab = reinterpret_cast<cplx*>(smem_raw);
@@ -455,7 +459,8 @@ __global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ 
     // the two source rows of a step (and their row factors) are fetched ONE STEP AHEAD, as in vconv_mixed2: at two waves per SIMD a trip
     // to HBM at the top of every step is not hidden (round 4: 1.9 ms at config 3 with the loads at the top of the step)
     cplx S0[NJ], S1[NJ], T0[NJ], T1[NJ];
-    double f0[NI], f1[NI], g0[NI], g1[NI];
+    double f0[NA], f1[NA], g0[NA], g1[NA];
+    int nb0 = 0, nb1 = 0;                       // first row factor of the prefetched rows
     {
         const int y1 = (y + 1 == N0) ? 0 : y + 1;
 #pragma unroll
@@ -463,10 +468,11 @@ __global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ 
             T0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
             T1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
         }
+        if (SPARSE) { nb0 = ibase[y]; nb1 = ibase[y1]; }
 #pragma unroll
-        for (int ii = 0; ii < NI; ++ii) {
-            g0[ii] = kbx[(size_t)ii * N0 + y];
-            g1[ii] = kbx[(size_t)ii * N0 + y1];
+        for (int ii = 0; ii < NA; ++ii) {
+            g0[ii] = kbx[(size_t)(nb0 + ii) * N0 + y];
+            g1[ii] = kbx[(size_t)(nb1 + ii) * N0 + y1];
         }
         y = (y1 + 1 == N0) ? 0 : y1 + 1;
     }
@@ -474,21 +480,23 @@ __global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ 
     for (int sI = 0; sI < NSRC; sI += 2) {
         int opq;
         asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
-        const cplx* __restrict__ ct = ctab + cl + opq;
+        const cplx* __restrict__ ct = ctab + cl + opq + nb0 * (NJ * L * CT);
+        const cplx* __restrict__ ct1 = ctab + cl + opq + nb1 * (NJ * L * CT);
         const int y1 = (y + 1 == N0) ? 0 : y + 1;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) { S0[jj] = T0[jj]; S1[jj] = T1[jj]; }
 #pragma unroll
-        for (int ii = 0; ii < NI; ++ii) { f0[ii] = g0[ii]; f1[ii] = g1[ii]; }
+        for (int ii = 0; ii < NA; ++ii) { f0[ii] = g0[ii]; f1[ii] = g1[ii]; }
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {       // (the rows after the last step's are read and dropped: any row index is valid)
             T0[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y * rs];
             T1[jj] = stage[(size_t)jj * plane_sz + mo + (size_t)y1 * rs];
         }
+        if (SPARSE) { nb0 = ibase[y]; nb1 = ibase[y1]; }
 #pragma unroll
-        for (int ii = 0; ii < NI; ++ii) {
-            g0[ii] = kbx[(size_t)ii * N0 + y];
-            g1[ii] = kbx[(size_t)ii * N0 + y1];
+        for (int ii = 0; ii < NA; ++ii) {
+            g0[ii] = kbx[(size_t)(nb0 + ii) * N0 + y];
+            g1[ii] = kbx[(size_t)(nb1 + ii) * N0 + y1];
         }
 #pragma unroll
         for (int q = 0; q < L; ++q) {           // tap a = q - W
@@ -498,10 +506,11 @@ __global__ void __launch_bounds__(256, 2) vconv_tensor(const cplx* __restrict__ 
             for (int jj = 0; jj < NJ; ++jj) {
                 double ex = 0.0, ey = 0.0, gx = 0.0, gy = 0.0;
 #pragma unroll
-                for (int ii = 0; ii < NI; ++ii) {
+                for (int ii = 0; ii < NA; ++ii) {
                     const cplx c = ct[((ii * NJ + jj) * L + q) * CT];
+                    const cplx d = SPARSE ? ct1[((ii * NJ + jj) * L + q) * CT] : c;
                     ex = fma(f0[ii], c.x, ex); ey = fma(f0[ii], c.y, ey);
-                    gx = fma(f1[ii], c.x, gx); gy = fma(f1[ii], c.y, gy);
+                    gx = fma(f1[ii], d.x, gx); gy = fma(f1[ii], d.y, gy);
                 }
                 ax = fma(S0[jj].x, ex, fma(-S0[jj].y, ey, ax));
                 ay = fma(S0[jj].x, ey, fma(S0[jj].y, ex, ay));

@@ -193,6 +193,7 @@ struct sfft_plan {
     double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
     // mixed-domain apply (polynomial kernels on the staged fast path, KerHW <= 8): no column transforms in the apply pass
+    int vt_na = 0; int* d_ibase = nullptr;     // vconv_tensor: at most vt_na consecutive row factors are nonzero on a row, the first listed per row (0: all factors)
     int vtensor = 0, vncf = 0;          // vtensor = n: n x n tensor basis through vconv_tensor; vncf = stage planes (column factors) of the mixed-domain apply
     int use_vconv = 0, vw = 8;          // vw = compile-time half width the tables are padded to (4, 8 or 12)
     bool staged_solve = false;          // the solve pass leaves the stage planes of I first in d_stage (4096^2 fast path)
@@ -756,6 +757,21 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                 p->vw = KerHW <= 4 ? 4 : 8;
                 PLAN_TRY(dev_alloc(p, &p->d_stage_a, (size_t)p->vncf * N0 * p->Nhp));
                 PLAN_TRY(dev_alloc(p, &p->d_ctabm, (size_t)p->Fij * (2 * p->vw + 1) * p->Nhp + 256));
+                // quadratic B-splines: three consecutive row factors per row (vconv_tensor's NA); anything wider sums over all of them
+                std::vector<int> ibase((size_t)N0, 0);
+                int span = 0;
+                for (int l = 0; l < N0; ++l) {
+                    int lo = BS.nkx, hi = -1;
+                    for (int i = 0; i < BS.nkx; ++i) if (BS.kbx[(size_t)i * N0 + l] != 0.0) { lo = std::min(lo, i); hi = std::max(hi, i); }
+                    if (hi < 0) { lo = 0; hi = 0; }
+                    span = std::max(span, hi - lo + 1);
+                    ibase[l] = std::min(lo, BS.nkx - 3);
+                }
+                if (span <= 3 && BS.nkx > 3 && !getenv("SFFT_NO_VT_SPARSE")) {
+                    p->vt_na = 3;
+                    PLAN_TRY(dev_alloc(p, &p->d_ibase, ibase.size()));
+                    PLAN_HIP(hipMemcpy(p->d_ibase, ibase.data(), ibase.size() * sizeof(int), hipMemcpyHostToDevice));
+                }
             }
         }
     }
@@ -1437,7 +1453,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_ibase, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
@@ -2305,10 +2321,11 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
             dim3 gt(ntile_t, (nstr + 31) / 32);
             const size_t ldst = (size_t)p->Fij * LT * CT * sizeof(cplx);
             cplx* trash = p->d_ctabm + (size_t)p->Fij * LT * p->Nhp;
-#define VT_LAUNCH(NN, WT) do { \
-            HIPCHK(hipFuncSetAttribute((const void*)vconv_tensor<NN, NN, WT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            SFFT_LAUNCH((vconv_tensor<NN, NN, WT, CT>), gt, dim3(256), ldst, s, FI, FD, p->d_ctabm, p->d_kbx, p->N0, p->Nh, p->Nhp, p->lay, trash, Rt); } while (0)
-#define VT_W(NN) do { if (p->vw == 4) VT_LAUNCH(NN, 4); else VT_LAUNCH(NN, 8); } while (0)
+#define VT_LAUNCH(NN, WT, NA) do { \
+            HIPCHK(hipFuncSetAttribute((const void*)vconv_tensor<NN, NN, WT, CT, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            SFFT_LAUNCH((vconv_tensor<NN, NN, WT, CT, NA>), gt, dim3(256), ldst, s, FI, FD, p->d_ctabm, p->d_kbx, p->d_ibase, p->N0, p->Nh, p->Nhp, p->lay, trash, Rt); } while (0)
+#define VT_W(NN) do { if (p->vt_na == 3) { if (p->vw == 4) VT_LAUNCH(NN, 4, 3); else VT_LAUNCH(NN, 8, 3); } \
+                      else { if (p->vw == 4) VT_LAUNCH(NN, 4, NN); else VT_LAUNCH(NN, 8, NN); } } while (0)
             switch (p->vtensor) { case 4: VT_W(4); break; case 5: VT_W(5); break; default: VT_W(6); break; }
 #undef VT_W
 #undef VT_LAUNCH
