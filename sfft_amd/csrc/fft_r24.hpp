@@ -195,8 +195,10 @@ __device__ __forceinline__ void fft_r24_front(cplx (&u)[16], cplx (&xin)[24], in
 // (The four writers of a 64-byte row piece are different workgroups; their dirty lines -- 6 MB in flight per XCD -- leave the 4 MB
 // L2 before they are complete: 13.8 GB written for 7.55 GB of spectra at config 3, PMC WRITE_SIZE.  Two panel neighbours per
 // 768-thread workgroup, i.e. whole 32-byte sectors, measured SLOWER: 4.31 against 4.10 ms, 52.9 against 56.0 pairs/s -- one workgroup
-// per CU instead of two.  The lane-quad scheme of cols_fwd_weighted_4096_q needs two parked columns per thread: 192 registers at
-// twelve waves per workgroup.  docs/LOG.md, round 4.)
+// per CU instead of two.  A bounded meeting of the four writers before their store phase -- one arrival counter per panel -- brought
+// the writes to 7.70 GB and the kernel from 4.31 to 4.52 ms: the extra bytes are NOT what this kernel waits for (150 rounds of two
+// workgroups per CU at ~27 us each: latency, twelve waves per CU).  The lane-quad scheme of cols_fwd_weighted_4096_q needs two parked
+// columns per thread: 192 registers at twelve waves per workgroup.  docs/LOG.md, round 4.)
 template <int Q>
 __global__ void __launch_bounds__(24 * Q) cols_fwd_weighted_r24(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int ncols,
                                                                 int Nhp, SpecLayout lay, const cplx* __restrict__ tw)
