@@ -191,27 +191,31 @@ __device__ __forceinline__ void fft_r24_front(cplx (&u)[16], cplx (&xin)[24], in
 }
 
 // Forward column pass of the weighted planes for N0 = 384 Q (see cols_fwd_weighted: same arguments, same XCD-aware order -- on one
-// XCD the eight columns that share 128-byte lines, then the next output of the same column group).  One column per workgroup.
-// (The four writers of a 64-byte row piece are different workgroups; their dirty lines -- 6 MB in flight per XCD -- leave the 4 MB
-// L2 before they are complete: 13.8 GB written for 7.55 GB of spectra at config 3, PMC WRITE_SIZE.  Two panel neighbours per
-// 768-thread workgroup, i.e. whole 32-byte sectors, measured SLOWER: 4.31 against 4.10 ms, 52.9 against 56.0 pairs/s -- one workgroup
-// per CU instead of two.  A bounded meeting of the four writers before their store phase -- one arrival counter per panel -- brought
-// the writes to 7.70 GB and the kernel from 4.31 to 4.52 ms: the extra bytes are NOT what this kernel waits for (150 rounds of two
-// workgroups per CU at ~27 us each: latency, twelve waves per CU).  The lane-quad scheme of cols_fwd_weighted_4096_q needs two parked
-// columns per thread: 192 registers at twelve waves per workgroup.  docs/LOG.md, round 4.)
-template <int Q>
-__global__ void __launch_bounds__(24 * Q) cols_fwd_weighted_r24(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int ncols,
-                                                                int Nhp, SpecLayout lay, const cplx* __restrict__ tw)
+// XCD the eight columns that share 128-byte lines, then the next output of the same column group).
+// History of the one-column form at config 3 (docs/LOG.md, round 4): 13.8 GB written for 7.55 GB of spectra (the four 16-byte writers
+// of a 64-byte piece are sibling workgroups whose lines leave L2 incomplete) -- yet a bounded meeting of the siblings before their
+// store phase, which brought the writes to 7.7 GB, made the kernel SLOWER (4.31 -> 4.52 ms), and so did two columns per workgroup in
+// separate waves (4.31 vs 4.10).  What it waits for is the rate of its 16-byte requests.
+// NC = 2 (6144 points): two panel neighbours per workgroup in NEIGHBOURING LANES (lane parity = column, team thread = lane >> 1), so
+// that every load / store instruction moves 32 contiguous bytes per lane pair: half the requests of the one-column form, which is
+// bound by the RATE of its 16-byte requests (64 distinct 64-byte pieces per wave instruction), not by bytes.  Each team has its own
+// LDS region, 16 doubles out of phase with the other's so that the lane pairs of a half-wave fall into complementary banks.
+template <int Q, int NC = 1>
+__global__ void __launch_bounds__(24 * Q * NC) cols_fwd_weighted_r24(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int ncols,
+                                                                     int Nhp, SpecLayout lay, const cplx* __restrict__ tw)
 {
     typedef R24<Q> F;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* lds = reinterpret_cast<double*>(smem_raw);
     constexpr int N0 = F::N;
-    const int j = threadIdx.x;
+    const int c = NC > 1 ? (int)(threadIdx.x & (NC - 1)) : 0;
+    const int j = (int)threadIdx.x / NC;
+    double* lds = reinterpret_cast<double*>(smem_raw) + c * (F::LDS + 16);
     const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
-    const int gq = t & 7, o = (t >> 3) % g.nout, tg = (t >> 3) / g.nout;
-    const int col = (tg * 8 + xcd) * 8 + gq;
-    if (col >= ncols) return;
+    constexpr int GW = 8 / NC;                                   // workgroups per 8-column group
+    const int gq = (t % GW) * NC + c, o = (t / GW) % g.nout, tg = (t / GW) / g.nout;
+    const int col0 = (tg * 8 + xcd) * 8 + gq;
+    if (NC == 1 && col0 >= ncols) return;
+    const int col = NC == 1 ? col0 : min(col0, ncols - 1);       // (a column past the end repeats the last one and is not stored: the teams share barriers)
     const size_t plane_sz = (size_t)N0 * Nhp, cofs = lay.col(col), rs = (size_t)lay.rstride;
     const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * plane_sz + cofs;
     const double* __restrict__ w = g.wx[o];
@@ -229,9 +233,10 @@ __global__ void __launch_bounds__(24 * Q) cols_fwd_weighted_r24(const cplx* __re
         u[r] = make_double2(z.x * f, z.y * f);
     }
     cplx xin[24];
-    const bool act = F::stage3_wave();
-    fft_r24_front<Q>(u, xin, j, F::stage2_wave(), act, lds, tw);
-    if (!act) return;
+    const int wv = __builtin_amdgcn_readfirstlane(j >> 6);      // wave of the team's thread numbering (uniform: a wave holds 64 / NC consecutive j)
+    const bool act = wv < F::NQ / 64, act2 = Q == 16 || wv < 6;
+    fft_r24_front<Q>(u, xin, j, act2, act, lds, tw);
+    if (!act || col0 >= ncols) return;
     cplx* __restrict__ dst = out + (size_t)g.out_plane[o] * plane_sz + cofs;
     twiddle24(xin, tw, j);
     cplx G[3][8];
@@ -239,7 +244,7 @@ __global__ void __launch_bounds__(24 * Q) cols_fwd_weighted_r24(const cplx* __re
 #pragma unroll
     for (int d = 0; d < 8; ++d)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { cplx* __restrict__ dr = dst + (size_t)(F::NQ * (d + 8 * c)) * rs; *at_byte(dr, jo) = dft24_x(G, d, c); }
+        for (int cc = 0; cc < 3; ++cc) { cplx* __restrict__ dr = dst + (size_t)(F::NQ * (d + 8 * cc)) * rs; *at_byte(dr, jo) = dft24_x(G, d, cc); }
 }
 
 // rows, real -> half complex (N1 = 384 Q), two image rows per transform, spatial factors fused (see rows_r2c_4096 for the arguments).

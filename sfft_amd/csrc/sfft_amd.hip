@@ -254,6 +254,7 @@ struct sfft_plan {
     int theta_slots = 0;                // 1: half width 9 .. 16 (KerHW 9 .. 16): the Theta passes as ordinary slots in groups of their own behind the Omega groups
     int n_groups_omg = 0;               //    (first launch only: n_groups counts them, n_groups_omg does not; env SFFT_THETA_SLOTS=0: a launch of their own)
     int rows_r24 = 0;                   // 16 / 24: 6144- / 9216-point row axis on the register-resident kernels of fft_r24.hpp (env SFFT_NO_ROWS_R24=1: the generic pass, A/B)
+    bool cols_r24_pair = true;          // 6144-point columns: two panel neighbours per workgroup in neighbouring lanes (env SFFT_COLS_R24_PAIR=0: one column)
     int cols_r24 = 0;                   // the same for the column axis (env SFFT_NO_COLS_R24=1)
     int no_wx_support = 0;              // env SFFT_NO_WX_SUPPORT=1: the generic weighted column pass reads rows whose row factor is zero too (A/B)
     std::vector<int> kbx_lo, kbx_hi;    // [nkx] first row / one past the last row where the kernel row factor is nonzero
@@ -783,9 +784,12 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     auto r24_q = [](const AxisHost& ax) { return (ax.big || ax.blue) ? 0 : ax.M == 6144 ? 16 : ax.M == 9216 ? 24 : 0; };
     p->rows_r24 = (p->no_fast_fft || getenv("SFFT_NO_ROWS_R24")) ? 0 : r24_q(p->ax1);
     p->cols_r24 = (p->no_fast_fft || getenv("SFFT_NO_COLS_R24")) ? 0 : r24_q(p->ax0);
+    if (const char* e = getenv("SFFT_COLS_R24_PAIR")) p->cols_r24_pair = atoi(e) != 0;
+    if (p->lay.mask < 1) p->cols_r24_pair = false;          // (row-major planes: neighbouring columns are not neighbours in memory)
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_r24<24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_r24<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!p->ax0.big) {
         pick_col_tile(p->ax0, &p->TC, &p->MS);
         p->nt_cols = fft_threads(p->TC * p->ax0.M);
@@ -1753,7 +1757,10 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
             if (p->cols_r24) {     // register-resident 6144- / 9216-point columns, one per workgroup, 64 columns per (XCD-interleaved) column group
                 const dim3 grid(64 * g.nout * ((p->Nh + 63) / 64));
-                if (p->cols_r24 == 16)
+                if (p->cols_r24 == 16 && p->cols_r24_pair)        // two panel neighbours per workgroup, in neighbouring lanes
+                    SFFT_LAUNCH((cols_fwd_weighted_r24<16, 2>), dim3(grid.x / 2), dim3(2 * R24<16>::NT), (2 * R24<16>::LDS + 16) * sizeof(double), s,
+                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
+                else if (p->cols_r24 == 16)
                     SFFT_LAUNCH(cols_fwd_weighted_r24<16>, grid, dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s,
                                        p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
                 else

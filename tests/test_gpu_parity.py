@@ -1289,6 +1289,9 @@ def test_r24_axis_kernels_agree_with_generic_passes(dev, shape):
     assert np.max(np.abs(new[2] - old[2])) <= 1e-11 * np.max(np.abs(old[2]))
     assert np.max(np.abs(new[3] - old[3])) <= 1e-11 * np.max(np.abs(old[3]))
     assert rms(new[1] - old[1]) <= 1e-7 * rms(old[1])
+    if shape[0] == 6144:     # the 6144-point column kernel runs two columns per workgroup (neighbouring lanes); one column per workgroup is the same arithmetic
+        one = _subtract_with_env(dev, {"SFFT_COLS_R24_PAIR": "0"}, shape, w, 2, 1, pair)
+        assert np.array_equal(new[2], one[2]) and np.array_equal(new[1], one[1])
 
 
 @pytest.mark.parametrize("shape,w,DK", [((256, 288), 8, 2), ((320, 4096), 8, 2), ((512, 384), 5, 3), ((384, 96), 12, 3)])
