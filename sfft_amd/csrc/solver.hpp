@@ -1327,14 +1327,9 @@ __global__ void __launch_bounds__(256) chol_back_all(const double* __restrict__ 
         }
     }
     double acc = 0.0;                                   // threads tid < 64: sum_c (L_cb^T x_c)[tid]
+    const double yb = (tid < nb) ? A[(size_t)n * ld + kb + tid] : 0.0;      // (fetched before the chain, not on it)
     for (int c = nblk - 1; c > b; --c) {
-        if (tid == 0) {      // bounded spin, as in chol_step
-            long long spins = 0;
-            while (__hip_atomic_load(&flags[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1LL << 26)) { atomicOr(status, 4); break; }
-            }
-        }
+        if (tid == 0) { df_poll(flags, c, epoch, status); df_acquire(); }      // relaxed polls, one acquire (bounded: reports, never hangs)
         __syncthreads();
         const int kc = c * CB, nc = min(CB, n - kc);
         if (tid < CB) xs[tid] = tid < nc ? __hip_atomic_load(&xv[kc + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
@@ -1352,18 +1347,19 @@ __global__ void __launch_bounds__(256) chol_back_all(const double* __restrict__ 
         if (tid < CB) acc += red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     }
     __syncthreads();
-    if (tid < CB) xs[tid] = tid < nb ? A[(size_t)n * ld + kb + tid] - acc : 0.0;       // y_b - strip products
+    if (tid < CB) xs[tid] = tid < nb ? yb - acc : 0.0;                                  // y_b - strip products
     __syncthreads();
     double ps = 0.0;
 #pragma unroll 4
     for (int i = gg; i < CB; i += 4) ps = fma(Wb[i][jj], xs[i], ps);                   // x_b = W_b^T rhs
     red[gg][jj] = ps;
     __syncthreads();
-    if (tid < nb) __hip_atomic_store(&xv[kb + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        __hip_atomic_store(&flags[b], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // publish as chol_dataflow does: write-through stores by the first wave, drained, then one relaxed flag store by its first lane
+    // (a fence + release store here cost ~1 us of the 3.5 us a block spends on the chain)
+    if (tid < CB) {
+        if (tid < nb) __hip_atomic_store(&xv[kb + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_store(&flags[b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
