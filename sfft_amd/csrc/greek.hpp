@@ -680,8 +680,9 @@ __global__ void __launch_bounds__(256) gather_cols(const double* __restrict__ I,
 #define OSP_SW 2                        // sweeps per step: a thread owns four consecutive positions per sweep
 #define OSP_HP 16                       // lag half width, padded
 #define OSP_NG (OSP_NT * OSP_SW)        // groups of four window positions per step = one buffer's groups (two per thread)
-#define OSP_CH (4 * OSP_NG - 2 * OSP_HP - 8)       // line positions per step (2008): its window with both halos fills the OSP_NG groups
-#define OSP_PL (OSP_NG + (2 * OSP_HP + 8) / 4)     // slots per plane: masked threads' windows reach past the groups (zeros, written once)
+#define OSP_CH (4 * OSP_NG)                        // line positions per step (2048: spans are mostly multiples of it -- with 2008 a third of the steps carried 40 .. 120 positions)
+#define OSP_NT_TAIL (2 * OSP_HP + 8)               // window positions behind the OSP_NG groups (the far halo and the reach of the last windows): one per thread tid < 40
+#define OSP_PL (OSP_NG + OSP_NT_TAIL / 4)          // slots per plane
 struct __attribute__((aligned(8))) OspD4 { double v[4]; };     // (image rows of a caller's array: 8-byte alignment is all that is promised)
 
 __global__ void __launch_bounds__(OSP_NT, 2) omega_sparse(const double* __restrict__ I, const double* __restrict__ strip,
@@ -693,7 +694,7 @@ __global__ void __launch_bounds__(OSP_NT, 2) omega_sparse(const double* __restri
     // the partner window in FOUR interleaved planes -- window position p sits at plane p & 3, slot p >> 2 -- so that the lanes of a wave,
     // whose windows start four positions apart, read consecutive slots of one plane (with the window stored contiguously every read was
     // an eight-way bank conflict)
-    __shared__ double Bl[2][4][OSP_PL];
+    __shared__ double Bl[2][4][OSP_PL + 1];
     __shared__ double red[OSP_NT / 64][2 * HP + 1];
     const int2 item = items[(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)];      // (product, lag); XCD b & 7 walks its own run
     if (item.x < 0) return;
@@ -712,14 +713,10 @@ __global__ void __launch_bounds__(OSP_NT, 2) omega_sparse(const double* __restri
     double acc[2 * HP + 1];
 #pragma unroll
     for (int e = 0; e <= 2 * HP; ++e) acc[e] = 0.0;
-    if (tid < 2 * 4 * (OSP_PL - OSP_NG)) {                      // the slots behind the groups, once
-        const int bp = tid / (OSP_PL - OSP_NG), sl = tid - bp * (OSP_PL - OSP_NG);
-        Bl[bp >> 2][bp & 3][OSP_NG + sl] = 0.0;
-    }
     // the raw operands of one step: own positions (line a, factor fA, weight) and the partner window (line b, factor fB)
     OspD4 rA[OSP_SW], rF[OSP_SW], rB[OSP_SW], rG[OSP_SW];
-    double rw[OSP_SW];
-    bool rv[OSP_SW];
+    double rw[OSP_SW], rtb = 0.0, rtg = 0.0;       // (rtb, rtg: this thread's position of the window's tail, threads tid < OSP_NT_TAIL)
+    bool rv[OSP_SW], rtv = false;
     auto fetch = [&](int kk, int chn) {            // line kk of the item's list, step chn of the line
         const SparseLine L = lines[k0 + kk];
         const double w = L.w;
@@ -739,6 +736,13 @@ __global__ void __launch_bounds__(OSP_NT, 2) omega_sparse(const double* __restri
             rG[ch] = *reinterpret_cast<const OspD4*>(fB + q);
             rv[ch] = 4 * g < len + 2 * HP;          // (zeros behind the halo: the last windows reach past it)
         }
+        {
+            const int pt = OSP_CH + min(tid, OSP_NT_TAIL - 1);
+            int q = base - HP + min(pt, len + 2 * HP - 1);
+            q += q < 0 ? NL : 0; q -= q >= NL ? NL : 0;
+            rtb = lb[q]; rtg = fB[q];
+            rtv = pt < len + 2 * HP;
+        }
     };
     double areg[OSP_SW][4];
     auto settle = [&](int buf) {                   // raw operands -> this step's registers and window
@@ -750,6 +754,8 @@ __global__ void __launch_bounds__(OSP_NT, 2) omega_sparse(const double* __restri
                 const double b = rB[ch].v[v] * rG[ch].v[v];
                 Bl[buf][v][OSP_NT * ch + tid] = rv[ch] ? b : 0.0;
             }
+        // (branch-free: the other threads write a slot nobody reads -- behind a branch the compiler sinks the multiply-adds again)
+        Bl[buf][tid & 3][tid < OSP_NT_TAIL ? OSP_NG + (tid >> 2) : OSP_PL] = rtv ? rtb * rtg : 0.0;
     };
     if (nsteps > 0) { fetch(0, 0); settle(0); }
     __syncthreads();

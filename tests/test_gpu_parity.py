@@ -803,7 +803,7 @@ def test_bspline_sparse_omega_equals_transformed_omega(dev, shape, w, deg, nk):
     """Omega products of B-spline terms whose row (or column) factors have disjoint supports are summed in real space (omega_sparse:
     a few 1-D correlations of image rows / columns, greek.hpp) instead of through the transforms.  Same linear system to rounding and
     the same result as with every product transformed (SFFT_NO_OMG_SPARSE=1); the plan reports how many products took the short
-    cut.  Shapes: one step per line, lines of several steps (2560 > OSP_CH = 2008), many knots, a line barely longer than the halo."""
+    cut.  Shapes: one step per line, lines of several steps (2560 > OSP_CH = 2048), many knots, a line barely longer than the halo."""
     import sfft_amd.BSplineSFFT as B
     from sfft_amd.utils.synthetic import make_pair
     N0, N1 = shape
