@@ -40,6 +40,8 @@ import time
 # queue serialise.  A pipelined run uses two streams per pair in flight (the plan's second stream carries the apply pass's forward
 # transforms), so the default is raised before the runtime initialises: 436 -> 466 pairs/s at four pairs in flight.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on this host class needs dmabuf IPC (RCCL otherwise fails with `hipIpcGetMemHandle: invalid argument`)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
