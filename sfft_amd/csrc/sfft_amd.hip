@@ -261,7 +261,7 @@ struct sfft_plan {
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     // A/B switches of the launch paths, read ONCE at plan creation (never getenv on a hot path)
-    int no_dft16_regs = 0, no_rader_r24 = 0, no_gamma_aside = 0, vconv2_w12 = 1, inv_r24 = 0;
+    int no_dft16_regs = 0, no_rader_r24 = 0, no_gamma_aside = 0, vconv2_w12 = 1, inv_r24 = -1;
     // Omega products of basis terms with (nearly) disjoint supports: computed in real space by omega_sparse, no transform pass
     std::vector<SparseProd> sprods; SparseProd* d_sprods = nullptr; SparseLine* d_slines = nullptr; int* d_scols = nullptr;
     double* d_strip = nullptr; int n_scols = 0; int2* d_sitems = nullptr; int n_sitems = 0;      // (items: eight runs of n_sitems / 8, one per XCD)
@@ -2419,11 +2419,12 @@ static int apply_finish(sfft_plan* p, const cplx* FI, cplx* FD, const double* d_
                 SFFT_LAUNCH(rows_c2r_diff_4096<SFFT_MAX_BQ>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);
         }
-        else if (p->rows_r24 && p->nby <= 4 && p->inv_r24 == 1) {
-            // 6144- / 9216-point rows: the register-resident inverse pass (fft_r24.hpp), OFF by default.  Alone it is faster (config 3
-            // inverse 0.48 -> 0.29 ms, config 5 1.15 -> 1.00 ms) but with two pairs in flight the configs lose throughput (config 3: 44.0 ->
-            // 43.3 pairs/s, config 5: 34.4 -> 33.9): its 246 registers x 384 threads fill a CU's register file, where the generic pass
-            // (168 registers, one workgroup per CU) leaves room for the other pair's Omega waves.  Latency switch: SFFT_INV_R24=1.
+        else if (p->rows_r24 && p->nby <= 4 && (p->inv_r24 == 1 || (p->inv_r24 < 0 && p->rows_r24 == 16))) {
+            // 6144- / 9216-point rows: the register-resident inverse pass (fft_r24.hpp).  Alone it is faster (config 3 inverse 0.49 -> 0.30 ms,
+            // config 5 1.17 -> 1.01 ms).  Pipelined, round 3 measured a loss (two pairs in flight: its 246 registers x 384 threads fill a
+            // CU's register file where the generic pass leaves room for the other pair's Omega waves); with round 4's kernels and three
+            // pairs in flight 6144-point rows gain 1 - 2 % (60.8 -> 61.4 pairs/s over three runs), 9216-point rows (84 spilled registers)
+            // are flat.  Default: on for 6144, off for 9216; SFFT_INV_R24=0 / 1 forces it.
             if (p->rows_r24 == 16)
                 SFFT_LAUNCH((rows_c2r_diff_r24<16, 4>), dim3((p->N0 + 1) / 2), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, FD, d_J,
                                    d_solution + p->Fijab, p->bk, d_diff, p->N0, p->lay, p->ax1.tw);

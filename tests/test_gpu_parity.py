@@ -1267,11 +1267,11 @@ def test_four_step_column_axis_variants_agree(dev, env):
 
 @pytest.mark.parametrize("shape", [(96, 6144), (80, 9216)])
 def test_r24_inverse_row_pass_agrees_with_generic_pass(dev, shape):
-    """SFFT_INV_R24=1 (off by default: faster alone, lower throughput with pairs in flight): the register-resident inverse row pass of
-    6144- / 9216-point rows (rows_c2r_diff_r24) gives the generic pass's difference image."""
+    """SFFT_INV_R24 (default: on for 6144-point rows, off for 9216): the register-resident inverse row pass of 6144- / 9216-point rows
+    (rows_c2r_diff_r24) gives the generic pass's difference image."""
     from sfft_amd.utils.synthetic import make_pair
     pair = make_pair(*shape, seed=62, mask=True, density=400.0)
-    ref = _subtract_with_env(dev, {}, shape, 3, 2, 1, pair)
+    ref = _subtract_with_env(dev, {"SFFT_INV_R24": "0"}, shape, 3, 2, 1, pair)
     alt = _subtract_with_env(dev, {"SFFT_INV_R24": "1"}, shape, 3, 2, 1, pair)
     assert rms(alt[1] - ref[1]) <= 1e-12 * max(rms(ref[1]), 1.0) + 1e-10 * rms(pair["SCI"])
     assert np.array_equal(alt[0], ref[0])
