@@ -4,7 +4,10 @@
     python bench.py --gpus N --steps K --warmup W                  BASELINE configs[1] (the headline; default)
     python bench.py --config 3|5 ...                               configs[2] (B-spline, 6144^2) / configs[4] (9232 x 9216, KerHW 12)
     python bench.py --pairs 62 ...                                 configs[3]: a fixed batch of independent pairs dealt to the ranks
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+Launch contract: `python bench.py --gpus N` as a plain command starts its N ranks itself (one process per GPU through
+torch.distributed.run on 127.0.0.1, RCCL); launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it
+uses the ranks it is given.  Either way WORLD_SIZE must equal --gpus and the communicator must count N ranks (`ranks_seen`), or the
+process exits with status 2 and prints no JSON line: an N-GPU request never yields a smaller job's number.
 
 A "step" is one GSS-equivalent pass (solve on the masked pair + apply to the full pair, the body of
 sfft.PureCupy_Customized_Packet.PCCP) over one BATCH of distinct synthetic image pairs that are resident in HBM when the
@@ -120,6 +123,25 @@ def alg_bytes(N0, N1, w, Fij, Fpq, n_colfac, DB, mixed_apply, theta_fused=False,
     return out
 
 
+def roofline_object(stage, kernel, t_ms, a_bytes, a_mfma_flops=0.0, traffic=None, **extra):
+    """One roofline object.  Both rates are ALGORITHMIC work over the measured duration: bytes against 8 TB/s and
+    matrix-pipe flops against 78.6 TFLOP/s; `bound` names the larger fraction and `achieved` / `peak` / `unit` / `frac` follow it.  The PMC
+    byte count of the same launch goes to `traffic` and `traffic_ratio` (= traffic / algorithmic bytes: over-fetch, 1.0 = every byte moved
+    once) -- it is never a numerator of `achieved` (tests/test_bench_accounting.py)."""
+    t = max(t_ms, 1e-6) * 1e-3
+    gbs, tf = a_bytes / t / 1e9, a_mfma_flops / t / 1e12
+    hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tf / FP64_PEAK_TFLOPS
+    o = {"kernel": kernel, "stage": stage, "avg_ms": t_ms, "alg_bytes_per_launch": a_bytes,
+         "alg_mfma_flops_per_launch": a_mfma_flops, "hbm_frac": hbm_frac, "mfma_frac": mfma_frac, "hbm_GBs": gbs, "mfma_tflops": tf,
+         "traffic": traffic, "traffic_ratio": (traffic / a_bytes) if (traffic and a_bytes) else None}
+    if mfma_frac > hbm_frac:
+        o.update(bound="mfma", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=mfma_frac)
+    else:
+        o.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac, sustained_peak_measured=HBM_COPY_MEASURED_GBS)
+    o.update(extra)
+    return o
+
+
 def _pick(d, keys):
     return {k: d[k] for k in keys if d is not None and k in d}
 
@@ -135,7 +157,7 @@ def _round(o, sig=5):
     return o
 
 
-ROOF_KEYS = ("bound", "kernel", "stage", "achieved", "peak", "unit", "frac", "traffic", "avg_ms")
+ROOF_KEYS = ("bound", "kernel", "stage", "achieved", "peak", "unit", "frac", "hbm_frac", "mfma_frac", "traffic", "traffic_ratio", "avg_ms")
 
 
 def compact(full):
@@ -151,6 +173,9 @@ def compact(full):
     for k in ("roofline", "roofline_hbm", "roofline_greek", "roofline_solve"):
         if k in full:
             out[k] = _pick(full[k], ROOF_KEYS)
+    if "pipeline" in full:
+        out["pipeline"] = _pick(full["pipeline"], ("bound", "achieved", "peak", "unit", "frac", "alg_bytes_per_pair"))
+    out.update(_pick(full, ("ranks_seen", "launch", "solve_lu_ms")))
     if "single_pair" in full:
         out["single_pair_ms"] = full["single_pair"]["ms"]
     if "prelim_apply_alone" in full:      # [alone, beside the solve] (ms): the apply pass's forward transforms
@@ -176,7 +201,8 @@ def compact(full):
         legs[cid] = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"), "timed_region_s": leg.get("config", {}).get("timed_region_s"),
                      "single_pair_ms": leg.get("single_pair", {}).get("ms"), "pairs_per_step": leg.get("config", {}).get("pairs_per_step"),
                      "prelim_apply_ms": [leg.get("prelim_apply_alone", {}).get("ms"), leg.get("prelim_apply_alone", {}).get("ms_beside_the_solve")],
-                     "dominant": _pick(dom, ("kernel", "bound", "frac", "avg_ms", "traffic")),
+                     "dominant": _pick(dom, ("kernel", "bound", "frac", "hbm_frac", "mfma_frac", "avg_ms", "traffic_ratio")),
+                     "pipeline_frac": leg.get("pipeline", {}).get("frac"), "solve_lu_ms": leg.get("solve_lu_ms"),
                      "bitwise_equal": leg.get("post_check", {}).get("bitwise_equal"),
                      "gathered_pairs": leg.get("gathered_pairs"), "failed_pairs": leg.get("failed_pairs")}
     if legs:
@@ -262,6 +288,8 @@ def parse_args(argv=None):
                     "xGMI, the default) or gloo (records and timing cross the ranks as host tensors; tests)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="TEST ONLY: every rank uses cuda:0 (two processes on a one-GPU box; "
                     "needs --dist-backend gloo, RCCL refuses two ranks on one device)")
+    ap.add_argument("--spawn", action="store_true", help="start the rank(s) through torch.distributed.run even at --gpus 1 (a process group with "
+                    "one rank: RCCL initialised, collectives executed)")
     ap.add_argument("--dk", type=int, default=-1, help="override the kernel polynomial order (quick runs / tests)")
     ap.add_argument("--db", type=int, default=-1, help="override the background polynomial order (quick runs / tests)")
     return ap.parse_args(argv)
@@ -276,7 +304,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
     import torch.distributed as dist
     from sfft_amd import _lib
     from sfft_amd.plan import Plan
-    from sfft_amd.sharding import shard_pair_ids, pack_record, gather_records, run_shard
+    from sfft_amd.sharding import shard_pair_ids, pack_record, gather_records, run_shard, all_failed_with_error
     from sfft_amd.utils.synthetic import make_pair
 
     dev = torch.device("cuda", local_rank)
@@ -353,6 +381,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             status[k] = e.code
 
     last_records = [None]
+    shard_errors = []            # (pair id, message) of pairs that failed with anything but an ABI status (run_shard also prints them)
 
     def run_steps(n):
         def static_worker(wi):
@@ -375,10 +404,10 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
                 torch.cuda.set_device(local_rank)
                 with torch.cuda.stream(streams[wi]):
                     return subtract(wi, my_ids.index(pid))
-            last_records[0] = run_shard(my_ids, S, work, NEQ, dev)
+            last_records[0] = run_shard(my_ids, S, work, NEQ, dev, errors=shard_errors)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     run_steps(args.warmup)
@@ -390,7 +419,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
     barrier()
     elapsed = time.perf_counter() - t_start
     comm_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -447,6 +476,8 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         recs = [pack_record(my_ids[k], status[k], elapsed * 1e3 / max(args.steps * len(my_ids), 1), sols[k]) for k in range(len(my_ids))]
     table = gather_records(recs, n_total, NEQ, comm_dev)
     n_failed = int((table[:, 1] != 0).sum().item())
+    if batch_mode and all_failed_with_error(recs):      # after the collective, so that no rank is left waiting in it
+        raise RuntimeError("rank %d: every pair of the shard failed with an exception: %r" % (rank, shard_errors[:3]))
 
     # ---- host-array variant (CP semantics): pinned host arrays in, host arrays out, H2D / D2H overlapped across streams ----
     host = None
@@ -520,55 +551,36 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             return " + ".join(names) if names else stage
         KERNEL_OF = {k: label(k) for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse")}
 
-        def roof(stages, dom="fwd_cols"):
-            ach = ab[dom] / (max(stages[dom], 1e-6) * 1e-3) / 1e9      # (a stage that was not timed separately, e.g. SFFT_STAGE_INTERLEAVE=1, reads 0)
-            traffic = pmc_cfg.get(dom, {}).get("hbm_bytes_per_launch")
-            return {"bound": "hbm", "kernel": KERNEL_OF.get(dom, dom), "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "sustained_peak_measured": HBM_COPY_MEASURED_GBS,
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": ab[dom], "avg_ms": stages[dom]}
+        def roof_obj(stage, t_ms, a_bytes, a_mfma_flops=0.0, **extra):
+            return roofline_object(stage, KERNEL_OF.get(stage, stage), t_ms, a_bytes, a_mfma_flops,
+                                   pmc_cfg.get(stage, {}).get("hbm_bytes_per_launch"), **extra)
 
-        def roof_flops(stages):
-            # `achieved` prices the MATRIX-pipe work only (the lag sums); the products and butterflies on the vector ALUs are listed beside it
-            tf = ab["greek_g1_mfma_flops"] / (stages["greek_g1"] * 1e-3) / 1e12
-            traffic = pmc_cfg.get("greek_g1", {}).get("hbm_bytes_per_launch")
-            return {"bound": "mfma", "kernel": KERNEL_OF["greek_g1"], "stage": "greek_g1", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "alg_flops_per_launch": ab["greek_g1_mfma_flops"],
-                    "valu_flops_per_launch": ab["greek_g1_flops"] - ab["greek_g1_mfma_flops"],
-                    "all_flops_tflops": ab["greek_g1_flops"] / (stages["greek_g1"] * 1e-3) / 1e12,
-                    "alg_bytes_per_launch": ab["greek_g1"], "avg_ms": stages["greek_g1"],
-                    "hbm_GBs_of_alg_bytes": ab["greek_g1"] / (stages["greek_g1"] * 1e-3) / 1e9,
-                    "sustained_peak_measured": 74.5,     # profiles/r02_mfma_f64_peak.txt: a loop of independent v_mfma_f64_4x4x4_4b_f64, TFLOP/s
-                    "decimated": decimated, "alg_flops_direct": ab["greek_g1_flops_direct"],
-                    "direct_equivalent_tflops": ab["greek_g1_flops_direct"] / (stages["greek_g1"] * 1e-3) / 1e12,
-                    "note": "alg_flops_per_launch = the lag sums as built (on the matrix cores when the lag half-width allows: "
-                            "v_mfma_f64_4x4x4_4b_f64, 74.5 TFLOP/s sustained in a loop of nothing else); with the radix-2 decimation step along "
-                            "the rows they run over half the rows (alg_flops_direct: the same pruned DFT taken directly).  The launch is "
-                            "as much HBM-side as matrix-side: see hbm_GBs_of_alg_bytes"}
+        def roof(stages, dom="fwd_cols"):
+            # (a stage that was not timed separately, e.g. SFFT_STAGE_INTERLEAVE=1, reads 0)
+            return roof_obj(dom, stages[dom], ab[dom])
+
+        def roof_greek(stages):
+            """the Omega + Theta launch: the lag sums on the matrix pipe (v_mfma_f64_4x4x4_4b_f64) when the lag half-width allows, its planes
+            and partial sums as bytes; whichever fraction is larger names the bound.  The products and butterflies on the vector ALUs are listed."""
+            t = stages["greek_g1"]
+            return roof_obj("greek_g1", t, ab["greek_g1"], ab["greek_g1_mfma_flops"] if g1_mfma else 0.0,
+                            valu_flops_per_launch=ab["greek_g1_flops"] - ab["greek_g1_mfma_flops"],
+                            all_flops_tflops=ab["greek_g1_flops"] / (max(t, 1e-6) * 1e-3) / 1e12,
+                            mfma_sustained_peak_measured=74.5,    # profiles/r02_mfma_f64_peak.txt: a loop of independent v_mfma_f64_4x4x4_4b_f64, TFLOP/s
+                            decimated=decimated, alg_flops_direct=ab["greek_g1_flops_direct"],
+                            direct_equivalent_tflops=ab["greek_g1_flops_direct"] / (max(t, 1e-6) * 1e-3) / 1e12,
+                            note="alg_mfma_flops_per_launch = the lag sums as built; with the radix-2 decimation step along the rows they run over half "
+                                 "the rows (alg_flops_direct: the same pruned DFT taken directly)")
 
         def roof_solve(stages):
             fl = n_sys ** 3 / 3.0                       # Cholesky factorisation (the triangular solves are O(n^2))
-            tf = fl / (max(stages["solve"], 1e-6) * 1e-3) / 1e12
-            return {"bound": "mfma", "regime": "latency: a chain of dependent 64-column block steps, not throughput", "kernel": KERNEL_OF["solve"],
-                    "stage": "solve", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                    "traffic": pmc_cfg.get("solve", {}).get("hbm_bytes_per_launch"),
-                    "alg_flops_per_launch": fl, "unknowns": n_sys, "avg_ms": stages["solve"]}
+            return roof_obj("solve", stages["solve"], 8.0 * n_sys * n_sys, fl, unknowns=n_sys,
+                            regime="latency: a chain of dependent 64-column block steps, not throughput")
 
         # the dominant stage by kernel time of one pair, among everything that is timed
         HBM_STAGES = [k for k in ("fwd_rows", "fwd_cols", "prelim_apply", "construct", "inverse") if k in ab]
         cand = {k: iso_stage.get(k, 0.0) for k in HBM_STAGES + ["greek_g1", "solve"]}
         dom = max(cand, key=lambda k: cand[k])
-        def roof_greek(stages):
-            """the Omega + Theta launch: priced on the matrix pipe unless its measured HBM traffic over its duration exceeds 4 TB/s -- then it sits
-            on the memory side (config 3: 7x over-fetch) and is reported as bound "hbm" with the TRAFFIC rate as `achieved`"""
-            r = roof_flops(stages) if g1_mfma else roof(stages, "greek_g1")
-            t = r.get("traffic")
-            if t and g1_mfma:
-                rate = t / (stages["greek_g1"] * 1e-3) / 1e9
-                r["hbm_traffic_GBs"] = rate
-                if rate > 4000.0:
-                    r = dict(r, bound="hbm", mfma_frac=r["frac"], mfma_achieved_tflops=r["achieved"], achieved=rate, peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=rate / HBM_PEAK_GBS)
-            return r
         roofline = roof_solve(iso_stage) if dom == "solve" else roof_greek(iso_stage) if dom == "greek_g1" else roof(iso_stage, dom)
         dom_hbm = max(HBM_STAGES, key=lambda k: cand[k])
         per_pair_keys = [k for k in ("fwd_rows", "fwd_cols", "greek_g1", "greek_g1b", "prelim_apply", "construct", "inverse") if k in ab]
@@ -597,6 +609,11 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             "roofline_hbm": dict(roof(iso_stage, dom_hbm), measured="same events, same launches: the HBM-bound stage with the most time"),
             "roofline_greek": dict(roof_greek(iso_stage), measured="same events, same launches"),
             "roofline_solve": dict(roof_solve(iso_stage), measured="same events, same launches"),
+            "pipeline": {"bound": "hbm", "achieved": sum(ab[k] for k in per_pair_keys) * (value / world) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": sum(ab[k] for k in per_pair_keys) * (value / world) / 1e9 / HBM_PEAK_GBS,
+                         "alg_bytes_per_pair": sum(ab[k] for k in per_pair_keys),
+                         "note": "the whole pipeline per GPU: the build's own algorithmic bytes of one pair (all HBM-side stages, solve + apply) x "
+                                 "pairs/s per GPU against 8 TB/s; the dense solve and the lag sums overlap with it on other streams"},
             "hbm_stages": {k: {"GBs": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9, "frac": ab[k] / (max(iso_stage[k], 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "ms": iso_stage[k], "alg_bytes": ab[k], "kernel": KERNEL_OF.get(k, k)} for k in HBM_STAGES},
             "prelim_apply_alone": {"ms": apply_alone.get("prelim_apply", 0.0), "ms_beside_the_solve": iso_stage.get("prelim_apply", 0.0),
@@ -613,7 +630,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
                                "as_built_GBs_per_gpu": sum(ab[k] for k in per_pair_keys) * (value / world) / 1e9,
                                "note": "reference-algorithm bytes (SURVEY 8d) x pairs/s per GPU; context, not the roofline: the build's own "
                                        "algorithmic bytes per pair are listed beside it"},
-            "gathered_pairs": int(table.shape[0]), "failed_pairs": n_failed,
+            "gathered_pairs": int(table.shape[0]), "failed_pairs": n_failed, "shard_errors_rank0": ["pair %d: %s" % e for e in shard_errors[:4]],
             "stage_kernels": stage_kernels,     # the kernels each stage launched, as the library recorded them (sfft_stage_kernels)
         }
         if batch_mode:
@@ -639,27 +656,72 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
     return out
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started as a plain command (no RANK / WORLD_SIZE in the environment): start the N ranks here -- one
+    process per GPU through torch.distributed.run on 127.0.0.1 -- and hand on their exit code; rank 0's JSON line reaches this process's
+    stdout unchanged (the children inherit it).  The reference fans one call out to its devices the same way
+    (sfft/MultiEasyCrowdedPacket.py:361-399, 698-710)."""
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if not args.all_ranks_on_device0 and args.gpus > n_dev:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s); refusing to print a smaller job's number\n" % (args.gpus, n_dev))
+        sys.exit(2)
+    env = dict(os.environ, SFFT_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse_args()
     import copy
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        self_launch(args)        # does not return
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    if world != args.gpus:       # never print a `world`-GPU number for a `--gpus N` request
+        sys.stderr.write("bench.py: rank %d: WORLD_SIZE=%d but --gpus %d -- launch exactly N ranks (or run plain `python bench.py --gpus N`, "
+                         "which starts them)\n" % (rank, world, args.gpus))
+        sys.exit(2)
     if args.all_ranks_on_device0:
         assert args.dist_backend == "gloo", "--all-ranks-on-device0 is a test mode and needs --dist-backend gloo"
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d: LOCAL_RANK %d but %d GPU(s) visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ      # started by torch.distributed.run (the driver's or self_launch's): a process group even at N = 1
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        # the ranks that actually run, counted on the communicator itself (device tensors over RCCL, host tensors over gloo)
+        ones = torch.ones(1, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+        if ranks_seen != args.gpus:
+            sys.stderr.write("bench.py: rank %d: the communicator holds %d ranks, --gpus %d\n" % (rank, ranks_seen, args.gpus))
+            sys.exit(2)
+    else:
+        ranks_seen = 1
 
     out = run_config(args, rank, world, local_rank, headline_extras=True)
 
@@ -688,8 +750,10 @@ def main():
             out["other_configs"] = dict(legs, note="short legs run after the headline's timed region (3 warm-up + 5 timed steps each, own "
                                         "barriers, plans and data); not part of `value`")
     if rank == 0:
+        out["ranks_seen"] = ranks_seen
+        out["launch"] = ("self" if os.environ.get("SFFT_BENCH_SELF_LAUNCHED") else "torchrun") + ":" + args.dist_backend if launched else "direct"
         emit(out)
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

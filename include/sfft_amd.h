@@ -58,6 +58,9 @@ enum {
                                        reference's dictionary entry, defined whether or not the stripes are removed) */
     SFFT_Q_OMG_SPARSE,              /* Omega products of this plan that are summed in real space (tabulated bases: terms with disjoint supports
                                        along one axis), not through the transforms; of FOMG / Fab^2 = Fij (Fij + 1) / 2 products */
+    SFFT_Q_CHOL_STATUS,             /* status bits the most recent Cholesky attempt left (0 = factorised): 1 | 2 = a pivot was not positive (the
+                                       reference's LU, SFFTSubtract.py:15-23, then takes the system), 4 = a dataflow hand-off poll ran out (a
+                                       scheduling stall, not a property of the system), 8 = launched on fewer than two workgroups */
     SFFT_Q_COUNT
 };
 

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(24 * Q * NC) cols_fwd_weighted_r24(const cplx*
     constexpr int GW = 8 / NC;                                   // workgroups per 8-column group
     const int gq = (t % GW) * NC + c, o = (t / GW) % g.nout, tg = (t / GW) / g.nout;
     const int col0 = (tg * 8 + xcd) * 8 + gq;
-    if (NC == 1 && col0 >= ncols) return;
+    if (col0 - c >= ncols) return;     // workgroup-uniform (col0 - c is the team-0 column; no barrier reached yet): every column of the workgroup is past the end
     const int col = NC == 1 ? col0 : min(col0, ncols - 1);       // (a column past the end repeats the last one and is not stored: the teams share barriers)
     const size_t plane_sz = (size_t)N0 * Nhp, cofs = lay.col(col), rs = (size_t)lay.rstride;
     const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * plane_sz + cofs;

@@ -233,7 +233,7 @@ struct sfft_plan {
     double* d_rowmom = nullptr; double* d_delta = nullptr;
     int* d_status = nullptr;
     size_t ws_bytes = 0;
-    int last_solver = 0, force_lu = 0;
+    int last_solver = 0, force_lu = 0, chol_status = 0;
     int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row (vconv_mixed)
     int num_cu = 256;
     int vconv_direct_launch = 0;        // env SFFT_VCONV_DIRECT=1: the leftover columns of the mixed-domain apply in a launch of their own (vconv_direct)
@@ -1496,6 +1496,7 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_FDEL: *v = p->Fpq; break;
         case SFFT_Q_WORKSPACE_BYTES: *v = (long long)p->ws_bytes; break;
         case SFFT_Q_LAST_SOLVER: *v = p->last_solver; break;
+        case SFFT_Q_CHOL_STATUS: *v = p->chol_status; break;
         case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_dense_w); break;
         case SFFT_Q_SCAFIJ: *v = p->nsca; break;
         case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
@@ -1966,9 +1967,9 @@ static int run_fill(sfft_plan* p, hipStream_t s, bool lower_only)
 
 __global__ void set_i32(int* __restrict__ v, int value) { *v = value; }
 
-__global__ void zero_f64(double* __restrict__ v, int n)
+__global__ void zero_f64(double* __restrict__ v, size_t n)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k < n) v[k] = 0.0;
 }
 
@@ -2056,7 +2057,7 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
     // Extend_Solution's zeros (removed unknowns stay exactly 0).  A kernel, not hipMemsetAsync: captured into the plan's hipGraph a
     // memset node was seen to leave these entries unwritten now and then when several plans replay their graphs from different
     // host threads at once (bench.py --pairs: 5 forbidden entries of a pair's Solution holding stale bytes); SFFT_SOL_MEMSET=1 restores it
-    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, p->NEQ);
+    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, (size_t)p->NEQ);
     const int nblk = (n + CB - 1) / CB;
     if (p->back_variant == 1) {
         if (!dataflow)      // (chol_dataflow leaves the inverses of the diagonal blocks behind itself)
@@ -2118,7 +2119,7 @@ static int run_lu(sfft_plan* p, double* d_solution, hipStream_t s)
     LAUNCH_CHECK();
     const size_t lds = (size_t)(n + 2) * 8;
     SFFT_LAUNCH(lu_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_xv);
-    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, p->NEQ);
+    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, (size_t)p->NEQ);
     SFFT_LAUNCH(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
                        p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
     LAUNCH_CHECK();
@@ -2168,8 +2169,11 @@ static int solve_check(sfft_plan* p, double* d_solution, hipStream_t s, bool* re
             }
         }
     }
+    if (!p->attempt_lu) p->chol_status = *p->h_status;
     if (*p->h_status == 0) return SFFT_OK;
     if (p->attempt_lu) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+    if (*p->h_status & 12)      // not a property of the system: say so before the pivoted LU takes over
+        fprintf(stderr, "sfft_amd: chol_dataflow reported status %d (4: hand-off poll timed out, 8: grid < 2 workgroups); solving by LU\n", *p->h_status);
     int rc;
     if ((rc = solve_attempt(p, true, d_solution, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
@@ -2185,6 +2189,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
 {
     ON_DEVICE(p->dev);
     int rc;
+    p->launch_error = 0;     // per call: one refused launch must not poison every later call on the plan
     // The fused row moments give each row-pass group (one per distinct source image) ONE moment output.  solve(I, I) has a single
     // group, so only one of the two moment sets would be written: such a call takes the separate row_moments launches.
     struct ScopedInt { int& r; int old; ScopedInt(int& ref, int v) : r(ref), old(ref) { r = v; } ~ScopedInt() { r = old; } }
@@ -2453,7 +2458,9 @@ extern "C" int sfft_apply(sfft_plan* p, const double* d_I, const double* d_J, co
     hipStream_t s = (hipStream_t)stream;
     ON_DEVICE(p->dev);
     int rc;
+    p->launch_error = 0;
     if ((rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
+    if (p->launch_error) return p->launch_error;     // a pass was refused: do not run the rest of the pipeline on untransformed planes
     if ((rc = apply_finish(p, p->use_vconv ? p->d_stage_a : p->d_spec, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
     return p->launch_error;
 }
@@ -2581,9 +2588,9 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
     int rc;
     if (!p->d_zero) {
         if ((rc = dev_alloc(p, &p->d_zero, (size_t)p->N0 * p->N1))) return rc;
-        SFFT_LAUNCH(zero_f64, dim3((p->N0 * p->N1 + 255) / 256), dim3(256), 0, s, p->d_zero, p->N0 * p->N1);
+        SFFT_LAUNCH(zero_f64, dim3((unsigned)(((size_t)p->N0 * p->N1 + 255) / 256)), dim3(256), 0, s, p->d_zero, (size_t)p->N0 * p->N1);
         if ((rc = dev_alloc(p, &p->d_zsol, (size_t)p->NEQ))) return rc;
-        SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, p->d_zsol, p->NEQ);
+        SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, p->d_zsol, (size_t)p->NEQ);
     }
     cplx* FD = p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp;
     SFFT_LAUNCH(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, (const cplx*)d_spec, FD, p->N0, p->Nh,

@@ -806,6 +806,10 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
     // are resident before any TR workgroup; a TR task only waits for PT tasks and for TR tasks earlier in the queue, all of which have
     // been taken by running workgroups.
     if (trace && tid == 0 && blockIdx.x == 0) trace[11] = wall_clock64();                       // (row 0, slot 11: kernel start)
+    if (gridDim.x < 2) {         // the PT / TR split needs a queue workgroup beside the diagonal one: report (-> LU), never spin
+        if (tid == 0) atomicOr(status, 8);
+        return;
+    }
     const int npt = max(1, min(2 + nbc / 3, (int)gridDim.x - 1));
     const int nbw = 0;      // (dedicated workgroups for the border-row chain TR(border, j) were measured too: the kernel ends 6 us after the last
                             //  diagonal block either way -- 575 us alone, 680 us beside the apply pass's transforms -- so they stay in the queue)

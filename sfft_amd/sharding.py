@@ -8,13 +8,15 @@ job and the only collective is an all_gather of one fixed-size record per pair
 (RCCL over xGMI on GPUs, gloo on CPU in the tests).  Difference images never leave their GPU.
 """
 import itertools
+import sys
 import threading
 import time
+import traceback
 
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_pair_ids", "pack_record", "gather_records", "run_shard", "STATUS_OK", "STATUS_SINGULAR", "STATUS_ERROR"]
+__all__ = ["shard_pair_ids", "pack_record", "gather_records", "run_shard", "STATUS_OK", "STATUS_SINGULAR", "STATUS_ERROR", "all_failed_with_error"]
 
 # per-pair status in the gathered record: the C ABI's return code of the pair's sfft_subtract (include/sfft_amd.h):
 # 0 ok, -1 invalid argument, -2 unsupported size, -3 HIP error, -4 singular system, -5 out of memory
@@ -68,8 +70,8 @@ def run_shard(pair_ids, n_workers, work_fn, neq, device, errors=None):
     numpy.linalg.LinAlgError for a singular system, _lib.SfftError (with the ABI's return code) for every other status of the
     C ABI, a plain Exception('MeLOn ERROR: ...') from the Python layer.  As in the reference (`except Exception` per task,
     sfft/MultiEasyCrowdedPacket.py:344, 646) a failing pair never stops the shard: its record carries a status (the ABI's code,
-    STATUS_SINGULAR, or STATUS_ERROR for any other Exception -- the message goes to `errors` when a list is passed) and a zero
-    solution, and the worker's plan goes on to the next pair.  So every rank always reaches the collective in gather_records.
+    STATUS_SINGULAR, or STATUS_ERROR for any other Exception -- pair id, message and traceback go to stderr, and (pair id, message)
+    to `errors` when a list is passed) and a zero solution, and the worker's plan goes on to the next pair.  So every rank always reaches the collective in gather_records.
     Only a non-Exception BaseException (KeyboardInterrupt, SystemExit) stops the workers and is re-raised here.
     Returns one record per pair, in shard order."""
     import numpy as np
@@ -95,10 +97,15 @@ def run_shard(pair_ids, n_workers, work_fn, neq, device, errors=None):
                 sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_SINGULAR
             except SfftError as e:
                 sol, status = torch.zeros(neq, dtype=torch.float64, device=device), e.code
-            except Exception as e:          # any other per-pair failure: recorded, the shard carries on
+            except Exception as e:          # any other per-pair failure: recorded, the shard carries on -- never silently
                 sol, status = torch.zeros(neq, dtype=torch.float64, device=device), STATUS_ERROR
+                msg = "%s: %s" % (type(e).__name__, e)
                 if errors is not None:
-                    errors.append((pid, "%s: %s" % (type(e).__name__, e)))
+                    errors.append((pid, msg))
+                # the reference prints the task's exception too (sfft/MultiEasyCrowdedPacket.py:344-351); with the traceback a
+                # programming error or a sticky device fault is not mistaken for a bad pair
+                sys.stderr.write("sfft_amd.sharding: pair %d failed on worker %d: %s\n%s" % (pid, wi, msg, traceback.format_exc()))
+                sys.stderr.flush()
             except BaseException as e:      # KeyboardInterrupt / SystemExit: stop taking pairs
                 fatal.append(e)
                 return
@@ -113,3 +120,10 @@ def run_shard(pair_ids, n_workers, work_fn, neq, device, errors=None):
     if fatal:
         raise fatal[0]
     return records
+
+
+def all_failed_with_error(records):
+    """True when a non-empty shard's pairs ALL ended with STATUS_ERROR (an Exception that is neither a singular system nor an ABI
+    status): that is a broken worker, not a batch of bad pairs.  Callers raise AFTER gather_records so that every rank still
+    reaches the collective."""
+    return len(records) > 0 and all(int(r[1].item()) == STATUS_ERROR for r in records)

@@ -38,6 +38,31 @@ def test_algorithmic_bytes_and_flops_of_config2():
     assert ab["B_alg_reference"] == 183 * 4 * 16 * N0 * N1 + 156 * 16 * N0 * N1 + 13 * 16 * N0 * N1 + 5 * 8 * N0 * N1
 
 
+def test_roofline_achieved_is_algorithmic_work_never_counter_traffic():
+    """the Omega launch of config 5 moved 56.7 GB by the PMC counters for 9.23 GB of planes in 8.39 ms; the object must
+    say 0.14 of HBM / 0.34 of the matrix peak with a traffic ratio of 6.1, not 0.84 of HBM."""
+    b = _bench()
+    flops = 0.34 * b.FP64_PEAK_TFLOPS * 1e12 * 8.39e-3
+    r = b.roofline_object("greek_g1", "greek_g1_mfma4g", 8.39, 9.23e9, flops, traffic=56.7e9)
+    assert r["bound"] == "mfma" and abs(r["frac"] - 0.34) < 1e-9 and abs(r["hbm_frac"] - 9.23e9 / 8.39e-3 / 8e12) < 1e-12
+    assert abs(r["hbm_frac"] - 0.1375) < 1e-3 and abs(r["traffic_ratio"] - 56.7 / 9.23) < 1e-9 and r["traffic"] == 56.7e9
+    assert abs(r["achieved"] - flops / 8.39e-3 / 1e12) < 1e-9 and r["unit"] == "TFLOP/s" and r["peak"] == b.FP64_PEAK_TFLOPS
+    # whatever the counters say, achieved / frac / bound do not move
+    for traffic in (None, 1.0, 9.23e9, 1e12):
+        q = b.roofline_object("greek_g1", "k", 8.39, 9.23e9, flops, traffic=traffic)
+        assert (q["achieved"], q["frac"], q["bound"], q["peak"]) == (r["achieved"], r["frac"], r["bound"], r["peak"])
+    # an HBM-side pass: bytes / time against 8 TB/s
+    h = b.roofline_object("fwd_cols", "cols_fwd_weighted_4096_q", 0.3641, 1.477e9, 0.0, traffic=1.514e9)
+    assert h["bound"] == "hbm" and abs(h["achieved"] - 1.477e9 / 0.3641e-3 / 1e9) < 1e-6 and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-12
+    assert abs(h["traffic_ratio"] - 1.514 / 1.477) < 1e-9
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def roofline_object("):src.index("def _pick(")]
+    assert "traffic /" in body and body.count("traffic") >= 3
+    for line in body.splitlines():          # the only arithmetic on `traffic` is the ratio
+        if "traffic" in line and ("gbs" in line.split("=")[0] or "achieved=" in line and "traffic" in line.split("achieved=")[1].split(",")[0]):
+            raise AssertionError(line)
+
+
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
             "config", "roofline", "cpu_baseline")
 

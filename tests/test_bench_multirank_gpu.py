@@ -21,13 +21,22 @@ def _free_port():
     return port
 
 
-def _launch(extra):
-    env = dict(os.environ)
+SMALL = ["--size", "512", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-other-configs", "--no-host-arrays"]
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "512", "--steps", "1", "--warmup", "1",
-           "--no-cpu", "--no-other-configs", "--no-host-arrays", "--dist-backend", "gloo", "--all-ranks-on-device0"] + extra
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    return env
+
+
+def _launch(extra, torchrun=True, gpus=2, tail=("--dist-backend", "gloo", "--all-ranks-on-device0")):
+    """torchrun=True: the way the driver launches N > 1; False: plain `python bench.py --gpus N`, which must start its ranks itself."""
+    head = [sys.executable]
+    if torchrun:
+        head += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    cmd = head + [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + SMALL + list(tail) + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     json_lines = [ln for ln in lines if ln.startswith("{")]
@@ -51,3 +60,41 @@ def test_bench_two_ranks_weak_scaling_headline_path():
     assert d["scaling"] == "weak" and d["config"]["pairs_per_step"] == 6 and d["post_check"]["bitwise_equal"] is True
     for k in ("roofline", "roofline_hbm", "roofline_greek", "roofline_solve"):
         assert set(("bound", "kernel", "achieved", "peak", "frac", "traffic", "avg_ms")) <= set(d[k]), k
+
+
+@pytest.mark.gpu
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it and no WORLD_SIZE in the environment: two ranks run, the line says so."""
+    d = _launch(["--pairs", "5"], torchrun=False)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launch"] == "self:gloo"
+    assert d["gathered_pairs"] == 5 and d["failed_pairs"] == 0 and d["config"]["pairs_per_step"] == 5
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_spawner_over_rccl():
+    """--gpus 1 --spawn: one rank started through torch.distributed.run with the nccl (= RCCL) backend: communicator created on the device,
+    barrier / all_reduce(MAX) / the record gather run on device tensors."""
+    d = _launch(["--batch", "3", "--streams", "2", "--spawn"], torchrun=False, gpus=1, tail=("--dist-backend", "nccl"))
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["launch"] == "self:nccl"
+    assert d["gathered_pairs"] == 3 and d["failed_pairs"] == 0 and d["post_check"]["bitwise_equal"] is True
+
+
+def _expect_refusal(cmd, env):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr.decode()[-2000:])
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]        # no JSON line: never a smaller job's number
+    return r.stderr.decode()
+
+
+def test_world_size_mismatch_fails_instead_of_warning():
+    """(no GPU needed: the check runs before any device work)  WORLD_SIZE=1 in the environment with --gpus 2 is an error, not a 1-GPU line."""
+    env = dict(_clean_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    err = _expect_refusal([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, env)
+    assert "WORLD_SIZE=1 but --gpus 2" in err
+
+
+def test_more_gpus_than_the_node_has_is_refused():
+    import torch
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    err = _expect_refusal([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 2)] + SMALL, _clean_env())
+    assert "refusing" in err
