@@ -466,6 +466,24 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             plans[0].apply(g["REF"], g["SCI"], fresh_s)
             torch.cuda.synchronize(dev)
             apply_alone = plans[0].stage_ms()
+        # the same system through the reference's own solver semantics -- LU with partial pivoting (lu.hpp, sfft_set_force_lu): the solve
+        # stage's duration beside the Cholesky path's, and the DIFF it leads to against the Cholesky run's
+        solve_lu = None
+        try:
+            plans[0].set_force_lu(True)
+            g = pairs[check_ids[0]]
+            lu_ms = []
+            for _ in range(3):
+                plans[0].subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"], out_solution=fresh_s, out_diff=fresh_d)
+                torch.cuda.synchronize(dev)
+                lu_ms.append(plans[0].stage_ms().get("solve", 0.0))
+            used_lu = plans[0].query("LAST_SOLVER") == 2
+            rel = float(((fresh_d - diffs[check_ids[0]]).abs().max() / diffs[check_ids[0]].abs().max()).item())
+            solve_lu = {"ms": float(np.median(lu_ms[1:])), "used_lu": bool(used_lu), "diff_max_rel_vs_cholesky": rel}
+        except Exception as e:      # (a failing LU leg must not take the line with it; it is reported)
+            solve_lu = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            plans[0].set_force_lu(False)
     plans[0].set_timing(False)
     assert post["bitwise_equal"] or post["max_rel_diff"] <= 1e-12, "pipelined result differs from the single-stream result: %r" % post
 
@@ -630,6 +648,7 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
                                "as_built_GBs_per_gpu": sum(ab[k] for k in per_pair_keys) * (value / world) / 1e9,
                                "note": "reference-algorithm bytes (SURVEY 8d) x pairs/s per GPU; context, not the roofline: the build's own "
                                        "algorithmic bytes per pair are listed beside it"},
+            "solve_lu_ms": (solve_lu or {}).get("ms"), "solve_lu": solve_lu,
             "gathered_pairs": int(table.shape[0]), "failed_pairs": n_failed, "shard_errors_rank0": ["pair %d: %s" % e for e in shard_errors[:4]],
             "stage_kernels": stage_kernels,     # the kernels each stage launched, as the library recorded them (sfft_stage_kernels)
         }

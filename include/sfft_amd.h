@@ -156,6 +156,14 @@ int sfft_get_system(sfft_plan* plan, double* d_LHMAT, double* d_RHb, void* strea
  * Synchronises. */
 int sfft_get_solver_system(sfft_plan* plan, double* d_bordered, int* d_index, void* stream);
 
+/* Parity aid: the dense solver alone on a caller's system of the plan's size.  d_bordered [n+1][n+1] float64 in the layout
+ * sfft_get_solver_system writes (rows / columns 0 .. n-1 the matrix, column n AND row n the right-hand side), n = SFFT_Q_SOLVER_N;
+ * use_lu = 1: LU with partial pivoting, the reference's solver (np.linalg.solve / cupy.linalg.solve, SFFTSubtract.py:15-23), for
+ * any nonsingular matrix; use_lu = 0: the Cholesky path (symmetric positive definite input, lower triangle + border row read).
+ * d_x [n] float64 receives the solution in the solver's own ordering (no Extend_Solution).  Returns SFFT_ERR_SINGULAR like
+ * sfft_solve.  Synchronises. */
+int sfft_dbg_solve_dense(sfft_plan* plan, const double* d_bordered, int use_lu, double* d_x, void* stream);
+
 /* Parity aid: SCALE * DFT2(I * kbx[i][row] * kby[j][col]) (= I * cx^i * cy^j for polynomial plans with i, j <= DK)
  * in the plan's half-spectrum layout, d_spec: [N0][N1/2+1] complex128 (interleaved re,im) -- items 3+4 of SURVEY.md 8(a). */
 int sfft_dbg_forward_spectrum(sfft_plan* plan, const double* d_I, int i, int j, double* d_spec, void* stream);

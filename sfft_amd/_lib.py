@@ -25,7 +25,7 @@ STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply
           "fwd_rows", "fwd_cols"]
 
 EXPORTS = ["sfft_plan_create", "sfft_plan_create_basis", "sfft_plan_create_varscale", "sfft_plan_set_regularization", "sfft_plan_destroy", "sfft_plan_query", "sfft_solve", "sfft_apply", "sfft_subtract",
-           "sfft_get_system", "sfft_get_solver_system", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",
+           "sfft_get_system", "sfft_get_solver_system", "sfft_dbg_solve_dense", "sfft_dbg_forward_spectrum", "sfft_fft_plan_create", "sfft_fft2_r2c", "sfft_ifft2_c2r",
            "sfft_grid_convolve", "sfft_spec_abs2_accumulate", "sfft_real_rsqrt", "sfft_spec_multiply", "sfft_half_to_full_real", "sfft_set_timing", "sfft_stage_ms", "sfft_stage_kernels", "sfft_set_force_lu",
            "sfft_last_error", "sfft_version"]
 
@@ -62,6 +62,7 @@ def _load():
     lib.sfft_subtract.argtypes = [vp, dp, dp, dp, dp, dp, dp, vp]
     lib.sfft_get_system.argtypes = [vp, dp, dp, vp]
     lib.sfft_get_solver_system.argtypes = [vp, dp, dp, vp]
+    lib.sfft_dbg_solve_dense.argtypes = [vp, dp, ip, dp, vp]
     lib.sfft_dbg_forward_spectrum.argtypes = [vp, dp, ip, ip, dp, vp]
     dbl, ll = ctypes.c_double, ctypes.c_longlong
     lib.sfft_fft_plan_create.argtypes = [ctypes.POINTER(vp), ip, ip, ip]

@@ -121,6 +121,7 @@ struct KLogScope {      // route the names of the launches in this scope to `log
 #include "greek.hpp"
 #include "fill.hpp"
 #include "solver.hpp"
+#include "lu.hpp"
 #include "construct.hpp"
 
 // ================================================================================================
@@ -220,6 +221,9 @@ struct sfft_plan {
     unsigned long long* d_trace = nullptr;   // env SFFT_DF_TRACE=1: [nbc][16] wall-clock stamps of the critical path of chol_dataflow (development aid)
     int dataflow = 1;                   // env SFFT_CHOL_DF=0: launch-per-step factorisation (A/B testing)
     int df_groups = 64;                 // env SFFT_CHOL_DF_WG: persistent workgroups of chol_dataflow
+    hipGraphExec_t lu_exec = nullptr;   // the pivoted-LU chain (lu.hpp), captured the same way on its first use
+    std::string lu_graph_kernels;
+    LuPerm* d_luperm = nullptr;         // [panels] row permutation lists of the LU panels
     hipGraphExec_t chol_exec = nullptr; // the factorisation + back substitution chain, captured once (env SFFT_NO_GRAPH=1: plain launches)
     int use_graph = 1;
     int* h_status = nullptr;            // pinned: status word of the most recent attempt
@@ -813,10 +817,9 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PLAN_HIP(hipFuncSetAttribute((const void*)lu_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if ((size_t)(p->NEQfs + 2) * 8 + (size_t)CB * (CB + 1) * 8 > 150 * 1024) {
+    if (p->NEQfs > LU_MAX_ROWS) {       // (the pivoted-LU panel keeps 64 rows per thread of one 512-thread workgroup in registers)
         sfft_plan_destroy(p);
-        return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "linear system too large for the on-chip back substitution of this build");
+        return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "linear system too large for the pivoted-LU panel of this build");
     }
 
     // index map of Remove_LSFStripes (SFFTSubtract.py:83-90); with tied scaling (mode 2) the kept entry ij00[0]
@@ -1293,6 +1296,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_tflags, (size_t)nblk_b * (nblk_b + 1) + 1));
         PLAN_HIP(hipMemset(p->d_tflags, 0, ((size_t)nblk_b * (nblk_b + 1) + 1) * sizeof(unsigned int)));
         PLAN_TRY(dev_alloc(p, &p->d_w16, (size_t)nblk_b * 1024));
+        PLAN_TRY(dev_alloc(p, &p->d_luperm, (size_t)nblk_b));
         if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
         if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
         if (const char* ev = getenv("SFFT_PANEL4")) p->panel4 = atoi(ev);
@@ -1457,8 +1461,10 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_ibase, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_luperm, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_ibase, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
+    if (p->lu_exec) hipGraphExecDestroy(p->lu_exec);
+
     if (p->h_status) hipHostFree(p->h_status);
     for (void* q : ptrs) dev_free(q);
     for (int s = 0; s < SFFT_ST_COUNT; ++s) { if (p->ev[s][0]) hipEventDestroy(p->ev[s][0]); if (p->ev[s][1]) hipEventDestroy(p->ev[s][1]); }
@@ -1973,6 +1979,33 @@ __global__ void zero_f64(double* __restrict__ v, size_t n)
     if (k < n) v[k] = 0.0;
 }
 
+// L^T x = y on the factor's layout (lower triangle, border row n = y, rd = reciprocal diagonal), then Extend_Solution.  The pivoted LU
+// (lu.hpp) hands its U over in the same layout (lu_transpose_upper) and ends here too.
+static int run_back_substitution(sfft_plan* p, double* d_solution, hipStream_t s, bool have_winv)
+{
+    const int n = p->NEQfs;
+    // Extend_Solution's zeros (removed unknowns stay exactly 0).  A kernel, not hipMemsetAsync: captured into the plan's hipGraph a
+    // memset node was seen to leave these entries unwritten now and then when several plans replay their graphs from different
+    // host threads at once (bench.py --pairs: 5 forbidden entries of a pair's Solution holding stale bytes); SFFT_SOL_MEMSET=1 restores it
+    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, (size_t)p->NEQ);
+    const int nblk = (n + CB - 1) / CB;
+    if (p->back_variant == 1) {
+        if (!have_winv)     // (chol_dataflow leaves the inverses of the diagonal blocks behind itself)
+            SFFT_LAUNCH(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
+        SFFT_LAUNCH(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->d_epoch, p->d_status);
+    } else
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int kb = b * CB, nb = std::min(CB, n - kb);
+        const int rows_below = n - (kb + nb);
+        const int nslice = rows_below > 0 ? std::min(BACK_SLICES, (rows_below + CB - 1) / CB) : 1;
+        SFFT_LAUNCH(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter, p->d_rd);
+    }
+    SFFT_LAUNCH(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
+                       p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
+    LAUNCH_CHECK();
+    return SFFT_OK;
+}
+
 static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s)
 {
     const int n = p->NEQfs;
@@ -2054,76 +2087,88 @@ static int run_cholesky_launches(sfft_plan* p, double* d_solution, hipStream_t s
             SFFT_LAUNCH(chol_update, dim3(ntile, ntile), dim3(256), 0, s, p->d_A, p->ld, n, k, Dnxt);
     }
     LAUNCH_CHECK();
-    // Extend_Solution's zeros (removed unknowns stay exactly 0).  A kernel, not hipMemsetAsync: captured into the plan's hipGraph a
-    // memset node was seen to leave these entries unwritten now and then when several plans replay their graphs from different
-    // host threads at once (bench.py --pairs: 5 forbidden entries of a pair's Solution holding stale bytes); SFFT_SOL_MEMSET=1 restores it
-    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, (size_t)p->NEQ);
-    const int nblk = (n + CB - 1) / CB;
-    if (p->back_variant == 1) {
-        if (!dataflow)      // (chol_dataflow leaves the inverses of the diagonal blocks behind itself)
-            SFFT_LAUNCH(chol_inv_diag, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_winv);
-        SFFT_LAUNCH(chol_back_all, dim3(nblk), dim3(256), 0, s, p->d_A, p->ld, n, p->d_winv, p->d_xv, p->d_bflags, p->d_epoch, p->d_status);
-    } else
-    for (int b = nblk - 1; b >= 0; --b) {
-        const int kb = b * CB, nb = std::min(CB, n - kb);
-        const int rows_below = n - (kb + nb);
-        const int nslice = rows_below > 0 ? std::min(BACK_SLICES, (rows_below + CB - 1) / CB) : 1;
-        SFFT_LAUNCH(chol_back_step, dim3(nslice), dim3(256), 0, s, p->d_A, p->ld, n, kb, p->d_xv, p->d_partial, p->d_counter, p->d_rd);
-    }
-    SFFT_LAUNCH(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
-                       p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
     LAUNCH_CHECK();
-    return SFFT_OK;
+    return run_back_substitution(p, d_solution, s, dataflow);
 }
 
 // The factorisation and back substitution are ~35 dependent launches with constant arguments (the flag stamps come from a
 // device counter): captured once per plan and replayed as one hipGraph.  Streams that cannot be captured (the legacy default
 // stream) and any capture failure fall back to plain launches.
-static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
+typedef int (*solver_chain_fn)(sfft_plan*, double*, hipStream_t);
+static int run_chain_graph(sfft_plan* p, double* d_solution, hipStream_t s, solver_chain_fn chain, hipGraphExec_t* exec, std::string* kernels)
 {
-    if (!p->use_graph || s == nullptr || d_solution != p->d_sol) return run_cholesky_launches(p, d_solution, s);
-    if (!p->chol_exec) {
+    if (!p->use_graph || s == nullptr || d_solution != p->d_sol) return chain(p, d_solution, s);
+    if (!*exec) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
             p->use_graph = 0;
-            return run_cholesky_launches(p, d_solution, s);
+            return chain(p, d_solution, s);
         }
         int rc;
-        { KLogScope cap(&p->graph_kernels); p->graph_kernels.clear(); rc = run_cholesky_launches(p, d_solution, s); }
+        { KLogScope cap(kernels); kernels->clear(); rc = chain(p, d_solution, s); }
         const hipError_t e = hipStreamEndCapture(s, &graph);
         hipError_t e2 = hipSuccess;
-        if (rc == SFFT_OK && e == hipSuccess && graph) e2 = hipGraphInstantiate(&p->chol_exec, graph, nullptr, nullptr, 0);
+        if (rc == SFFT_OK && e == hipSuccess && graph) e2 = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
         if (graph) hipGraphDestroy(graph);
-        if (rc != SFFT_OK || e != hipSuccess || e2 != hipSuccess || !p->chol_exec) {
+        if (rc != SFFT_OK || e != hipSuccess || e2 != hipSuccess || !*exec) {
             (void)hipGetLastError();
-            p->chol_exec = nullptr;
+            *exec = nullptr;
             p->use_graph = 0;
-            return run_cholesky_launches(p, d_solution, s);
+            if (rc != SFFT_OK) return rc;          // the chain itself refused (e.g. a system beyond the LU panel's reach): not a capture problem
+            return chain(p, d_solution, s);
         }
     }
-    if (tl_klog) note_kernels(p->graph_kernels);
-    HIPCHK(hipGraphLaunch(p->chol_exec, s));
+    if (tl_klog) note_kernels(*kernels);
+    HIPCHK(hipGraphLaunch(*exec, s));
     return SFFT_OK;
+}
+
+static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
+{
+    return run_chain_graph(p, d_solution, s, run_cholesky_launches, &p->chol_exec, &p->graph_kernels);
+}
+
+// ---- pivoted LU (lu.hpp): the reference's solver (SFFTSubtract.py:15-23) ---------------------------------------------------------
+template <int W, int R>
+static void launch_lu_panel(sfft_plan* p, int n, int k0, int nb, LuPerm* perm, hipStream_t s)
+{
+    SFFT_LAUNCH((lu_panel<W, R>), dim3(1), dim3(LU_NT), 0, s, p->d_A, p->ld, n, k0, nb, perm, p->d_status);
+}
+
+static int run_lu_launches(sfft_plan* p, double* d_solution, hipStream_t s)
+{
+    const int n = p->NEQfs;
+    if (n > LU_MAX_ROWS) return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "linear system too large for the pivoted-LU panel of this build");
+    const int npan = (n + LU_NB - 1) / LU_NB;
+    unsigned int* d_queue = p->d_tflags + (size_t)npan * (npan + 1);
+    SFFT_LAUNCH(chol_begin, dim3(1), dim3(PANEL4_MAX_OUTER), 0, s, p->d_epoch, d_queue, p->d_pq);       // a new stamp for chol_back_all's flags
+    for (int pn = 0; pn < npan; ++pn) {
+        const int k0 = pn * LU_NB, nb = std::min(LU_NB, n - k0), m = n - k0;
+        LuPerm* perm = p->d_luperm + pn;
+        // rows per thread x sub-panel width: R x W = 64 doubles of the panel in registers per thread (512 threads)
+        if (m <= 1 * LU_NT) launch_lu_panel<16, 1>(p, n, k0, nb, perm, s);
+        else if (m <= 2 * LU_NT) launch_lu_panel<16, 2>(p, n, k0, nb, perm, s);
+        else if (m <= 3 * LU_NT) launch_lu_panel<16, 3>(p, n, k0, nb, perm, s);
+        else if (m <= 4 * LU_NT) launch_lu_panel<16, 4>(p, n, k0, nb, perm, s);
+        else if (m <= 8 * LU_NT) launch_lu_panel<8, 8>(p, n, k0, nb, perm, s);
+        else if (m <= 16 * LU_NT) launch_lu_panel<4, 16>(p, n, k0, nb, perm, s);
+        else if (m <= 32 * LU_NT) launch_lu_panel<2, 32>(p, n, k0, nb, perm, s);
+        else launch_lu_panel<1, 64>(p, n, k0, nb, perm, s);
+        const int right = n + 1 - (k0 + nb);                  // columns right of the panel, the right-hand side included (>= 1)
+        SFFT_LAUNCH(lu_swap_trsm, dim3((right + LU_NB - 1) / LU_NB), dim3(256), 0, s, p->d_A, p->ld, n, k0, nb, (const LuPerm*)perm);
+        const int below = n - (k0 + nb);
+        if (below > 0)
+            SFFT_LAUNCH(lu_gemm, dim3((right + LU_NB - 1) / LU_NB, (below + LU_NB - 1) / LU_NB), dim3(256), 0, s, p->d_A, p->ld, n, k0, nb);
+    }
+    SFFT_LAUNCH(lu_transpose_upper, dim3((n + 1 + LU_NB - 1) / LU_NB, npan), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_status);
+    LAUNCH_CHECK();
+    return run_back_substitution(p, d_solution, s, false);
 }
 
 static int run_lu(sfft_plan* p, double* d_solution, hipStream_t s)
 {
-    const int n = p->NEQfs;
-    for (int k = 0; k < n; ++k) {
-        SFFT_LAUNCH(lu_pivot, dim3(1), dim3(1024), 0, s, p->d_A, p->ld, n, k, p->d_status);
-        const int rem = n - k - 1;
-        if (rem > 0)
-            SFFT_LAUNCH(lu_rank1, dim3((rem + 1 + 63) / 64, (rem + 15) / 16), dim3(256), 0, s, p->d_A, p->ld, n, k);
-    }
-    LAUNCH_CHECK();
-    const size_t lds = (size_t)(n + 2) * 8;
-    SFFT_LAUNCH(lu_backsolve, dim3(1), dim3(1024), lds, s, p->d_A, p->ld, n, p->d_xv);
-    SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, d_solution, (size_t)p->NEQ);
-    SFFT_LAUNCH(scatter_solution, dim3((n + 255) / 256), dim3(256), 0, s, p->d_xv, n, p->d_idx, d_solution, p->NEQ,
-                       p->fa.tie_first, p->fa.tie_cnt, p->fa.tie_stride);
-    LAUNCH_CHECK();
-    return SFFT_OK;
+    return run_chain_graph(p, d_solution, s, run_lu_launches, &p->lu_exec, &p->lu_graph_kernels);
 }
 
 static int apply_prelim(sfft_plan* p, const double* d_I, cplx* dst, hipStream_t s);
@@ -2552,6 +2597,36 @@ extern "C" int sfft_get_solver_system(sfft_plan* p, double* d_bordered, int* d_i
     if (d_index) SFFT_LAUNCH(iota_or_copy, dim3((n + 255) / 256), dim3(256), 0, s, p->d_idx, n, d_index);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(s));
+    return SFFT_OK;
+}
+
+__global__ void __launch_bounds__(256) dbg_load_bordered(const double* __restrict__ src, int n, double* __restrict__ A, int ld)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c <= n) A[(size_t)r * ld + c] = src[(size_t)r * (n + 1) + c];
+}
+
+extern "C" int sfft_dbg_solve_dense(sfft_plan* p, const double* d_bordered, int use_lu, double* d_x, void* stream)
+{
+    if (!p || !d_bordered || !d_x) return set_err(SFFT_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    ON_DEVICE(p->dev);
+    const int n = p->NEQfs;
+    int rc;
+    SFFT_LAUNCH(set_i32, dim3(1), dim3(1), 0, s, p->d_status, 0);
+    SFFT_LAUNCH(dbg_load_bordered, dim3((n + 1 + 255) / 256, n + 1), dim3(256), 0, s, d_bordered, n, p->d_A, p->ld);
+    LAUNCH_CHECK();
+    {
+        StageTimer t(p, SFFT_ST_SOLVE, s);
+        if (use_lu) { if ((rc = run_lu(p, p->d_sol, s))) return rc; }
+        else { if ((rc = run_cholesky(p, p->d_sol, s))) return rc; }
+    }
+    HIPCHK(hipMemcpyAsync(p->h_status, p->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(d_x, p->d_xv, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    p->last_solver = use_lu ? 2 : 1;
+    if (!use_lu) p->chol_status = *p->h_status;
+    if (*p->h_status != 0) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
     return SFFT_OK;
 }
 

@@ -1375,72 +1375,6 @@ __global__ void __launch_bounds__(256) scatter_solution(const double* __restrict
     if (t >= 1 && t < tie_cnt) solution[tie_first + t * tie_stride] = xv[tie_first];   // position of tie_first in x equals its value
 }
 
-// ---- LU with partial pivoting (fallback; matches the reference's getrf/gesv semantics) --------------------
-// A is [(n+1)][ld]; rows < n, columns <= n (column n = rhs).  Unblocked right-looking elimination.
-__global__ void __launch_bounds__(1024) lu_pivot(double* __restrict__ A, int ld, int n, int k, int* __restrict__ status)
-{
-    __shared__ double bestv[16];
-    __shared__ int besti[16];
-    __shared__ int piv;
-    const int tid = threadIdx.x;
-    double bv = -1.0; int bi = k;
-    for (int i = k + tid; i < n; i += 1024) {
-        const double v = fabs(A[(size_t)i * ld + k]);
-        if (v > bv) { bv = v; bi = i; }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_down(bv, off); const int oi = __shfl_down(bi, off);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 16; ++w) if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
-        piv = bi;
-        if (!(bv > 0.0)) atomicOr(status, 2);
-    }
-    __syncthreads();
-    const int p = piv;
-    if (p != k) {
-        for (int c = tid; c <= n; c += 1024) {
-            const double t = A[(size_t)k * ld + c];
-            A[(size_t)k * ld + c] = A[(size_t)p * ld + c];
-            A[(size_t)p * ld + c] = t;
-        }
-    }
-    __syncthreads();
-    const double d = A[(size_t)k * ld + k];
-    for (int i = k + 1 + tid; i < n; i += 1024) A[(size_t)i * ld + k] /= d;
-}
-
-__global__ void __launch_bounds__(256) lu_rank1(double* __restrict__ A, int ld, int n, int k)
-{
-    const int j = k + 1 + blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ib = k + 1 + blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
-    if (j > n) return;
-    const double u = A[(size_t)k * ld + j];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = ib + r;
-        if (i < n) A[(size_t)i * ld + j] = fma(-A[(size_t)i * ld + k], u, A[(size_t)i * ld + j]);
-    }
-}
-
-__global__ void __launch_bounds__(1024) lu_backsolve(const double* __restrict__ A, int ld, int n, double* __restrict__ xv)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* yv = reinterpret_cast<double*>(smem_raw);
-    const int tid = threadIdx.x;
-    for (int c = tid; c < n; c += 1024) yv[c] = A[(size_t)c * ld + n];
-    __syncthreads();
-    for (int i = n - 1; i >= 0; --i) {
-        if (tid == 0) yv[i] = yv[i] / A[(size_t)i * ld + i];
-        __syncthreads();
-        const double xi = yv[i];
-        for (int c = tid; c < i; c += 1024) yv[c] = fma(-A[(size_t)c * ld + i], xi, yv[c]);
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 1024) xv[i] = yv[i];
-}
+// (the pivoted LU lives in lu.hpp)
 
 #endif

@@ -128,6 +128,20 @@ class Plan:
         return B[:n, :n], B[n, :n], idx
 
     @_locked
+    def solve_dense(self, A, b, use_lu=True):
+        """The dense solver alone (sfft_dbg_solve_dense): x with A x = b for a caller's [n][n] matrix, n = SOLVER_N.  use_lu: LU with
+        partial pivoting (any nonsingular A), else the Cholesky path (symmetric positive definite A).  Raises LinAlgError when singular."""
+        n = self.query("SOLVER_N")
+        assert tuple(A.shape) == (n, n) and tuple(b.shape) == (n,), (A.shape, b.shape, n)
+        B = torch.zeros((n + 1, n + 1), dtype=torch.float64, device=self._dev())
+        B[:n, :n] = A
+        B[:n, n] = b
+        B[n, :n] = b
+        x = torch.empty(n, dtype=torch.float64, device=self._dev())
+        _lib.check(_lib.lib().sfft_dbg_solve_dense(self._h, B.data_ptr(), 1 if use_lu else 0, x.data_ptr(), self._stream_ptr(self._dev())))
+        return x
+
+    @_locked
     def forward_spectrum(self, I, i, j):
         self._check_img(I, "PixA_I")
         out = torch.empty((self.N0, self.N1 // 2 + 1), dtype=torch.complex128, device=self._dev())

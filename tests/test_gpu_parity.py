@@ -592,6 +592,16 @@ def test_config3_bspline_strip_matches_oracle(dev, shape):
     assert rel_rms_err(D, D_o) <= 1e-6
     ij00 = np.arange(8 * 17 + 8, 25 * 289, 289)
     assert np.all(sol[ij00] == sol[ij00[0]])
+    if shape == (6144, 96):     # the same system through the reference's own solver, LU with partial pivoting (lu.hpp), at n = 7207: same gates
+        plan.set_force_lu(True)
+        try:
+            sol_lu, D_lu, _ = BGSS.GSS(REF, SCI, mREF, mSCI, cfg, VERBOSE_LEVEL=0)
+            assert plan.query("LAST_SOLVER") == 2
+        finally:
+            plan.set_force_lu(False)
+        assert rel_rms_err(D_lu, D_o) <= 1e-6
+        assert np.all(sol_lu[ij00] == sol_lu[ij00[0]])
+        assert np.max(np.abs(sol_lu - sol)) <= 1e-6 * np.max(np.abs(sol))
     clear_plan_cache()
 
 
@@ -623,6 +633,15 @@ def test_config2_full_size_matches_oracle(dev, big):
     Da = plan.apply(g["REF"], g["SCI"], _to(dev, sol_o)).cpu().numpy()
     assert rms(Da - D_o) <= 1e-10 * rms(pair["SCI"])
     assert rel_rms_err(diff.cpu().numpy(), D_o) <= 1e-6
+    # the same pair through the reference's own solver, LU with partial pivoting (lu.hpp; n = 1735): same end-to-end gate
+    plan.set_force_lu(True)
+    try:
+        sol_lu, diff_lu = plan.subtract(g["REF"], g["SCI"], g["mREF"], g["mSCI"])
+        assert plan.query("LAST_SOLVER") == 2
+    finally:
+        plan.set_force_lu(False)
+    assert rel_rms_err(diff_lu.cpu().numpy(), D_o) <= 1e-6
+    assert float((sol_lu - sol).abs().max()) <= 1e-8 * float(sol.abs().max())
 
 
 @pytest.mark.parametrize("shape", [(9232, 128), (128, 9216)], ids=["cols9232", "rows9216"])
