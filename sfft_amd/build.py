@@ -1,32 +1,57 @@
-"""Build recipe for the HIP library (gfx950 only).  `python -m sfft_amd.build` or __graft_entry__.build()."""
+"""Build recipe for the HIP library (gfx950 only).  `python -m sfft_amd.build` or __graft_entry__.build().
+Two translation units -- csrc/sfft_amd.hip (everything but the pivoted LU) and csrc/lu.hip (the LU kernels: one panel kernel
+instantiation per register-tile shape, minutes of compile time) -- compiled side by side into build/*.o and linked into one
+libsfft_amd.so; an object is rebuilt only when one of its own sources is newer."""
 import os
 import subprocess
 import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG_DIR, "csrc", "sfft_amd.hip")
+CSRC = os.path.join(PKG_DIR, "csrc")
+SRC = os.path.join(CSRC, "sfft_amd.hip")
 LIB = os.path.join(PKG_DIR, "libsfft_amd.so")
+OBJ_DIR = os.path.join(os.path.dirname(PKG_DIR), "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "sfft_amd.h")
+LU_ONLY = ("lu.hip", "lu.hpp")                      # sources only csrc/lu.hip sees; lu_api.hpp is seen by both units
+
+
+def _units():
+    every = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    main_deps = [f for f in every if os.path.basename(f) not in LU_ONLY] + ([HEADER] if os.path.exists(HEADER) else [])
+    lu_deps = [os.path.join(CSRC, f) for f in ("lu.hip", "lu.hpp", "lu_api.hpp")]
+    return [(SRC, os.path.join(OBJ_DIR, "sfft_amd.o"), main_deps), (os.path.join(CSRC, "lu.hip"), os.path.join(OBJ_DIR, "lu.o"), lu_deps)]
+
+
+def _stale(target, deps):
+    return (not os.path.exists(target)) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(target)
 
 
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    newest = max(os.path.getmtime(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(PKG_DIR, "csrc")) for f in fs)
-    hdr = os.path.join(os.path.dirname(PKG_DIR), "include", "sfft_amd.h")
-    if os.path.exists(hdr):
-        newest = max(newest, os.path.getmtime(hdr))
-    return newest > os.path.getmtime(LIB)
+    units = _units()
+    return any(_stale(o, d) for _, o, d in units) or _stale(LIB, [o for _, o, _ in units if os.path.exists(o)] or [SRC])
 
 
 def build_library(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    units = _units()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    procs = []
+    for src, obj, deps in units:
+        if force or _stale(obj, deps):
+            cmd = [HIPCC] + CFLAGS + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    objs = [o for _, o, _ in units]
+    if procs or force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return LIB
 
 

@@ -1,0 +1,80 @@
+// lu.hip -- translation unit of the pivoted-LU kernels (lu.hpp) and their launchers (lu_api.hpp).  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+typedef double d4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d4s mfma16(double av, double bv, d4s acc) { return __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0); }
+
+#include "lu.hpp"
+
+template <int W, int R>
+static const char* panel(const char* name, double* A, int ld, int n, int k0, int nb, LuPerm* perm, int* status, hipStream_t s)
+{
+    hipLaunchKernelGGL((lu_panel<W, R>), dim3(1), dim3(LU_NT), 0, s, A, ld, n, k0, nb, perm, status);
+    return name;
+}
+
+// sub-panel width W x rows per thread R (256 threads): W R <= 96 doubles keeps the register tile in the 256 directly addressable
+// registers.  W = 16 is the widest sub-panel whose per-column candidate traffic (write the wave's row, read the winner's) stays
+// small beside the elimination itself; more rows than 16-wide tiles hold take narrower sub-panels.
+static const char* launch_panel(double* A, int ld, int n, int k0, int nb, LuPerm* perm, int* status, hipStream_t s)
+{
+    const int rpt = (n - k0 + LU_NT - 1) / LU_NT;           // rows per thread
+#define LU_CASE(W, R) if (rpt <= R) return panel<W, R>("lu_panel<" #W "," #R ">", A, ld, n, k0, nb, perm, status, s)
+    LU_CASE(16, 2); LU_CASE(16, 4); LU_CASE(16, 6); LU_CASE(8, 8); LU_CASE(8, 12); LU_CASE(4, 16); LU_CASE(4, 24); LU_CASE(2, 48);
+#undef LU_CASE
+    return panel<1, 96>("lu_panel<1,96>", A, ld, n, k0, nb, perm, status, s);
+}
+
+static inline void say(lu_note_fn note, const char* name) { if (note && name) note(name); }
+
+// U12 = L11^-1 A12 (after the rows of `perm`, if any, went into place) and A22 -= L21 U12 on the columns [k0 + nb, cend)
+static void update(double* A, int ld, int n, int k0, int nb, const LuPerm* perm, int cend, hipStream_t s, lu_note_fn note)
+{
+    const int right = cend - (k0 + nb), below = n - (k0 + nb);
+    if (right <= 0) return;
+    hipLaunchKernelGGL(lu_swap_trsm, dim3((right + LU_NB - 1) / LU_NB), dim3(256), 0, s, A, ld, n, k0, nb, perm, cend);
+    say(note, "lu_swap_trsm");
+    if (below > 0) {
+        hipLaunchKernelGGL(lu_gemm, dim3((right + LU_NB - 1) / LU_NB, (below + LU_NB - 1) / LU_NB), dim3(256), 0, s, A, ld, n, k0, nb, cend);
+        say(note, "lu_gemm");
+    }
+}
+
+static void apply_perm(double* A, int ld, const LuPerm* perm, int cbeg, int cend, hipStream_t s, lu_note_fn note)
+{
+    if (cend <= cbeg) return;
+    hipLaunchKernelGGL(lu_apply_perm, dim3((cend - cbeg + LU_NB - 1) / LU_NB), dim3(256), 0, s, A, ld, perm, cbeg, cend);
+    say(note, "lu_apply_perm");
+}
+
+// Panels of 64 columns.  Up to LU_ONE_KERNEL_ROWS rows the panel is ONE launch (16-column sub-panels inside the kernel, left-looking).
+// Taller panels would need sub-panels of 8, 4, 2 columns, whose left-looking updates re-read the panel's L columns 224 / 480 / 992 times
+// per row through one CU: they are factored in four GROUPS of 16 columns instead -- each group one panel launch on all rows, followed by
+// the update of the panel's remaining columns by the whole chip -- and the groups' row lists are then applied to the rest of the matrix.
+#define LU_ONE_KERNEL_ROWS (6 * LU_NT)
+#define LU_GROUP 16
+void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, double* rd, hipStream_t s, lu_note_fn note)
+{
+    const int npan = (n + LU_NB - 1) / LU_NB;
+    for (int pn = 0; pn < npan; ++pn) {
+        const int K0 = pn * LU_NB, NBo = n - K0 < LU_NB ? n - K0 : LU_NB;
+        LuPerm* pl = perms + (size_t)LU_PERMS_PER_PANEL * pn;
+        if (n - K0 <= LU_ONE_KERNEL_ROWS) {
+            say(note, launch_panel(A, ld, n, K0, NBo, pl, status, s));
+            update(A, ld, n, K0, NBo, pl, n + 1, s, note);
+            continue;
+        }
+        const int ngrp = (NBo + LU_GROUP - 1) / LU_GROUP;
+        for (int g = 0; g < ngrp; ++g) {
+            const int k0 = K0 + LU_GROUP * g, nb = K0 + NBo - k0 < LU_GROUP ? K0 + NBo - k0 : LU_GROUP;
+            say(note, launch_panel(A, ld, n, k0, nb, pl + g, status, s));
+            apply_perm(A, ld, pl + g, K0, k0, s, note);                  // the panel's earlier columns: their rows follow
+            update(A, ld, n, k0, nb, pl + g, K0 + NBo, s, note);         // the panel's later columns
+        }
+        for (int g = 0; g < ngrp; ++g) apply_perm(A, ld, pl + g, K0 + NBo, n + 1, s, note);      // everything right of the panel, list after list
+        update(A, ld, n, K0, NBo, nullptr, n + 1, s, note);
+    }
+    hipLaunchKernelGGL(lu_transpose_upper, dim3((n + 1 + LU_NB - 1) / LU_NB, npan), dim3(256), 0, s, A, ld, n, rd, status);
+    say(note, "lu_transpose_upper");
+}

@@ -1,5 +1,5 @@
 // lu.hpp -- dense solve with the reference's own semantics: LU with partial (row) pivoting, blocked for the matrix cores.
-// Part of libsfft_amd (MI355X / gfx950); included by sfft_amd.hip only (after solver.hpp).
+// Part of libsfft_amd (MI355X / gfx950); included by lu.hip only (host side: lu_api.hpp).
 //
 // The reference solves every system by pivoted LU (np.linalg.solve / cupy.linalg.solve -> getrf + getrs,
 // sfft/sfftcore/SFFTSubtract.py:15-23, 398-403, 743-747).  Here LU takes the systems whose Cholesky attempt meets a non-positive
@@ -28,12 +28,7 @@
 #ifndef SFFT_AMD_LU_HPP
 #define SFFT_AMD_LU_HPP
 
-#define LU_NB 64
-#define LU_NT 512
-#define LU_MAXTOUCH (2 * LU_NB)
-#define LU_MAX_ROWS (LU_NT * 64)     // rows of the largest panel: 64 per thread
-
-struct LuPerm { int count; int pad[3]; int pos[LU_MAXTOUCH]; int src[LU_MAXTOUCH]; };     // one per panel
+#include "lu_api.hpp"
 
 template <int W> __device__ __forceinline__ void lu_ld_row(const double* __restrict__ p, double (&out)[W])
 {
@@ -54,162 +49,247 @@ template <int W> __device__ __forceinline__ void lu_st_row(double* __restrict__ 
     } else p[0] = in[0];
 }
 
-// lazy (left-looking) update of the registers' sub-panel with C earlier panel columns kb .. kb + C - 1:
-// a[q][jj] -= L[row q][kb + u] * U[kb + u][c0 + jj], taken QG rows at a time (QG x C doubles of L in flight per thread)
-template <int W, int R, int QG, int C>
-__device__ __forceinline__ void lu_lazy_chunk(double (&a)[R][W], const int (&loc)[R], const double* __restrict__ A, int ld, int k0, int kb, int c0,
-                                              const double (*Ub)[LU_NB + 1])
+// ---- cross-lane reductions on the DPP path (no LDS round trips on the pivot chain) -------------------------------------------------
+// inclusive scan steps row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast 15 into rows 1 and 3 and row_bcast 31 into
+// rows 2 and 3: lane 63 holds the wave's result
+template <int CTRL, int RM> __device__ __forceinline__ unsigned int lu_dpp_max32(unsigned int v)
 {
-#pragma unroll
-    for (int q0 = 0; q0 < R; q0 += QG) {
-        double l[QG][C];
-#pragma unroll
-        for (int q = 0; q < QG; ++q) lu_ld_row<C>(A + (size_t)loc[q0 + q] * ld + k0 + kb, l[q]);
-#pragma unroll
-        for (int u = 0; u < C; ++u) {
-            double ub[W];
-#pragma unroll
-            for (int jj = 0; jj < W; ++jj) ub[jj] = Ub[kb + u][c0 + jj];
-#pragma unroll
-            for (int q = 0; q < QG; ++q)
-#pragma unroll
-                for (int jj = 0; jj < W; ++jj) a[q0 + q][jj] = fma(-l[q][u], ub[jj], a[q0 + q][jj]);
-        }
-    }
+    const unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, 0xF, false);
+    return t > v ? t : v;
+}
+__device__ __forceinline__ unsigned int lu_wave_max32(unsigned int v)
+{
+    v = lu_dpp_max32<0x111, 0xF>(v); v = lu_dpp_max32<0x112, 0xF>(v); v = lu_dpp_max32<0x114, 0xF>(v); v = lu_dpp_max32<0x118, 0xF>(v);
+    v = lu_dpp_max32<0x142, 0xA>(v); v = lu_dpp_max32<0x143, 0xC>(v);
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit maximum as two 32-bit ones (one v_max_u32_dpp per step): the high words, then the low words of the lanes that hold the
+// largest high word
+__device__ __forceinline__ unsigned long long lu_wave_max64(unsigned long long v)
+{
+    const unsigned int hi = (unsigned int)(v >> 32), lo = (unsigned int)v;
+    const unsigned int mh = lu_wave_max32(hi);
+    const unsigned int ml = lu_wave_max32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
+}
+template <int CTRL, int RM> __device__ __forceinline__ unsigned int lu_dpp_min32(unsigned int v)
+{
+    const unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, RM, 0xF, false);
+    return t < v ? t : v;
+}
+__device__ __forceinline__ unsigned int lu_wave_min32(unsigned int v)
+{
+    v = lu_dpp_min32<0x111, 0xF>(v); v = lu_dpp_min32<0x112, 0xF>(v); v = lu_dpp_min32<0x114, 0xF>(v); v = lu_dpp_min32<0x118, 0xF>(v);
+    v = lu_dpp_min32<0x142, 0xA>(v); v = lu_dpp_min32<0x143, 0xC>(v);
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// 1 / x to ~1 ulp: hardware estimate + two Newton steps (an IEEE division is ~40 dependent instructions on the pivot chain)
+__device__ __forceinline__ double lu_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+// |v| as an ordered integer key: IEEE bit patterns of non-negative doubles sort like unsigned integers (a NaN sorts above
+// infinity: it becomes the pivot and the solution comes out NaN, as from LAPACK)
+__device__ __forceinline__ unsigned long long lu_key(double v)
+{
+    return (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull;
+}
+
+// compile-time loop: the body sees its index as a constant (a `#pragma unroll` loop this large is only partially unrolled, and a
+// runtime index into the register tile sends the tile to scratch)
+template <int I, int N, typename F> __device__ __forceinline__ void lu_static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); lu_static_for<I + 1, N>(f); }
+}
+
+#ifdef LU_TRACE          // scripts/micro/lu_panel_trace.hip: s_memtime stamps of thread 0 at the phase boundaries of one panel launch
+__device__ long long lu_trace[256];
+#define LU_STAMP(slot) do { if (threadIdx.x == 0) lu_trace[slot] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define LU_STAMP(slot) do { } while (0)
+#endif
+
+struct __attribute__((aligned(16))) LuCand { double piv; int pos; int phys; };      // piv: the candidate's entry in the pivot column (its magnitude is the key)
+
+template <int CTRL> __device__ __forceinline__ unsigned int lu_quad_max32(unsigned int v)
+{
+    const unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+    return t > v ? t : v;
+}
+template <int CTRL> __device__ __forceinline__ unsigned int lu_quad_min32(unsigned int v)
+{
+    const unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, 0xF, 0xF, false);
+    return t < v ? t : v;
+}
+
+// The panel kernel.  256 threads = one wave per SIMD (the pivot chain is instruction-issue bound: everything a column needs is
+// executed by every wave, so fewer, fatter waves win); thread t owns PHYSICAL rows k0 + t + 256 q, q < R, for the whole kernel.
+// A row never changes its thread: a pivot exchange only exchanges the POSITIONS pos[q] the two rows stand for (idamax's first-row
+// tie rule needs positions; the data needs no move at all).
 template <int W, int R>
 __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld, int n, int k0, int nb, LuPerm* __restrict__ perm,
                                                   int* __restrict__ status)
 {
     constexpr int NW = LU_NT / 64;
+    static_assert(NW == 4, "the cross-wave selection reduces over a lane quad");
+    constexpr int WP = W < 2 ? 2 : W;
+    constexpr int NS = LU_NB > W ? LU_NB - W : 1;   // columns a panel can have right of a sub-panel
     __shared__ double Ub[LU_NB][LU_NB + 1];         // pivot rows of the panel: Ub[i][c] = U[k0 + i][k0 + c], c >= i
-    __shared__ double Lp[W][LU_NB + 1];             // L entries of the newest W pivot rows (panel columns < c0 + W)
-    __shared__ double Tt[W][LU_NB + 1];             // their entries right of the sub-panel with the earlier sub-panels' updates applied
-    __shared__ __attribute__((aligned(16))) double cdat[2][NW][W < 2 ? 2 : W];      // candidate row of each wave
-    __shared__ __attribute__((aligned(16))) double ddat[2][W < 2 ? 2 : W];          // the row that sits at the pivot position
-    __shared__ double cval[2][NW];
-    __shared__ int crow[2][NW], cloc[2][NW], dloc[2];
-    __shared__ int ploc[LU_NB];                     // physical row that holds pivot row k0 + i
+    __shared__ double Lp[W < 32 ? W : 32][LU_NB + 1];      // L entries of the newest W pivot rows (panel columns < c0 + W); W = 64 is always one pass
+    __shared__ double Tt[W < 32 ? W : 32][LU_NB + 1];      // their entries right of the sub-panel (raw, then with the earlier sub-panels' updates applied)
+    __shared__ __attribute__((aligned(16))) double cdat[2][NW][WP];      // candidate row of each wave
+    __shared__ LuCand cand[2][NW];
+    __shared__ int ploc[LU_NB];                     // physical row of pivot row k0 + i
     __shared__ int tcount, tpos[LU_MAXTOUCH], tsrc[LU_MAXTOUCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // rows of this thread: position pos(q) = k0 + tid + LU_NT q (constant); loc[q] = physical row whose data sits at that position now
     double a[R][W];
-    int loc[R];
+    int pos[R];                                     // the position physical row k0 + tid + 256 q stands for (-1: no such row)
 #pragma unroll
-    for (int q = 0; q < R; ++q) loc[q] = min(k0 + tid + LU_NT * q, n - 1);      // (slots past the last row point at a valid row and stay masked)
+    for (int q = 0; q < R; ++q) pos[q] = (k0 + tid + LU_NT * q < n) ? k0 + tid + LU_NT * q : -1;
     if (tid == 0) tcount = 0;
+    if (tid < LU_MAXTOUCH) { tpos[tid] = k0; tsrc[tid] = k0; }
+    const bool one_pass = (nb <= W);                // the whole panel is one sub-panel: rows go straight to their final places
 
+    LU_STAMP(0);
     for (int c0 = 0; c0 < nb; c0 += W) {
         const bool full = (c0 + W <= nb);
-        // first slot that holds rows at or below the sub-panel's first pivot position (positions k0 .. k0 + 63 are slot 0 of threads 0 .. 63)
-        // ---- (a) load the sub-panel's columns of every row at or below position k0 + c0 ------------------------------------
+        LU_STAMP(1 + 8 * (c0 / W));
+        // ---- (a) the sub-panel's columns of every row, (b) the earlier sub-panels' updates (left-looking; rows that are pivot rows
+        //      already ride along untouched and stay masked below).  All loads are independent of each other: the raw columns and
+        //      the first chunk of L are in flight together, each further chunk is fetched a step ahead ------------------------------
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            const double* __restrict__ src = A + (size_t)loc[q] * ld + k0 + c0;
+            const double* __restrict__ src = A + (size_t)min(k0 + tid + LU_NT * q, n - 1) * ld + k0 + c0;
             if (full) lu_ld_row<W>(src, a[q]);
             else {
 #pragma unroll
                 for (int jj = 0; jj < W; ++jj) a[q][jj] = src[min(jj, nb - 1 - c0)];
             }
         }
-        // ---- (b) the earlier sub-panels' updates (rows above position k0 + c0 are pivot rows: untouched here, masked below) -------
         if (c0 > 0) {
-            // QG x C doubles of L in flight per thread (<= 32): 16-byte loads wherever the chunk allows
-            constexpr int QG = R < 16 ? R : 16;
-            constexpr int C = (QG * 8 <= 32) ? 8 : (QG * 4 <= 32) ? 4 : 2;
-            int kb = 0;
-            for (; kb + C <= c0; kb += C) lu_lazy_chunk<W, R, QG, C>(a, loc, A, ld, k0, kb, c0, Ub);
-            for (; kb < c0; ++kb) lu_lazy_chunk<W, R, QG, 1>(a, loc, A, ld, k0, kb, c0, Ub);
-        }
-        // ---- (c) factor the W columns: one barrier per column -----------------------------------------------------------------
+            if constexpr (R <= 16) {
+                // C columns of L per step and row.  A step is one memory round trip (the L columns come from L2 / HBM, ~1.5 us) and only
+                // R C 16-byte-pair loads deep, so the steps must be FEW: C = min(W, 16) -- at W = 16 three steps for the last sub-panel
+                // (two columns per step with the next step prefetched took 24 steps: 35 us per sub-panel at R = 6)
+                constexpr int C = W < 16 ? W : 16;
+                for (int kb = 0; kb < c0; kb += C) {
+                    double lc[R][C];
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            if (c0 + j < nb) {                                  // (workgroup uniform)
-                const int kd = k0 + c0 + j;                     // the position this column's pivot row goes to
-                const int buf = j & 1;
-                double bv = -1.0; int br = 0x7fffffff;
+                    for (int q = 0; q < R; ++q) lu_ld_row<C>(A + (size_t)min(k0 + tid + LU_NT * q, n - 1) * ld + k0 + kb, lc[q]);
 #pragma unroll
-                for (int q = 0; q < R; ++q) {
-                    const int pos = k0 + tid + LU_NT * q;
-                    const double v = fabs(a[q][j]);
-                    if (pos >= kd && pos < n && v > bv) { bv = v; br = pos; }          // q ascending: ties keep the first position
-                }
+                    for (int u = 0; u < C; ++u) {
+                        double ub[W];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double ov = __shfl_xor(bv, off); const int orow = __shfl_xor(br, off);
-                    if (ov > bv || (ov == bv && orow < br)) { bv = ov; br = orow; }
-                }
-#pragma unroll
-                for (int q = 0; q < R; ++q)
-                    if (k0 + tid + LU_NT * q == br) {           // the wave's candidate: its whole sub-panel row and its physical row
-#pragma unroll
-                        for (int jj = 0; jj < W; ++jj) cdat[buf][wv][jj] = a[q][jj];
-                        cloc[buf][wv] = loc[q];
-                    }
-                if (lane == 0) { cval[buf][wv] = bv; crow[buf][wv] = br; }
-                if (tid == c0 + j) {                            // the row that sits at the pivot position (slot 0 of thread c0 + j)
-#pragma unroll
-                    for (int jj = 0; jj < W; ++jj) ddat[buf][jj] = a[0][jj];
-                    dloc[buf] = loc[0];
-                }
-                __syncthreads();
-                double gv = -1.0; int gr = 0x7fffffff, gw = 0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const double v = cval[buf][w]; const int r = crow[buf][w];
-                    if (v > gv || (v == gv && r < gr)) { gv = v; gr = r; gw = w; }
-                }
-                if (gv > 0.0) {
-                    double prow[W];
-#pragma unroll
-                    for (int jj = 0; jj < W; ++jj) prow[jj] = cdat[buf][gw][jj];
-                    const int pl = cloc[buf][gw];
-                    if (gr != kd) {                              // the row from the pivot position goes where the pivot row came from
+                        for (int jj = 0; jj < W; ++jj) ub[jj] = Ub[kb + u][c0 + jj];
 #pragma unroll
                         for (int q = 0; q < R; ++q)
-                            if (k0 + tid + LU_NT * q == gr) {
 #pragma unroll
-                                for (int jj = 0; jj < W; ++jj) a[q][jj] = ddat[buf][jj];
-                                loc[q] = dloc[buf];
-                            }
+                            for (int jj = 0; jj < W; ++jj) a[q][jj] = fma(-lc[q][u], ub[jj], a[q][jj]);
                     }
-                    if (tid == c0 + j) {
+                }
+            } else {
+                for (int kb = 0; kb < c0; ++kb) {
 #pragma unroll
-                        for (int jj = 0; jj < W; ++jj) a[0][jj] = prow[jj];
-                        loc[0] = pl;
-                    }
-                    const double rp = 1.0 / prow[j];             // (dgetf2 scales by the reciprocal too)
+                    for (int q0 = 0; q0 < R; q0 += 8) {
+                        double l[8];
 #pragma unroll
-                    for (int q = 0; q < R; ++q) {
-                        const int pos = k0 + tid + LU_NT * q;
-                        if (pos > kd && pos < n) {
-                            const double l = a[q][j] * rp;
-                            a[q][j] = l;
+                        for (int q = 0; q < 8; ++q) l[q] = A[(size_t)min(k0 + tid + LU_NT * (q0 + q), n - 1) * ld + k0 + kb];
+                        double ub[W];
 #pragma unroll
-                            for (int jj = 0; jj < W; ++jj)          // (constant trip count: `jj = j + 1` stays a loop and keeps `a` in scratch)
-                                if (jj > j) a[q][jj] = fma(-l, prow[jj], a[q][jj]);
-                        }
-                    }
-                    if (tid == 0) ploc[c0 + j] = pl;
-                    if (tid >= j && tid < W) Ub[c0 + j][c0 + tid] = cdat[buf][gw][tid];
-                } else {                                         // no nonzero (or only NaN) entries left in this column: singular
-                    if (tid == 0) atomicOr(status, 2);
-                    if (tid == c0 + j) {
-                        ploc[c0 + j] = loc[0];
+                        for (int jj = 0; jj < W; ++jj) ub[jj] = Ub[kb][c0 + jj];
 #pragma unroll
-                        for (int jj = 0; jj < W; ++jj)
-                            if (jj >= j) Ub[c0 + j][c0 + jj] = a[0][jj];
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int jj = 0; jj < W; ++jj) a[q0 + q][jj] = fma(-l[q], ub[jj], a[q0 + q][jj]);
                     }
                 }
             }
         }
-        // ---- (d) the sub-panel goes back to its physical rows ------------------------------------------------------------------
+        LU_STAMP(2 + 8 * (c0 / W));
+        // ---- (c) factor the W columns: one barrier per column -----------------------------------------------------------------
+        lu_static_for<0, W>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (c0 + j < nb) {                                  // (workgroup uniform)
+                const int kd = k0 + c0 + j;                     // the position this column's pivot row goes to
+                const int buf = j & 1;
+                unsigned long long bk = 0ull; int bp = 0x7fffffff;
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const unsigned long long key = (pos[q] >= kd) ? lu_key(a[q][j]) : 0ull;
+                    const bool better = key > bk || (key == bk && key != 0ull && pos[q] < bp);     // ties: the first POSITION (idamax)
+                    bk = better ? key : bk;
+                    bp = better ? pos[q] : bp;
+                }
+                const unsigned long long wk = lu_wave_max64(bk);
+                const int wp = (int)lu_wave_min32((bk == wk && wk != 0ull) ? (unsigned int)bp : 0x7fffffffu);
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+                    if (pos[q] == wp) {                         // the wave's candidate: its row from column j on (wp = 0x7fffffff: nobody)
+#pragma unroll
+                        for (int jj = 0; jj < W; ++jj)
+                            if (jj >= j) cdat[buf][wv][jj] = a[q][jj];
+                        cand[buf][wv] = LuCand{a[q][j], wp, k0 + tid + LU_NT * q};
+                    }
+                if (wk == 0ull && lane == 0) cand[buf][wv] = LuCand{0.0, 0x7fffffff, k0};
+                if (j >= 4 && j <= 6) LU_STAMP(200 + 4 * (j - 4) + 0);
+                __syncthreads();
+                if (j >= 4 && j <= 6) LU_STAMP(200 + 4 * (j - 4) + 1);
+                // every lane reads candidate (lane & 3); two butterfly steps inside the lane quad give every lane the workgroup's winner
+                const LuCand cd = cand[buf][lane & 3];
+                const unsigned long long ckey = lu_key(cd.piv);
+                const unsigned int chi = (unsigned int)(ckey >> 32), clo = (unsigned int)ckey;
+                const unsigned int ghi = lu_quad_max32<0x4E>(lu_quad_max32<0xB1>(chi));
+                const unsigned int glo = lu_quad_max32<0x4E>(lu_quad_max32<0xB1>(chi == ghi ? clo : 0u));
+                const unsigned long long gk = ((unsigned long long)ghi << 32) | glo;
+                unsigned int gru = lu_quad_min32<0xB1>(ckey == gk ? (unsigned int)cd.pos : 0x7fffffffu);
+                gru = lu_quad_min32<0x4E>(gru);
+                const int gr = (int)gru;
+                if (gk != 0ull) {
+                    const int gw = __ffsll((long long)__ballot(cd.pos == gr && ckey == gk)) - 1;      // (< 4: the quads repeat)
+                    if (tid == 0) ploc[c0 + j] = __builtin_amdgcn_readlane(cd.phys, gw);
+                    double prow[W];
+#pragma unroll
+                    for (int jj = 0; jj < W; ++jj) prow[jj] = (jj >= j) ? cdat[buf][gw][jj] : 0.0;
+                    // the pivot element comes with the candidate record: its reciprocal is under way while the row itself is still being read
+                    const double rp = lu_rcp(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cd.piv), gw),
+                                                              __builtin_amdgcn_readlane(__double2loint(cd.piv), gw)));      // (dgetf2 scales by the reciprocal too)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {                // branch-free: rows that are not below the pivot position take l = 0
+                        pos[q] = (pos[q] == kd) ? gr : (pos[q] == gr ? kd : pos[q]);      // the two rows exchange positions, not data
+                        const bool act = pos[q] > kd;
+                        const double l = act ? a[q][j] * rp : 0.0;
+                        a[q][j] = act ? l : a[q][j];
+#pragma unroll
+                        for (int jj = 0; jj < W; ++jj)          // (constant trip count: `jj = j + 1` stays a loop and keeps `a` in scratch)
+                            if (jj > j) a[q][jj] = fma(-l, prow[jj], a[q][jj]);
+                    }
+                    if (tid >= j && tid < W) Ub[c0 + j][c0 + tid] = cdat[buf][gw][tid];
+                } else {                                         // no nonzero (or only NaN) entries left in this column: singular
+                    if (tid == 0) atomicOr(status, 2);
+#pragma unroll
+                    for (int q = 0; q < R; ++q)
+                        if (pos[q] == kd) {                      // the row at the pivot position stays there
+                            ploc[c0 + j] = k0 + tid + LU_NT * q;
+#pragma unroll
+                            for (int jj = 0; jj < W; ++jj)
+                                if (jj >= j) Ub[c0 + j][c0 + jj] = a[q][jj];
+                        }
+                }
+            }
+        });
+        LU_STAMP(3 + 8 * (c0 / W));
+        // ---- (d) the sub-panel goes back: to its physical rows, or -- a panel of one sub-panel -- straight to the final positions
+        //      (every row at or below k0 is in registers then, so writing each to its position IS the permutation) ---------------------
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            const int pos = k0 + tid + LU_NT * q;
-            if (pos >= k0 + c0 && pos < n) {
-                double* __restrict__ dst = A + (size_t)loc[q] * ld + k0 + c0;
+            if (pos[q] >= k0 + c0) {
+                double* __restrict__ dst = A + (size_t)(one_pass ? pos[q] : k0 + tid + LU_NT * q) * ld + k0 + c0;
                 if (full) lu_st_row<W>(dst, a[q]);
                 else {
 #pragma unroll
@@ -217,18 +297,34 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
                 }
             }
         }
-        __syncthreads();                // the stores are visible to the workgroup; ploc / Ub of this sub-panel are complete
-        // ---- (f) the new pivot rows right of the sub-panel become U rows now (the later sub-panels need them in (b)) -------------
+        __syncthreads();                // ploc / Ub of this sub-panel are complete; (d)'s stores are visible to the workgroup
+        LU_STAMP(4 + 8 * (c0 / W));
+        // ---- (f) the new pivot rows right of the sub-panel become U rows now (the later sub-panels need them in (b)): their L
+        //      entries and their raw entries come in one round trip (unconditional, clamped loads: a masked load is a branch) ----------
         const int cr0 = c0 + W, ncr = nb - cr0;
+        if constexpr (W < LU_NB) {
         if (ncr > 0) {
-            for (int e = tid; e < W * cr0; e += LU_NT) {
-                const int i = e / cr0, kk = e - i * cr0;
-                Lp[i][kk] = A[(size_t)ploc[c0 + i] * ld + k0 + kk];
+            constexpr int WL = W < 32 ? W : 32;
+            constexpr int NIT = (WL * NS + LU_NT - 1) / LU_NT;
+            double lv[NIT], tv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + LU_NT * it;
+                const int el = min(e, W * cr0 - 1), il = el / cr0, kk = el - il * cr0;
+                lv[it] = A[(size_t)ploc[c0 + il] * ld + k0 + kk];
+                const int et = min(e, W * ncr - 1), i2 = et / ncr, c = cr0 + (et - i2 * ncr);
+                tv[it] = A[(size_t)ploc[c0 + i2] * ld + k0 + c];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + LU_NT * it;
+                if (e < W * cr0) { const int il = e / cr0; Lp[il][e - il * cr0] = lv[it]; }
+                if (e < W * ncr) { const int i2 = e / ncr; Tt[i2][cr0 + (e - i2 * ncr)] = tv[it]; }
             }
             __syncthreads();
             for (int e = tid; e < W * ncr; e += LU_NT) {
                 const int i = e / ncr, c = cr0 + (e - i * ncr);
-                double t = A[(size_t)ploc[c0 + i] * ld + k0 + c];
+                double t = Tt[i][c];
                 for (int kk = 0; kk < c0; ++kk) t = fma(-Lp[i][kk], Ub[kk][c], t);
                 Tt[i][c] = t;
             }
@@ -249,26 +345,27 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
             }
             __syncthreads();
         }
+        }
     }
 
+    LU_STAMP(100);
     // ---- the panel's own columns are permuted into place; the list goes out for the slabs right of the panel ----------------------
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const int pos = k0 + tid + LU_NT * q;
-        if (pos < n && loc[q] != pos) {
+        if (pos[q] >= 0 && pos[q] != k0 + tid + LU_NT * q) {
             const int e = atomicAdd(&tcount, 1);
-            if (e < LU_MAXTOUCH) { tpos[e] = pos; tsrc[e] = loc[q]; }
+            if (e < LU_MAXTOUCH) { tpos[e] = pos[q]; tsrc[e] = k0 + tid + LU_NT * q; }
         }
     }
     __syncthreads();
     const int cnt = min(tcount, LU_MAXTOUCH);
-    {
-        constexpr int PER = LU_MAXTOUCH * LU_NB / LU_NT;        // 16
+    if (!one_pass) {
+        constexpr int PER = LU_MAXTOUCH * LU_NB / LU_NT;        // 32
         double tmp[PER];
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
             const int idx = tid + LU_NT * it, e = idx >> 6, c = idx & 63;
-            tmp[it] = (e < cnt && c < nb) ? A[(size_t)tsrc[e] * ld + k0 + c] : 0.0;
+            tmp[it] = A[(size_t)tsrc[e] * ld + k0 + min(c, nb - 1)];        // (entries past cnt point at row k0: loaded, never stored)
         }
         __syncthreads();
 #pragma unroll
@@ -279,74 +376,124 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
     }
     if (tid == 0) perm->count = cnt;
     if (tid < cnt) { perm->pos[tid] = tpos[tid]; perm->src[tid] = tsrc[tid]; }
+    LU_STAMP(101);
 }
 
 // One workgroup per 64-column slab right of the panel: rows into place, then U12 = L11^-1 A12.
-__global__ void __launch_bounds__(256) lu_swap_trsm(double* __restrict__ A, int ld, int n, int k0, int nb, const LuPerm* __restrict__ perm)
+// One round trip: the rows of A12 are read from where they ARE (position k0 + i still sits at row srcof[i]), together with the
+// rows that only move; after the barrier the moved rows are written and the triangular solve runs wave-local -- wave w owns
+// columns 16 w .. 16 w + 15 of the slab, lane (c16, rq) holds rows rq + 4 u, u < 16, of column c16 in registers, and row i
+// reaches the other lanes of its column through one __shfl per step (no barrier, no LDS traffic for B).
+__global__ void __launch_bounds__(256) lu_swap_trsm(double* __restrict__ A, int ld, int n, int k0, int nb, const LuPerm* __restrict__ perm, int cend)
 {
     __shared__ double Ls[LU_NB][LU_NB + 1];
-    __shared__ double Bs[LU_NB][LU_NB + 1];
+    __shared__ double Gs[LU_MAXTOUCH][LU_NB];
+    __shared__ int spos[LU_MAXTOUCH], ssrc[LU_MAXTOUCH], srcof[LU_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c16 = lane & 15, rq = lane >> 4;
+    const int cs = k0 + nb + LU_NB * (int)blockIdx.x, wc = min(LU_NB, cend - cs);       // columns [k0 + nb, cend) in slabs of 64
+    const int cnt = perm ? perm->count : 0;
+    if (tid < LU_NB) srcof[tid] = k0 + min(tid, nb - 1);
+    if (tid < LU_MAXTOUCH) { spos[tid] = tid < cnt ? perm->pos[tid] : 0; ssrc[tid] = tid < cnt ? perm->src[tid] : 0; }
+    __syncthreads();
+    if (tid < cnt && spos[tid] < k0 + nb) srcof[spos[tid] - k0] = ssrc[tid];
+    __syncthreads();
+    // rows that only move are staged through LDS, 32 rows (8 loads per thread, unconditional and clamped) per step
+    double bcol[16], lv[16];
+    const int mycol = cs + min(16 * wv + c16, wc - 1);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bcol[u] = A[(size_t)srcof[rq + 4 * u] * ld + mycol];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, r = e >> 6, c = e & 63;
+        lv[it] = A[(size_t)(k0 + min(r, nb - 1)) * ld + k0 + min(c, nb - 1)];
+    }
+    const int gc = tid & 63, gr0 = tid >> 6;
+    for (int e0 = 0; e0 < cnt; e0 += 32) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = A[(size_t)ssrc[e0 + gr0 + 4 * u] * ld + cs + min(gc, wc - 1)];      // (entries past cnt read row 0)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Gs[e0 + gr0 + 4 * u][gc] = t[u];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = tid + 256 * it, r = e >> 6, c = e & 63;
+        Ls[r][c] = (r < nb && c < r) ? lv[it] : 0.0;
+    }
+    __syncthreads();                                        // every read of the slab is done; Ls and Gs are complete
+    for (int e0 = 0; e0 < cnt; e0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + gr0 + 4 * u;
+            if (e < cnt && gc < wc && spos[e] >= k0 + nb) A[(size_t)spos[e] * ld + cs + gc] = Gs[e][gc];
+        }
+    }
+    lu_static_for<0, LU_NB - 1>([&](auto ic) {      // (a compile-time loop: bcol[] must keep constant indices to stay in registers)
+        constexpr int i = decltype(ic)::value, ui = i >> 2, rqi = i & 3;
+        const double bi = __shfl(bcol[ui], (rqi << 4) | c16);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u > ui) bcol[u] = fma(-Ls[rq + 4 * u][i], bi, bcol[u]);
+            else if (u == ui) bcol[u] = fma(rq > rqi ? -Ls[rq + 4 * u][i] : 0.0, bi, bcol[u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);              // (without it the scheduler hoists every step's LDS reads to the top: 512 registers and scratch)
+    });
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int r = rq + 4 * u;
+        if (r < nb && 16 * wv + c16 < wc) A[(size_t)(k0 + r) * ld + cs + 16 * wv + c16] = bcol[u];
+    }
+}
+
+// Rows into place on columns [cbeg, cend) (64-column slabs): row perm->pos[e] receives row perm->src[e].  Two-level panels
+// (lu.hip) apply the lists of their 16-column groups to the panel's earlier columns and, one list after the other, to everything
+// right of the panel.
+__global__ void __launch_bounds__(256) lu_apply_perm(double* __restrict__ A, int ld, const LuPerm* __restrict__ perm, int cbeg, int cend)
+{
+    __shared__ double Gs[LU_MAXTOUCH][LU_NB];
     __shared__ int spos[LU_MAXTOUCH], ssrc[LU_MAXTOUCH];
-    const int tid = threadIdx.x;
-    const int cs = k0 + nb + LU_NB * (int)blockIdx.x, wc = min(LU_NB, n + 1 - cs);
+    const int tid = threadIdx.x, cs = cbeg + LU_NB * (int)blockIdx.x, wc = min(LU_NB, cend - cs);
     const int cnt = perm->count;
     if (tid < LU_MAXTOUCH) { spos[tid] = tid < cnt ? perm->pos[tid] : 0; ssrc[tid] = tid < cnt ? perm->src[tid] : 0; }
     __syncthreads();
-    {
-        constexpr int PER = LU_MAXTOUCH * LU_NB / 256;          // 32
-        double tmp[PER];
+    const int gc = tid & 63, gr0 = tid >> 6;
+    for (int e0 = 0; e0 < cnt; e0 += 32) {
+        double t[8];
 #pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int idx = tid + 256 * it, e = idx >> 6, c = idx & 63;
-            tmp[it] = (e < cnt && c < wc) ? A[(size_t)ssrc[e] * ld + cs + c] : 0.0;
-        }
-        __syncthreads();
+        for (int u = 0; u < 8; ++u) t[u] = A[(size_t)ssrc[e0 + gr0 + 4 * u] * ld + cs + min(gc, wc - 1)];      // (entries past cnt read row 0)
 #pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int idx = tid + 256 * it, e = idx >> 6, c = idx & 63;
-            if (e < cnt && c < wc) A[(size_t)spos[e] * ld + cs + c] = tmp[it];
-        }
+        for (int u = 0; u < 8; ++u) Gs[e0 + gr0 + 4 * u][gc] = t[u];
     }
     __syncthreads();
-    {
-        double lv[16], bv[16];
+    for (int e0 = 0; e0 < cnt; e0 += 32) {
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int e = tid + 256 * it, r = e >> 6, c = e & 63;
-            lv[it] = A[(size_t)(k0 + min(r, nb - 1)) * ld + k0 + min(c, nb - 1)];
-            bv[it] = A[(size_t)(k0 + min(r, nb - 1)) * ld + cs + min(c, wc - 1)];
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + gr0 + 4 * u;
+            if (e < cnt && gc < wc) A[(size_t)spos[e] * ld + cs + gc] = Gs[e][gc];
         }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int e = tid + 256 * it, r = e >> 6, c = e & 63;
-            Ls[r][c] = (r < nb && c < r) ? lv[it] : 0.0;
-            Bs[r][c] = (r < nb && c < wc) ? bv[it] : 0.0;
-        }
-    }
-    const int c = tid & 63, rg = tid >> 6;
-    for (int i = 0; i + 1 < nb; ++i) {
-        __syncthreads();
-        const double bi = Bs[i][c];
-        for (int r = i + 1 + rg; r < nb; r += 4) Bs[r][c] = fma(-Ls[r][i], bi, Bs[r][c]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = tid + 256 * it, r = e >> 6, cc = e & 63;
-        if (r < nb && cc < wc) A[(size_t)(k0 + r) * ld + cs + cc] = Bs[r][cc];
     }
 }
 
 // A22 -= L21 U12: tile (blockIdx.y, blockIdx.x) of 64 x 64 below / right of the panel; K = nb <= 64.
 #define LU_GS 66
-__global__ void __launch_bounds__(256) lu_gemm(double* __restrict__ A, int ld, int n, int k0, int nb)
+__global__ void __launch_bounds__(256) lu_gemm(double* __restrict__ A, int ld, int n, int k0, int nb, int cend)
 {
     __shared__ double Ls[LU_NB][LU_GS];             // [row][k]
     __shared__ double Us[LU_NB][LU_NB + 16];        // [k][column]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int wr = wv >> 1, wc = wv & 1;
     const int r0 = k0 + nb + LU_NB * (int)blockIdx.y, c0 = k0 + nb + LU_NB * (int)blockIdx.x;
-    const int nr = min(LU_NB, n - r0), nc = min(LU_NB, n + 1 - c0);
+    const int nr = min(LU_NB, n - r0), nc = min(LU_NB, cend - c0);             // columns [k0 + nb, cend)
+    double oldv[2][2][4];                           // the tile of A22 itself: fetched with the operands (one round trip, not two)
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 32 * wr + 16 * it + lk + 4 * q, j = 32 * wc + 16 * jt + ln;
+                oldv[it][jt][q] = A[(size_t)(r0 + min(i, nr - 1)) * ld + c0 + min(j, nc - 1)];      // (clamped and unconditional: a masked load becomes a branch per element)
+            }
     {
         double2 lv[8], uv[8];
 #pragma unroll
@@ -384,25 +531,16 @@ __global__ void __launch_bounds__(256) lu_gemm(double* __restrict__ A, int ld, i
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) acc[it][jt] = mfma16(av[it], bv[jt], acc[it][jt]);
     }
-    // accumulator element q of lane (ln, lk): row 4 lk + q?  -- as chol_syrk: row = lk + 4 q, column = ln
+    // (accumulator element q of lane (ln, lk): row lk + 4 q, column ln -- as chol_syrk)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        double oldv[2][4];
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 32 * wr + 16 * it + lk + 4 * q, j = 32 * wc + 16 * jt + ln;
-                oldv[jt][q] = (i < nr && j < nc) ? A[(size_t)(r0 + i) * ld + c0 + j] : 0.0;
-            }
+    for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = 32 * wr + 16 * it + lk + 4 * q, j = 32 * wc + 16 * jt + ln;
-                if (i < nr && j < nc) A[(size_t)(r0 + i) * ld + c0 + j] = oldv[jt][q] - acc[it][jt][q];
+                if (i < nr && j < nc) A[(size_t)(r0 + i) * ld + c0 + j] = oldv[it][jt][q] - acc[it][jt][q];
             }
-    }
 }
 
 // After the last panel: U^T over the lower triangle (tile (bi, bj), bj >= bi, read from the upper triangle and written

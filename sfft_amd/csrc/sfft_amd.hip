@@ -121,7 +121,7 @@ struct KLogScope {      // route the names of the launches in this scope to `log
 #include "greek.hpp"
 #include "fill.hpp"
 #include "solver.hpp"
-#include "lu.hpp"
+#include "lu_api.hpp"
 #include "construct.hpp"
 
 // ================================================================================================
@@ -1296,7 +1296,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_tflags, (size_t)nblk_b * (nblk_b + 1) + 1));
         PLAN_HIP(hipMemset(p->d_tflags, 0, ((size_t)nblk_b * (nblk_b + 1) + 1) * sizeof(unsigned int)));
         PLAN_TRY(dev_alloc(p, &p->d_w16, (size_t)nblk_b * 1024));
-        PLAN_TRY(dev_alloc(p, &p->d_luperm, (size_t)nblk_b));
+        PLAN_TRY(dev_alloc(p, &p->d_luperm, (size_t)LU_PERMS_PER_PANEL * nblk_b));
         if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
         if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
         if (const char* ev = getenv("SFFT_PANEL4")) p->panel4 = atoi(ev);
@@ -2130,12 +2130,7 @@ static int run_cholesky(sfft_plan* p, double* d_solution, hipStream_t s)
 }
 
 // ---- pivoted LU (lu.hpp): the reference's solver (SFFTSubtract.py:15-23) ---------------------------------------------------------
-template <int W, int R>
-static void launch_lu_panel(sfft_plan* p, int n, int k0, int nb, LuPerm* perm, hipStream_t s)
-{
-    SFFT_LAUNCH((lu_panel<W, R>), dim3(1), dim3(LU_NT), 0, s, p->d_A, p->ld, n, k0, nb, perm, p->d_status);
-}
-
+static void lu_note(const char* name) { if (tl_klog) note_kernel(name); }
 static int run_lu_launches(sfft_plan* p, double* d_solution, hipStream_t s)
 {
     const int n = p->NEQfs;
@@ -2143,25 +2138,7 @@ static int run_lu_launches(sfft_plan* p, double* d_solution, hipStream_t s)
     const int npan = (n + LU_NB - 1) / LU_NB;
     unsigned int* d_queue = p->d_tflags + (size_t)npan * (npan + 1);
     SFFT_LAUNCH(chol_begin, dim3(1), dim3(PANEL4_MAX_OUTER), 0, s, p->d_epoch, d_queue, p->d_pq);       // a new stamp for chol_back_all's flags
-    for (int pn = 0; pn < npan; ++pn) {
-        const int k0 = pn * LU_NB, nb = std::min(LU_NB, n - k0), m = n - k0;
-        LuPerm* perm = p->d_luperm + pn;
-        // rows per thread x sub-panel width: R x W = 64 doubles of the panel in registers per thread (512 threads)
-        if (m <= 1 * LU_NT) launch_lu_panel<16, 1>(p, n, k0, nb, perm, s);
-        else if (m <= 2 * LU_NT) launch_lu_panel<16, 2>(p, n, k0, nb, perm, s);
-        else if (m <= 3 * LU_NT) launch_lu_panel<16, 3>(p, n, k0, nb, perm, s);
-        else if (m <= 4 * LU_NT) launch_lu_panel<16, 4>(p, n, k0, nb, perm, s);
-        else if (m <= 8 * LU_NT) launch_lu_panel<8, 8>(p, n, k0, nb, perm, s);
-        else if (m <= 16 * LU_NT) launch_lu_panel<4, 16>(p, n, k0, nb, perm, s);
-        else if (m <= 32 * LU_NT) launch_lu_panel<2, 32>(p, n, k0, nb, perm, s);
-        else launch_lu_panel<1, 64>(p, n, k0, nb, perm, s);
-        const int right = n + 1 - (k0 + nb);                  // columns right of the panel, the right-hand side included (>= 1)
-        SFFT_LAUNCH(lu_swap_trsm, dim3((right + LU_NB - 1) / LU_NB), dim3(256), 0, s, p->d_A, p->ld, n, k0, nb, (const LuPerm*)perm);
-        const int below = n - (k0 + nb);
-        if (below > 0)
-            SFFT_LAUNCH(lu_gemm, dim3((right + LU_NB - 1) / LU_NB, (below + LU_NB - 1) / LU_NB), dim3(256), 0, s, p->d_A, p->ld, n, k0, nb);
-    }
-    SFFT_LAUNCH(lu_transpose_upper, dim3((n + 1 + LU_NB - 1) / LU_NB, npan), dim3(256), 0, s, p->d_A, p->ld, n, p->d_rd, p->d_status);
+    lu_factor_launches(p->d_A, p->ld, n, p->d_luperm, p->d_status, p->d_rd, s, lu_note);
     LAUNCH_CHECK();
     return run_back_substitution(p, d_solution, s, false);
 }
