@@ -208,4 +208,58 @@ __global__ void __launch_bounds__(256) finish_diff(const cplx* __restrict__ Zf, 
     if (l1 < N0) DIFF[(size_t)l1 * N1 + n] = J[(size_t)l1 * N1 + n] - bkg_eval<SFFT_MAX_BQ>(bk, c1, n, N1) + z.y;
 }
 
+// ================================================================================================
+// Axes with no on-chip factorisation at all (a prime factor above the on-chip Bluestein limit: 4621, 10006 = 2 x 5003, 10007 ...):
+// Bluestein's algorithm THROUGH the four-step transform -- x_n c_n zero-padded to M = 2^k >= 2 N - 1 points, an M-point four-step
+// transform, the product with the transformed chirp filter, the inverse M-point transform, the product with c_k (c_k = exp(-i pi k^2 / N)).
+// The three element-wise kernels move 16 x 16 tiles of (line, element) through LDS so that both the strided image side (column
+// transforms: the LINE index is contiguous) and the compact work array (the element index is contiguous) see whole 256-byte pieces.
+// mode 0: in -> W (chirp, optional row weight, optional conjugation, zero padding); mode 1: W -> out (chirp, optional conjugation).
+// ================================================================================================
+struct BlueDesc { int N, M, nlines, line0, conj, transposed; long long st, lst; const double* w; };
+
+__global__ void __launch_bounds__(256) bigblue_move(const cplx* __restrict__ src, cplx* __restrict__ dst, BlueDesc d, const cplx* __restrict__ chirp, int mode)
+{
+    __shared__ cplx tile[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int k0 = blockIdx.x * 16, l0 = blockIdx.y * 16;
+    const int kend = mode == 0 ? d.M : d.N;
+    // image side coordinates of this thread: transposed (lines contiguous) -> tx runs over lines; else tx runs over elements
+    const int li = d.transposed ? l0 + tx : l0 + ty, ki = d.transposed ? k0 + ty : k0 + tx;
+    // work-array side: tx runs over elements
+    const int lw = l0 + ty, kw = k0 + tx;
+    if (mode == 0) {
+        cplx z = make_double2(0.0, 0.0);
+        if (li < d.nlines && ki < d.N) {
+            z = src[(size_t)(d.line0 + li) * d.lst + (size_t)ki * d.st];
+            if (d.conj) z.y = -z.y;
+            if (d.w) { const double f = d.w[ki]; z.x *= f; z.y *= f; }
+            const cplx c = chirp[ki];
+            z = make_double2(z.x * c.x - z.y * c.y, z.x * c.y + z.y * c.x);
+        }
+        if (d.transposed) { tile[ty][tx] = z; __syncthreads(); z = tile[tx][ty]; }
+        if (lw < d.nlines && kw < kend) dst[(size_t)lw * d.M + kw] = z;
+    } else {
+        cplx z = make_double2(0.0, 0.0);
+        if (lw < d.nlines && kw < kend) {
+            z = src[(size_t)lw * d.M + kw];
+            const cplx c = chirp[kw];
+            z = make_double2(z.x * c.x - z.y * c.y, z.x * c.y + z.y * c.x);
+            if (d.conj) z.y = -z.y;
+        }
+        if (d.transposed) { tile[ty][tx] = z; __syncthreads(); z = tile[tx][ty]; }
+        if (li < d.nlines && ki < kend) dst[(size_t)(d.line0 + li) * d.lst + (size_t)ki * d.st] = z;
+    }
+}
+
+// W[l][k] *= bf[k]  (bf: the M-point transform of the chirp filter, divided by M)
+__global__ void __launch_bounds__(256) bigblue_filter(cplx* __restrict__ W, const cplx* __restrict__ bf, int M)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= M) return;
+    cplx* q = W + (size_t)blockIdx.y * M + k;
+    const cplx z = *q, b = bf[k];
+    *q = make_double2(z.x * b.x - z.y * b.y, z.x * b.y + z.y * b.x);
+}
+
 #endif

@@ -139,6 +139,10 @@ struct AxisHost {
     int A = 0, B = 0;
     AxisHost* subA = nullptr;
     AxisHost* subB = nullptr;
+    // ... and for lengths with no on-chip factorisation either (a prime factor > 4608): Bluestein through a four-step transform of
+    // BM = 2^k >= 2 N - 1 points (subA = the BM-point axis; chirp [N], bf [BM]); big is set too, big_axis_transform dispatches
+    bool bigblue = false;
+    int BM = 0;
 };
 
 struct sfft_plan {
@@ -191,6 +195,7 @@ struct sfft_plan {
     // workspaces
     cplx* d_spec = nullptr;             // [Fij+1][N0][Nhp]   (plane Fij: J in solve, FD in apply)
     cplx *d_big1 = nullptr, *d_big2 = nullptr, *d_colscr = nullptr;   // work arrays of the four-step path
+    cplx *d_bb1 = nullptr, *d_bb2 = nullptr; int bb_lines = 0;        // work arrays [bb_lines][BM] of the Bluestein-through-four-step axes
     double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
     // mixed-domain apply (polynomial kernels on the staged fast path, KerHW <= 8): no column transforms in the apply pass
@@ -417,6 +422,41 @@ static bool fits_on_chip(int N)
 static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis = false, bool rader = false);
 static bool rader_ok(int N) { return N == RADER_M + 1 && !getenv("SFFT_NO_RADER") && !getenv("SFFT_NO_R16"); }
 
+#define BIGBLUE_MAX_N 16384
+#define BIGBLUE_WORK_ELEMS ((size_t)1 << 24)         // complex elements per work array (256 MB): lines are taken in batches of this many / BM
+static int build_big_axis(sfft_plan* p, AxisHost& ax, int N, bool rader);
+// exp(-i pi k^2 / N) and the BM-point transform of its conjugate's wrap-around extension (the Bluestein filter), BM = 2^k >= 2 N - 1 > 8192
+static int build_bigblue_axis(sfft_plan* p, AxisHost& ax, int N)
+{
+    const long double PI = acosl(-1.0L);
+    if (N > BIGBLUE_MAX_N) return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "image side not supported by this build: sides above 16384 must factor as A * B "
+                                          "with both factors on chip (power of two <= 8192, 2^a 3^b <= 9216, any length <= 4608)");
+    int M = 1; while (M < 2 * N - 1) M <<= 1;
+    ax.N = N; ax.big = true; ax.bigblue = true; ax.BM = M; ax.A = 0; ax.B = 0; ax.M = 0; ax.logM = 0; ax.blue = 0;
+    ax.subA = new AxisHost();
+    int rc;
+    if ((rc = build_big_axis(p, *ax.subA, M, false))) return rc;          // M = 16384 / 32768: 4096 x 4 / 4096 x 8
+    std::vector<cplx> c(N);
+    std::vector<long double> fr(M, 0.0L), fi(M, 0.0L);
+    for (int k = 0; k < N; ++k) {
+        const long long q = ((long long)k * k) % (2LL * N);
+        const long double a2 = PI * q / N;
+        c[k] = make_double2((double)cosl(a2), (double)-sinl(a2));
+        fr[k] = cosl(a2); fi[k] = sinl(a2);
+        if (k > 0) { fr[M - k] = fr[k]; fi[M - k] = fi[k]; }
+    }
+    host_fft_pow2(fr, fi);
+    std::vector<cplx> bf(M);
+    for (int k = 0; k < M; ++k) bf[k] = make_double2((double)(fr[k] / M), (double)(fi[k] / M));
+    if ((rc = dev_alloc(p, &ax.chirp, N)) || (rc = dev_alloc(p, &ax.bf, M))) return rc;
+    HIPCHK(hipMemcpy(ax.chirp, c.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ax.bf, bf.data(), M * sizeof(cplx), hipMemcpyHostToDevice));
+    if (!p->d_bb1) {
+        if ((rc = dev_alloc(p, &p->d_bb1, BIGBLUE_WORK_ELEMS)) || (rc = dev_alloc(p, &p->d_bb2, BIGBLUE_WORK_ELEMS))) return rc;
+    }
+    return SFFT_OK;
+}
+
 // N = A * B with A the largest power-of-two factor (<= 4096) such that B fits on chip too
 static int build_big_axis(sfft_plan* p, AxisHost& ax, int N, bool rader)
 {
@@ -439,9 +479,7 @@ static int build_big_axis(sfft_plan* p, AxisHost& ax, int N, bool rader)
         const double c = cost(a, false) + cost(b, rader) + 1e-6 * (padded(a) + padded(b));      // (ties: the smaller on-chip transforms)
         if (c < best) { best = c; A = a; B = b; }
     }
-    if (!A) return set_err(SFFT_ERR_UNSUPPORTED_SIZE,
-                           "image side not supported by this build: it must fit one on-chip transform (power of two <= 8192, "
-                           "2^a 3^b <= 9216, any length <= 4096) or factor as A * B with both factors on chip");
+    if (!A) return build_bigblue_axis(p, ax, N);        // no factorisation with both factors on chip: Bluestein through a four-step transform
     ax.N = N; ax.big = true; ax.A = A; ax.B = B; ax.M = 0; ax.logM = 0; ax.blue = 0;
     ax.subA = new AxisHost(); ax.subB = new AxisHost();
     int rc;
@@ -1460,7 +1498,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     DeviceGuard device_guard_(p->dev);
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
-                    p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
+                    p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_bb1, p->d_bb2, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
                     p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_luperm, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_ibase, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->lu_exec) hipGraphExecDestroy(p->lu_exec);
@@ -1601,6 +1639,21 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
 static void big_axis_transform(sfft_plan* p, const AxisHost& ax, cplx* data, cplx* scr, long long st, long long lst, int nlines,
                                bool lines_fastest, int inverse, hipStream_t s, const cplx* src = nullptr, const double* wrow = nullptr)
 {
+    if (ax.bigblue) {       // Bluestein through the BM-point four-step transform, a batch of lines at a time through the compact work arrays
+        const int M = ax.BM, per = (int)std::min<size_t>(BIGBLUE_WORK_ELEMS / (size_t)M, 16384);
+        for (int l0 = 0; l0 < nlines; l0 += per) {
+            const int nl = std::min(per, nlines - l0);
+            BlueDesc bd; bd.N = ax.N; bd.M = M; bd.nlines = nl; bd.line0 = l0; bd.conj = inverse; bd.transposed = (lst < st) ? 1 : 0;
+            bd.st = st; bd.lst = lst; bd.w = wrow;
+            SFFT_LAUNCH(bigblue_move, dim3((M + 15) / 16, (nl + 15) / 16), dim3(256), 0, s, src ? src : (const cplx*)data, p->d_bb1, bd, (const cplx*)ax.chirp, 0);
+            big_axis_transform(p, *ax.subA, p->d_bb1, p->d_bb2, 1, M, nl, false, 0, s);
+            SFFT_LAUNCH(bigblue_filter, dim3((M + 255) / 256, nl), dim3(256), 0, s, p->d_bb1, (const cplx*)ax.bf, M);
+            big_axis_transform(p, *ax.subA, p->d_bb1, p->d_bb2, 1, M, nl, false, 1, s);
+            bd.w = nullptr;
+            SFFT_LAUNCH(bigblue_move, dim3((ax.N + 15) / 16, (nl + 15) / 16), dim3(256), 0, s, (const cplx*)p->d_bb1, data, bd, (const cplx*)ax.chirp, 1);
+        }
+        return;
+    }
     PassDesc d1; memset(&d1, 0, sizeof(d1));
     d1.w = wrow; d1.w_js = 1; d1.w_es = ax.B;
     d1.len = ax.A; d1.J = ax.B; d1.nlines = nlines; d1.mode = lines_fastest ? 2 : 1;
