@@ -30,9 +30,9 @@ typedef struct sfft_plan sfft_plan;
 enum {
     SFFT_OK = 0,
     SFFT_ERR_INVALID_ARG = -1,      /* bad DK/DB/size: Python shim raises the reference's 'MeLOn ERROR' texts */
-    SFFT_ERR_UNSUPPORTED_SIZE = -2, /* image side not supported by the on-chip FFT of this build */
+    SFFT_ERR_UNSUPPORTED_SIZE = -2, /* an image side above 16384 with no factorisation into on-chip transforms, or more than 24 576 unknowns */
     SFFT_ERR_HIP = -3,              /* a HIP runtime call failed (message has the HIP error string) */
-    SFFT_ERR_SINGULAR = -4,         /* linear system could not be solved (LU hit an exactly zero pivot) */
+    SFFT_ERR_SINGULAR = -4,         /* linear system could not be solved (the pivoted LU found no nonzero pivot in a column) */
     SFFT_ERR_NOMEM = -5
 };
 

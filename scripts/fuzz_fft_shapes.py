@@ -14,6 +14,17 @@ special = [8, 9, 12, 15, 16, 17, 24, 27, 31, 32, 33, 48, 63, 64, 65, 81, 96, 97,
            729, 768, 1000, 1023, 1024, 1025, 1152, 1536, 2047, 2048, 2049, 2187, 3072, 4095, 4097, 4608, 5000, 6144, 8192, 8193, 9216]
 worst = 0.0
 unsupported = 0
+if os.environ.get("FUZZ_PLAN_ONLY"):       # FUZZ_PLAN_ONLY=500: that many random sides in [8, MAXSIDE], as rows and as columns: every one must plan
+    sides = sorted(set(int(x) for x in rng.integers(8, MAXSIDE + 1, size=int(os.environ["FUZZ_PLAN_ONLY"]))))
+    bad = []
+    for N in sides:
+        for shape in ((N, 16), (16, N)):
+            try:
+                Plan(shape[0], shape[1], 1, 0, 0, True, device=0).close()
+            except Exception as e:
+                bad.append((shape, str(e)[:50]))
+    print("%d distinct sides in [8, %d] planned as rows and as columns; refused: %d %s" % (len(sides), MAXSIDE, len(bad), bad[:5]))
+    sys.exit(1 if bad else 0)
 for it in range(count):
     N0 = int(rng.choice(special)) if rng.random() < 0.6 else int(rng.integers(8, MAXSIDE))
     N1 = int(rng.choice(special)) if rng.random() < 0.6 else int(rng.integers(8, MAXSIDE))

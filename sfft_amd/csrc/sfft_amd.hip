@@ -448,7 +448,13 @@ static int build_bigblue_axis(sfft_plan* p, AxisHost& ax, int N)
     host_fft_pow2(fr, fi);
     std::vector<cplx> bf(M);
     for (int k = 0; k < M; ++k) bf[k] = make_double2((double)(fr[k] / M), (double)(fi[k] / M));
-    if ((rc = dev_alloc(p, &ax.chirp, N)) || (rc = dev_alloc(p, &ax.bf, M))) return rc;
+    std::vector<cplx> r(N);                             // the N-th roots of unity every big axis carries (untangle_rows, the mixed-domain apply ...)
+    for (int k = 0; k < N; ++k) {
+        const long double ang = -2.0L * PI * k / N;
+        r[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    if ((rc = dev_alloc(p, &ax.chirp, N)) || (rc = dev_alloc(p, &ax.bf, M)) || (rc = dev_alloc(p, &ax.root, N))) return rc;
+    HIPCHK(hipMemcpy(ax.root, r.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ax.chirp, c.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ax.bf, bf.data(), M * sizeof(cplx), hipMemcpyHostToDevice));
     if (!p->d_bb1) {
