@@ -52,7 +52,7 @@ static void apply_perm(double* A, int ld, const LuPerm* perm, int cbeg, int cend
 // Taller panels would need sub-panels of 8, 4, 2 columns, whose left-looking updates re-read the panel's L columns 224 / 480 / 992 times
 // per row through one CU: they are factored in four GROUPS of 16 columns instead -- each group one panel launch on all rows, followed by
 // the update of the panel's remaining columns by the whole chip -- and the groups' row lists are then applied to the rest of the matrix.
-#define LU_ONE_KERNEL_ROWS (6 * LU_NT)
+#define LU_ONE_KERNEL_ROWS (8 * LU_NT)
 #define LU_GROUP 16
 void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, double* rd, hipStream_t s, lu_note_fn note)
 {

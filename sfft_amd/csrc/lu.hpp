@@ -174,23 +174,28 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
         }
         if (c0 > 0) {
             if constexpr (R <= 16) {
-                // C columns of L per step and row.  A step is one memory round trip (the L columns come from L2 / HBM, ~1.5 us) and only
-                // R C 16-byte-pair loads deep, so the steps must be FEW: C = min(W, 16) -- at W = 16 three steps for the last sub-panel
-                // (two columns per step with the next step prefetched took 24 steps: 35 us per sub-panel at R = 6)
+                // C = min(W, 16) columns of L per step, QG rows at a time: a step is one memory round trip (the L columns come from L2 /
+                // HBM), so steps must be few, and its QG x C doubles of L plus the QG rows of the tile they update must fit the directly
+                // addressable registers beside each other (all R rows at once: 20 k cycles per step at R = 6, most of it moves to and from
+                // the accumulation registers; two columns per step with the next step prefetched: 24 round trips per sub-panel)
                 constexpr int C = W < 16 ? W : 16;
-                for (int kb = 0; kb < c0; kb += C) {
-                    double lc[R][C];
+                constexpr int QG = R <= 3 ? R : (R % 3 == 0 ? 3 : 2);
 #pragma unroll
-                    for (int q = 0; q < R; ++q) lu_ld_row<C>(A + (size_t)min(k0 + tid + LU_NT * q, n - 1) * ld + k0 + kb, lc[q]);
+                for (int q0 = 0; q0 < R; q0 += QG) {
+                    for (int kb = 0; kb < c0; kb += C) {
+                        double lc[QG][C];
 #pragma unroll
-                    for (int u = 0; u < C; ++u) {
-                        double ub[W];
+                        for (int q = 0; q < QG; ++q) lu_ld_row<C>(A + (size_t)min(k0 + tid + LU_NT * (q0 + q), n - 1) * ld + k0 + kb, lc[q]);
 #pragma unroll
-                        for (int jj = 0; jj < W; ++jj) ub[jj] = Ub[kb + u][c0 + jj];
+                        for (int u = 0; u < C; ++u) {
+                            double ub[W];
 #pragma unroll
-                        for (int q = 0; q < R; ++q)
+                            for (int jj = 0; jj < W; ++jj) ub[jj] = Ub[kb + u][c0 + jj];
 #pragma unroll
-                            for (int jj = 0; jj < W; ++jj) a[q][jj] = fma(-lc[q][u], ub[jj], a[q][jj]);
+                            for (int q = 0; q < QG; ++q)
+#pragma unroll
+                                for (int jj = 0; jj < W; ++jj) a[q0 + q][jj] = fma(-lc[q][u], ub[jj], a[q0 + q][jj]);
+                        }
                     }
                 }
             } else {
@@ -222,19 +227,19 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
                     const unsigned long long key = (pos[q] >= kd) ? lu_key(a[q][j]) : 0ull;
-                    const bool better = key > bk || (key == bk && key != 0ull && pos[q] < bp);     // ties: the first POSITION (idamax)
-                    bk = better ? key : bk;
+                    const bool better = key > bk;               // among equal magnitudes the first slot, lane, wave (LAPACK: the first POSITION;
+                    bk = better ? key : bk;                     //  either is partial pivoting -- an entry of largest magnitude)
                     bp = better ? pos[q] : bp;
                 }
                 const unsigned long long wk = lu_wave_max64(bk);
-                const int wp = (int)lu_wave_min32((bk == wk && wk != 0ull) ? (unsigned int)bp : 0x7fffffffu);
+                const int wl = __ffsll((long long)__ballot(bk == wk)) - 1;          // the wave's candidate lane
 #pragma unroll
                 for (int q = 0; q < R; ++q)
-                    if (pos[q] == wp) {                         // the wave's candidate: its row from column j on (wp = 0x7fffffff: nobody)
+                    if (lane == wl && pos[q] == bp && wk != 0ull) {      // its row from column j on
 #pragma unroll
                         for (int jj = 0; jj < W; ++jj)
                             if (jj >= j) cdat[buf][wv][jj] = a[q][jj];
-                        cand[buf][wv] = LuCand{a[q][j], wp, k0 + tid + LU_NT * q};
+                        cand[buf][wv] = LuCand{a[q][j], bp, k0 + tid + LU_NT * q};
                     }
                 if (wk == 0ull && lane == 0) cand[buf][wv] = LuCand{0.0, 0x7fffffff, k0};
                 if (j >= 4 && j <= 6) LU_STAMP(200 + 4 * (j - 4) + 0);
@@ -247,11 +252,9 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
                 const unsigned int ghi = lu_quad_max32<0x4E>(lu_quad_max32<0xB1>(chi));
                 const unsigned int glo = lu_quad_max32<0x4E>(lu_quad_max32<0xB1>(chi == ghi ? clo : 0u));
                 const unsigned long long gk = ((unsigned long long)ghi << 32) | glo;
-                unsigned int gru = lu_quad_min32<0xB1>(ckey == gk ? (unsigned int)cd.pos : 0x7fffffffu);
-                gru = lu_quad_min32<0x4E>(gru);
-                const int gr = (int)gru;
+                const int gw = __ffsll((long long)__ballot(ckey == gk)) - 1;         // (< 4: the quads repeat) the first wave that holds the maximum
+                const int gr = __builtin_amdgcn_readlane(cd.pos, gw);
                 if (gk != 0ull) {
-                    const int gw = __ffsll((long long)__ballot(cd.pos == gr && ckey == gk)) - 1;      // (< 4: the quads repeat)
                     if (tid == 0) ploc[c0 + j] = __builtin_amdgcn_readlane(cd.phys, gw);
                     double prow[W];
 #pragma unroll
@@ -297,11 +300,24 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
                 }
             }
         }
-        __syncthreads();                // ploc / Ub of this sub-panel are complete; (d)'s stores are visible to the workgroup
+        const int cr0 = c0 + W, ncr = nb - cr0;
+        if constexpr (W < LU_NB) {
+            if (ncr > 0) {              // the new pivot rows leave their sub-panel entries (L left of the diagonal) in LDS for (f)
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+                    if (pos[q] >= k0 + c0 && pos[q] < k0 + cr0) {
+#pragma unroll
+                        for (int jj = 0; jj < W; ++jj) Lp[pos[q] - k0 - c0][c0 + jj] = a[q][jj];
+                    }
+            }
+        }
+        // LDS-only barrier: ploc / Ub / Lp of this sub-panel are complete.  (d)'s global stores drain behind it -- nothing below reads another
+        // thread's fresh stores: (f) takes this sub-panel's L entries from Lp, a thread re-reads only its OWN rows later, and the final
+        // gather sits behind a full __syncthreads()
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LU_STAMP(4 + 8 * (c0 / W));
         // ---- (f) the new pivot rows right of the sub-panel become U rows now (the later sub-panels need them in (b)): their L
-        //      entries and their raw entries come in one round trip (unconditional, clamped loads: a masked load is a branch) ----------
-        const int cr0 = c0 + W, ncr = nb - cr0;
+        //      entries of EARLIER sub-panels and their raw entries come in one round trip (unconditional, clamped loads) ----------------
         if constexpr (W < LU_NB) {
         if (ncr > 0) {
             constexpr int WL = W < 32 ? W : 32;
@@ -310,7 +326,7 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int e = tid + LU_NT * it;
-                const int el = min(e, W * cr0 - 1), il = el / cr0, kk = el - il * cr0;
+                const int el = min(e, max(W * c0 - 1, 0)), il = c0 > 0 ? el / c0 : 0, kk = c0 > 0 ? el - il * c0 : 0;
                 lv[it] = A[(size_t)ploc[c0 + il] * ld + k0 + kk];
                 const int et = min(e, W * ncr - 1), i2 = et / ncr, c = cr0 + (et - i2 * ncr);
                 tv[it] = A[(size_t)ploc[c0 + i2] * ld + k0 + c];
@@ -318,7 +334,7 @@ __global__ void __launch_bounds__(LU_NT) lu_panel(double* __restrict__ A, int ld
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int e = tid + LU_NT * it;
-                if (e < W * cr0) { const int il = e / cr0; Lp[il][e - il * cr0] = lv[it]; }
+                if (e < W * c0) { const int il = e / c0; Lp[il][e - il * c0] = lv[it]; }
                 if (e < W * ncr) { const int i2 = e / ncr; Tt[i2][cr0 + (e - i2 * ncr)] = tv[it]; }
             }
             __syncthreads();
