@@ -99,6 +99,46 @@ __global__ void __launch_bounds__(256) strided_dft16_cols(const cplx* __restrict
     }
 }
 
+// ... and for every output plane that shares the stage plane (the staged forward column pass: outputs = stage plane x row factor
+// kbx[i], round 5): the 16 strided points are read ONCE, each output applies its own row factor, transforms and writes to its own
+// scratch plane.  Config 5 (orders 3 / 3): 5 stage planes feed 11 outputs -- 5 plane reads instead of 11 in this pass.
+#define DFT16_MAX_OUT 4
+struct Dft16Outs { int nout; const double* w[DFT16_MAX_OUT]; cplx* out[DFT16_MAX_OUT]; };
+__global__ void __launch_bounds__(256) strided_dft16_cols_multi(const cplx* __restrict__ in, Dft16Outs o, PassDesc d, const cplx* __restrict__ rootN)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);          // wave-uniform
+    const int line = (int)blockIdx.x * 64 + lane;
+    if (j >= d.J) return;
+    const bool ok = line < d.nlines;
+    const long long li = (long long)(ok ? line : d.nlines - 1) * d.lst_in + (long long)j * d.js_in;
+    cplx u[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) u[e] = in[li + (long long)e * d.es_in];
+    const long long lo = (long long)line * d.lst_out + (long long)j * d.js_out;
+#pragma unroll
+    for (int q = 0; q < DFT16_MAX_OUT; ++q) {
+        if (q >= o.nout) break;                                            // (uniform)
+        cplx v[16];
+        const double* __restrict__ w = o.w[q];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double f = w ? w[j * d.w_js + e * d.w_es] : 1.0;
+            v[e] = make_double2(u[e].x * f, u[e].y * f);
+        }
+        dft16(v);
+        if (ok) {
+            cplx* __restrict__ out = o.out[q];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                cplx z = v[R16_OUT(k)];
+                z = cmul(z, rootN[(int)(((long long)j * k) % d.N)]);
+                out[lo + (long long)k * d.es_out] = z;
+            }
+        }
+    }
+}
+
 // The same pass for a Rader sub-axis (N = 577, config 5's 9232 = 16 x 577 column axis), lines fastest (mode 2): a kernel of its own so that
 // the compiler sees one transform, not every path of lds_dft (strided_dft is 52 k instructions and sits at its register cap).
 // RADER_TC lines (columns) x 577 elements per workgroup: each row of the tile is RADER_TC x 16 contiguous bytes.

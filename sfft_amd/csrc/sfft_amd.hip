@@ -270,6 +270,7 @@ struct sfft_plan {
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     // A/B switches of the launch paths, read ONCE at plan creation (never getenv on a hot path)
+    int colscr_planes = 1, no_dft16_multi = 0;      // scratch planes of the four-step column path; SFFT_NO_DFT16_MULTI=1: one first pass per output (A/B)
     int no_dft16_regs = 0, no_rader_r24 = 0, no_gamma_aside = 0, vconv2_w12 = 1, inv_r24 = -1;
     // Omega products of basis terms with (nearly) disjoint supports: computed in real space by omega_sparse, no transform pass
     std::vector<SparseProd> sprods; SparseProd* d_sprods = nullptr; SparseLine* d_slines = nullptr; int* d_scols = nullptr;
@@ -687,6 +688,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_G1_MFMA")) { p->g1_mfma = atoi(ev); if (p->g1_mfma == 1) p->g1_mfma = 2; }
     if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     if (getenv("SFFT_NO_DFT16_REGS")) p->no_dft16_regs = 1;
+    if (getenv("SFFT_NO_DFT16_MULTI")) p->no_dft16_multi = 1;
     if (getenv("SFFT_NO_RADER_R24")) p->no_rader_r24 = 1;
     if (getenv("SFFT_NO_GAMMA_ASIDE")) p->no_gamma_aside = 1;
     if (const char* ev = getenv("SFFT_VCONV2_W12")) p->vconv2_w12 = atoi(ev);
@@ -849,7 +851,12 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_TRY(dev_alloc(p, &p->d_big1, (size_t)((N0 + 1) / 2) * N1));
         PLAN_TRY(dev_alloc(p, &p->d_big2, (size_t)((N0 + 1) / 2) * N1));
     }
-    if (p->ax0.big) PLAN_TRY(dev_alloc(p, &p->d_colscr, (size_t)N0 * p->Nhp));
+    if (p->ax0.big) {
+        // 16 x B column axes: the outputs of a stage plane share the first pass, each through a scratch plane of its own (up to DFT16_MAX_OUT)
+        const bool multi = !p->ax0.bigblue && p->ax0.A == 16 && p->ax0.subA && p->ax0.subA->M == 16 && !p->ax0.subA->blue && !p->no_dft16_regs && !p->no_dft16_multi;
+        p->colscr_planes = multi ? std::min(DFT16_MAX_OUT, std::max(1, p->nkx)) : 1;
+        PLAN_TRY(dev_alloc(p, &p->d_colscr, (size_t)p->colscr_planes * N0 * p->Nhp));
+    }
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1642,6 +1649,23 @@ static void launch_pass(sfft_plan* p, const cplx* in, cplx* out, PassDesc d, con
 // Result lands in `data` again (scr is a same-shaped scratch).  inverse: e^{+i} (conjugation on the way in and out).
 // src / wrow (optional): read the input from another plane of the same shape and multiply input element (row) by wrow[row] -- the
 // weighted forward column pass of the staged transforms (columns only: the element index is the row).
+static void four_step_passes(const AxisHost& ax, long long st, long long lst, int nlines, bool lines_fastest, int inverse, const double* wrow,
+                             PassDesc* p1, PassDesc* p2)
+{
+    PassDesc d1; memset(&d1, 0, sizeof(d1));
+    d1.w = wrow; d1.w_js = 1; d1.w_es = ax.B;
+    d1.len = ax.A; d1.J = ax.B; d1.nlines = nlines; d1.mode = lines_fastest ? 2 : 1;
+    d1.js_in = st; d1.es_in = (long long)ax.B * st; d1.lst_in = lst;
+    d1.js_out = d1.js_in; d1.es_out = d1.es_in; d1.lst_out = lst;
+    d1.twiddle = 1; d1.N = ax.N; d1.conj_in = inverse; d1.conj_out = 0; d1.scale = 1.0;
+    PassDesc d2; memset(&d2, 0, sizeof(d2));
+    d2.len = ax.B; d2.J = ax.A; d2.nlines = nlines; d2.mode = lines_fastest ? 2 : 0;
+    d2.js_in = (long long)ax.B * st; d2.es_in = st; d2.lst_in = lst;
+    d2.js_out = st; d2.es_out = (long long)ax.A * st; d2.lst_out = lst;
+    d2.twiddle = 0; d2.N = ax.N; d2.conj_in = 0; d2.conj_out = inverse; d2.scale = 1.0;
+    *p1 = d1; *p2 = d2;
+}
+
 static void big_axis_transform(sfft_plan* p, const AxisHost& ax, cplx* data, cplx* scr, long long st, long long lst, int nlines,
                                bool lines_fastest, int inverse, hipStream_t s, const cplx* src = nullptr, const double* wrow = nullptr)
 {
@@ -1660,19 +1684,31 @@ static void big_axis_transform(sfft_plan* p, const AxisHost& ax, cplx* data, cpl
         }
         return;
     }
-    PassDesc d1; memset(&d1, 0, sizeof(d1));
-    d1.w = wrow; d1.w_js = 1; d1.w_es = ax.B;
-    d1.len = ax.A; d1.J = ax.B; d1.nlines = nlines; d1.mode = lines_fastest ? 2 : 1;
-    d1.js_in = st; d1.es_in = (long long)ax.B * st; d1.lst_in = lst;
-    d1.js_out = d1.js_in; d1.es_out = d1.es_in; d1.lst_out = lst;
-    d1.twiddle = 1; d1.N = ax.N; d1.conj_in = inverse; d1.conj_out = 0; d1.scale = 1.0;
+    PassDesc d1, d2;
+    four_step_passes(ax, st, lst, nlines, lines_fastest, inverse, wrow, &d1, &d2);
     launch_pass(p, src ? src : data, scr, d1, *ax.subA, ax.root, s);
-    PassDesc d2; memset(&d2, 0, sizeof(d2));
-    d2.len = ax.B; d2.J = ax.A; d2.nlines = nlines; d2.mode = lines_fastest ? 2 : 0;
-    d2.js_in = (long long)ax.B * st; d2.es_in = st; d2.lst_in = lst;
-    d2.js_out = st; d2.es_out = (long long)ax.A * st; d2.lst_out = lst;
-    d2.twiddle = 0; d2.N = ax.N; d2.conj_in = 0; d2.conj_out = inverse; d2.scale = 1.0;
     launch_pass(p, scr, data, d2, *ax.subB, ax.root, s);
+}
+
+// The staged forward column pass on a four-step axis whose first factor is 16 (9232 = 16 x 577): the outputs of one stage plane, at most
+// DFT16_MAX_OUT at a time, share ONE read of the stage plane in the first pass (strided_dft16_cols_multi); every output then takes its own
+// second pass from its scratch plane.  false: this axis / build does not take that route (the caller transforms output by output).
+static bool staged_cols_shared_first_pass(sfft_plan* p, const AxisHost& ax, const cplx* stage, int nout, cplx* const* dsts, const double* const* wx,
+                                          long long st, long long lst, int nlines, hipStream_t s)
+{
+    if (ax.bigblue || !ax.subA || ax.A != 16 || ax.subA->M != 16 || ax.subA->blue || p->no_dft16_regs || p->colscr_planes < 2 || p->no_dft16_multi) return false;
+    PassDesc d1, d2;
+    four_step_passes(ax, st, lst, nlines, true, 0, p->d_ones, &d1, &d2);        // (d1.w only says "weighted": the kernel takes the weights per output)
+    const size_t plane_sz = (size_t)p->N0 * p->Nhp;
+    for (int o0 = 0; o0 < nout; o0 += std::min(DFT16_MAX_OUT, p->colscr_planes)) {
+        const int no = std::min(std::min(DFT16_MAX_OUT, p->colscr_planes), nout - o0);
+        Dft16Outs oo; memset(&oo, 0, sizeof(oo));
+        oo.nout = no;
+        for (int q = 0; q < no; ++q) { oo.w[q] = wx[o0 + q]; oo.out[q] = p->d_colscr + (size_t)q * plane_sz; }
+        SFFT_LAUNCH(strided_dft16_cols_multi, dim3((d1.nlines + 63) / 64, (d1.J + 3) / 4), dim3(256), 0, s, stage, oo, d1, (const cplx*)ax.root);
+        for (int q = 0; q < no; ++q) launch_pass(p, p->d_colscr + (size_t)q * plane_sz, dsts[o0 + q], d2, *ax.subB, ax.root, s);
+    }
+    return true;
 }
 
 static void launch_cols(sfft_plan* p, cplx* data, int nplanes, int inverse, hipStream_t s)
@@ -1794,10 +1830,14 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
         if (p->ax0.big) {
             // four-step column axis: every output plane is the transform of its stage plane times the row factor, applied as the first
             // pass reads the stage plane (same traffic as transforming a finished plane; the row pass ran once per column factor)
-            for (int k = 0; k < nst; ++k)
+            for (int k = 0; k < nst; ++k) {
+                std::vector<cplx*> dsts; std::vector<const double*> wxs;
+                for (const Out& o : stages[k].outs) { dsts.push_back(dst + (size_t)o.plane * plane_sz); wxs.push_back(o.wx == p->d_ones ? nullptr : o.wx); }
+                if (staged_cols_shared_first_pass(p, p->ax0, p->d_stage + (size_t)k * plane_sz, (int)dsts.size(), dsts.data(), wxs.data(), p->Nhp, 1, p->Nh, s)) continue;
                 for (const Out& o : stages[k].outs)
                     big_axis_transform(p, p->ax0, dst + (size_t)o.plane * plane_sz, p->d_colscr, p->Nhp, 1, p->Nh, true, 0, s,
                                        p->d_stage + (size_t)k * plane_sz, o.wx == p->d_ones ? nullptr : o.wx);
+            }
             LAUNCH_CHECK();
             if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; tl_klog = klog_outer; }
             return SFFT_OK;
