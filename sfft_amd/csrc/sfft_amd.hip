@@ -270,6 +270,7 @@ struct sfft_plan {
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
     int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
     // A/B switches of the launch paths, read ONCE at plan creation (never getenv on a hot path)
+    bool want_mom_event = false, mom_event_recorded = false;   // solve pass: ev_mom right behind the row pass (the Gamma block then runs beside the COLUMN pass)
     int colscr_planes = 1, no_dft16_multi = 0;      // scratch planes of the four-step column path; SFFT_NO_DFT16_MULTI=1: one first pass per output (A/B)
     int no_dft16_regs = 0, no_rader_r24 = 0, no_gamma_aside = 0, vconv2_w12 = 1, inv_r24 = -1;
     // Omega products of basis terms with (nearly) disjoint supports: computed in real space by omega_sparse, no transform pass
@@ -1904,6 +1905,7 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                            p->d_stage + (size_t)k0 * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
     }
     LAUNCH_CHECK();
+    if (p->want_mom_event && p->rowmom_fused && d_J) { HIPCHK(hipEventRecord(p->ev_mom, s)); p->mom_event_recorded = true; }     // the row moments exist from here on
     if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][1], s); p->ev_valid[st_rows] = true; tl_klog = klog_outer; }
     if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][0], s); tl_klog = &p->stage_kernels[st_cols]; }
     const int npairs = (p->Nh + 1) / 2;
@@ -2315,9 +2317,13 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     // group, so only one of the two moment sets would be written: such a call takes the separate row_moments launches.
     struct ScopedInt { int& r; int old; ScopedInt(int& ref, int v) : r(ref), old(ref) { r = v; } ~ScopedInt() { r = old; } }
         rowmom_scope(p->rowmom_fused, d_I == d_J ? 0 : p->rowmom_fused);
+    const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !p->no_gamma_aside;
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
-        if ((rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS))) return rc;
+        p->want_mom_event = gamma_aside; p->mom_event_recorded = false;
+        rc = forward_basis_planes(p, d_I, d_J, p->d_spec, s, true, SFFT_ST_FWD_ROWS, SFFT_ST_FWD_COLS);
+        p->want_mom_event = false;
+        if (rc) return rc;
 #define ROWMOM_J(NQT) SFFT_LAUNCH(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_J, p->d_rowmom, p->N0, p->N1, p->d_tby, p->nby)
         if (p->rowmom_fused) { /* written by rows_r2c_4096 */ }
         else if (p->nby == 1) ROWMOM_J(1); else if (p->nby == 2) ROWMOM_J(2); else if (p->nby == 3) ROWMOM_J(3); else if (p->nby == 4) ROWMOM_J(4);
@@ -2327,11 +2333,13 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         LAUNCH_CHECK();
     }
     // The real-space Gamma block (two small kernels on the row moments) does not depend on the spectra: when the moments came out of
-    // the row pass it runs on the plan's second stream, beside the Omega launch, and joins before the system is filled
-    const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !p->no_gamma_aside;
+    // the row pass it runs on the plan's second stream and joins before the system is filled.  On the 4096^2 fast path its start event
+    // sits right behind the ROW pass, so it runs beside the column pass and is long done when fill_system is due; beside the Omega
+    // launch (rounds 2 - 4) its one-thread-per-row kernel stretched from 27 to 342 us and fill_system waited ~28 us for it
+    // (profiles/r05_timeline_cfg2_one_pair.txt)
     if (gamma_aside) {
         const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
-        HIPCHK(hipEventRecord(p->ev_mom, s));
+        if (!p->mom_event_recorded) HIPCHK(hipEventRecord(p->ev_mom, s));
         HIPCHK(hipStreamWaitEvent(p->s2, p->ev_mom, 0));
         SFFT_LAUNCH(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, p->s2, d_I, p->d_rowmomI, p->d_tby,
                            p->gam_tab ? p->d_kby : (const double*)nullptr, nd, p->gam_db, p->w, p->N0, p->N1, p->d_gamR);
