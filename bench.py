@@ -168,8 +168,8 @@ def compact(full):
                        "vs_baseline", "dtype", "data"))
     cfg = full.get("config", {})
     out["config"] = _pick(cfg, ("workload", "baseline_config", "pairs_per_step", "pairs_in_flight_per_gpu", "timed_region_s", "NEQ", "solver"))
-    if len(out["config"].get("workload", "")) > 260:
-        out["config"]["workload"] = out["config"]["workload"][:257] + "..."
+    if len(out["config"].get("workload", "")) > 200:
+        out["config"]["workload"] = out["config"]["workload"][:197] + "..."
     for k in ("roofline", "roofline_hbm", "roofline_greek", "roofline_solve"):
         if k in full:
             out[k] = _pick(full[k], ROOF_KEYS)
@@ -185,6 +185,10 @@ def compact(full):
         out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "seconds_per_pair", "spread_s", "protocol", "cpu_model", "physical_cores",
                                          "all_cores_s_per_pair", "full_protocol"))
         out["cpu_baseline"]["sample"] = "one full GSS of the 4096x4096 seed-1234 pair (pair 0 of the GPU batch), no size scaling"
+        if isinstance(out["cpu_baseline"].get("protocol"), str):        # (the full wording is in the full object)
+            out["cpu_baseline"]["protocol"] = out["cpu_baseline"]["protocol"][:96]
+        if isinstance(out["cpu_baseline"].get("full_protocol"), dict):
+            out["cpu_baseline"]["full_protocol"] = _pick(out["cpu_baseline"]["full_protocol"], ("threads_8_s_per_pair", "all_cores_s_per_pair", "runs_each", "warmups_each"))
     if "post_check" in full:
         out["post_check"] = _pick(full["post_check"], ("pairs_checked", "bitwise_equal", "max_rel_diff"))
     if "host_arrays" in full:
