@@ -52,9 +52,11 @@ static void apply_perm(double* A, int ld, const LuPerm* perm, int cbeg, int cend
 // Taller panels would need sub-panels of 8, 4, 2 columns, whose left-looking updates re-read the panel's L columns 224 / 480 / 992 times
 // per row through one CU: they are factored in four GROUPS of 16 columns instead -- each group one panel launch on all rows, followed by
 // the update of the panel's remaining columns by the whole chip -- and the groups' row lists are then applied to the rest of the matrix.
-#define LU_ONE_KERNEL_ROWS (8 * LU_NT)
+#define LU_ONE_KERNEL_ROWS (xchg && epoch_ctr ? 4 * LU_NT : 8 * LU_NT)
 #define LU_GROUP 16
-void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, double* rd, hipStream_t s, lu_note_fn note)
+size_t lu_xchg_bytes() { return sizeof(LuXchg); }
+
+void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, double* rd, void* xchg, const unsigned int* epoch_ctr, hipStream_t s, lu_note_fn note)
 {
     const int npan = (n + LU_NB - 1) / LU_NB;
     for (int pn = 0; pn < npan; ++pn) {
@@ -62,6 +64,21 @@ void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, do
         LuPerm* pl = perms + (size_t)LU_PERMS_PER_PANEL * pn;
         if (n - K0 <= LU_ONE_KERNEL_ROWS) {
             say(note, launch_panel(A, ld, n, K0, NBo, pl, status, s));
+            update(A, ld, n, K0, NBo, pl, n + 1, s, note);
+            continue;
+        }
+        if (xchg && epoch_ctr && n - K0 <= 6 * LU_NT * LU_MW_MAXG) {
+            // tall panel: G <= 16 workgroups, the pivot of every column agreed through global hand-off slots (lu_panel_mw); as few rows per
+            // thread as 16 workgroups allow (the pivot chain's cost per column grows with them)
+            const int m = n - K0;
+            const int Rw = m <= 2 * LU_NT * LU_MW_MAXG ? 2 : m <= 3 * LU_NT * LU_MW_MAXG ? 3 : m <= 4 * LU_NT * LU_MW_MAXG ? 4 : 6;
+            const int G = (m + Rw * LU_NT - 1) / (Rw * LU_NT);
+            hipLaunchKernelGGL(lu_perm_reset, dim3(1), dim3(64), 0, s, pl);
+#define LU_MW(RR) hipLaunchKernelGGL(lu_panel_mw<RR>, dim3(G), dim3(LU_NT), 0, s, A, ld, n, K0, NBo, pl, status, (LuXchg*)xchg, epoch_ctr, pn)
+            if (Rw == 2) LU_MW(2); else if (Rw == 3) LU_MW(3); else if (Rw == 4) LU_MW(4); else LU_MW(6);
+#undef LU_MW
+            say(note, "lu_panel_mw");
+            apply_perm(A, ld, pl, K0, K0 + NBo, s, note);                // the panel's own columns: rows into place
             update(A, ld, n, K0, NBo, pl, n + 1, s, note);
             continue;
         }

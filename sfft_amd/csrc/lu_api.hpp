@@ -15,5 +15,8 @@ struct LuPerm { int count; int pad[3]; int pos[LU_MAXTOUCH]; int src[LU_MAXTOUCH
 // LU_PERMS_PER_PANEL lists per 64-column panel.  note(name) is called once per launch with the kernel's name (may be null).
 #define LU_PERMS_PER_PANEL 4
 typedef void (*lu_note_fn)(const char* kernel_name);
-void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, double* rd, hipStream_t s, lu_note_fn note);
+// xchg: lu_xchg_bytes() bytes of zero-initialised device memory (the hand-off slots of the multi-workgroup panel; nullptr: tall panels are
+// factored in 16-column groups on one workgroup instead); epoch_ctr: the device counter chol_begin advances once per solve.
+size_t lu_xchg_bytes();
+void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, double* rd, void* xchg, const unsigned int* epoch_ctr, hipStream_t s, lu_note_fn note);
 #endif

@@ -229,6 +229,7 @@ struct sfft_plan {
     hipGraphExec_t lu_exec = nullptr;   // the pivoted-LU chain (lu.hpp), captured the same way on its first use
     std::string lu_graph_kernels;
     LuPerm* d_luperm = nullptr;         // [panels] row permutation lists of the LU panels
+    double* d_luxchg = nullptr;         // hand-off slots of the multi-workgroup LU panel (systems taller than 2048 rows)
     hipGraphExec_t chol_exec = nullptr; // the factorisation + back substitution chain, captured once (env SFFT_NO_GRAPH=1: plain launches)
     int use_graph = 1;
     int* h_status = nullptr;            // pinned: status word of the most recent attempt
@@ -1349,6 +1350,10 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         PLAN_HIP(hipMemset(p->d_tflags, 0, ((size_t)nblk_b * (nblk_b + 1) + 1) * sizeof(unsigned int)));
         PLAN_TRY(dev_alloc(p, &p->d_w16, (size_t)nblk_b * 1024));
         PLAN_TRY(dev_alloc(p, &p->d_luperm, (size_t)LU_PERMS_PER_PANEL * nblk_b));
+        if (p->NEQfs > 1024) {
+            PLAN_TRY(dev_alloc(p, &p->d_luxchg, (lu_xchg_bytes() + 7) / 8));
+            PLAN_HIP(hipMemset(p->d_luxchg, 0, lu_xchg_bytes()));
+        }
         if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
         if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
         if (const char* ev = getenv("SFFT_PANEL4")) p->panel4 = atoi(ev);
@@ -1513,7 +1518,7 @@ extern "C" int sfft_plan_destroy(sfft_plan* p)
     free_axis(p->ax0); free_axis(p->ax1);
     void* ptrs[] = {p->d_idx, p->d_phi, p->d_Xp, p->d_Yq, p->d_passes, p->d_jobs, p->d_spec, p->d_gp, p->d_patches, p->d_A, p->d_sol,
                     p->d_rtab, p->d_rowmom, p->d_delta, p->d_status, p->d_dbuf, p->d_xv, p->d_partial, p->d_counter, p->d_w0tab, p->d_rd, p->d_spec2, p->d_big1, p->d_big2, p->d_colscr, p->d_bb1, p->d_bb2, p->d_kbx, p->d_kby, p->d_tbx, p->d_tby, p->d_zero, p->d_zsol,
-                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_luperm, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_ibase, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
+                    p->d_sbx, p->d_sby, p->d_ireg, p->d_sst, p->d_csst, p->d_dsst, p->d_ones, p->d_stage, p->d_stage_a, p->d_ctabm, p->d_winv, p->d_luperm, p->d_luxchg, p->d_bflags, p->d_epoch, p->d_tflags, p->d_trace, p->d_w16, p->d_groups, p->d_g1trace, p->d_sprods, p->d_slines, p->d_scols, p->d_strip, p->d_sitems, p->d_ibase, p->d_cyp, p->d_rowmomI, p->d_gamR, p->d_pq};
     if (p->chol_exec) hipGraphExecDestroy(p->chol_exec);
     if (p->lu_exec) hipGraphExecDestroy(p->lu_exec);
 
@@ -2239,7 +2244,7 @@ static int run_lu_launches(sfft_plan* p, double* d_solution, hipStream_t s)
     const int npan = (n + LU_NB - 1) / LU_NB;
     unsigned int* d_queue = p->d_tflags + (size_t)npan * (npan + 1);
     SFFT_LAUNCH(chol_begin, dim3(1), dim3(PANEL4_MAX_OUTER), 0, s, p->d_epoch, d_queue, p->d_pq);       // a new stamp for chol_back_all's flags
-    lu_factor_launches(p->d_A, p->ld, n, p->d_luperm, p->d_status, p->d_rd, s, lu_note);
+    lu_factor_launches(p->d_A, p->ld, n, p->d_luperm, p->d_status, p->d_rd, p->d_luxchg, p->d_epoch, s, lu_note);
     LAUNCH_CHECK();
     return run_back_substitution(p, d_solution, s, false);
 }
