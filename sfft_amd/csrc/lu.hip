@@ -74,7 +74,7 @@ void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, do
             const int Rw = m <= 2 * LU_NT * LU_MW_MAXG ? 2 : m <= 3 * LU_NT * LU_MW_MAXG ? 3 : m <= 4 * LU_NT * LU_MW_MAXG ? 4 : 6;
             const int G = (m + Rw * LU_NT - 1) / (Rw * LU_NT);
             hipLaunchKernelGGL(lu_perm_reset, dim3(1), dim3(64), 0, s, pl);
-#define LU_MW(RR) hipLaunchKernelGGL(lu_panel_mw<RR>, dim3(G), dim3(LU_NT), 0, s, A, ld, n, K0, NBo, pl, status, (LuXchg*)xchg, epoch_ctr, pn)
+#define LU_MW(RR) hipLaunchKernelGGL(lu_panel_mw<RR>, dim3(8 * G), dim3(LU_NT), 0, s, A, ld, n, K0, NBo, pl, status, (LuXchg*)xchg, epoch_ctr, pn)
             if (Rw == 2) LU_MW(2); else if (Rw == 3) LU_MW(3); else if (Rw == 4) LU_MW(4); else LU_MW(6);
 #undef LU_MW
             say(note, "lu_panel_mw");

@@ -422,34 +422,46 @@ typedef unsigned int lu_u4 __attribute__((ext_vector_type(4)));
 struct LuXchg {
     lu_u4 rec[LU_NB][LU_MW_MAXG][LU_XG];
     lu_u4 trow[LU_NB / LU_MW_W][LU_MW_W][LU_NB];            // [sub-panel][pivot row i][panel column]
+    lu_u4 hello[LU_MW_MAXG];                                // launch start: the XCD every workgroup runs on
 };
-__device__ __forceinline__ void lu_put(__amdgpu_buffer_rsrc_t rsrc, int byteoff, unsigned long long bits, unsigned int stamp)
+// near = every workgroup of the launch runs on the SAME XCD (checked at launch start from HW_REG_XCC_ID, never assumed): the XCD's L2 is
+// then the meeting point -- stores that stay in it (sc0: the L1 writes through) and device-scope loads (sc1: past the L1, served by that L2) -- at a fraction of the latency of
+// the write-through-to-memory / read-from-memory pair (sc1 stores, sc0 sc1 loads) that any placement needs.
+__device__ __forceinline__ void lu_put(lu_u4* p, unsigned long long bits, unsigned int stamp, bool near)
 {
     lu_u4 pk; pk.x = (unsigned int)bits; pk.y = (unsigned int)(bits >> 32); pk.z = stamp; pk.w = 0u;
-    __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, byteoff, 0, /*aux: sc1*/ 16);
+    if (near) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(p), "v"(pk) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(pk) : "memory");
 }
-// spin (bounded) until the granule carries this launch's stamp; returns its 8 value bytes.  (Inline asm: written with the buffer-load builtin
-// the compiler hoists the load out of the spin loop -- its "volatile" aux bit is not honoured here -- and the loop only sleeps.)
-__device__ __forceinline__ lu_u4 lu_ld16_sys(const lu_u4* p)
+// (inline asm: written with the buffer-load builtin the compiler hoists the load out of the spin loop -- its "volatile" aux bit is not honoured
+//  here -- and the loop only sleeps)
+__device__ __forceinline__ lu_u4 lu_ld16(const lu_u4* p, bool near)
 {
     lu_u4 g;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g) : "v"(p) : "memory");
+    if (near) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g) : "v"(p) : "memory");
     return g;
 }
 #define LU_XK 5                                              // granules a lane of wave 0 watches per column: ceil(16 x 18 / 64)
-__device__ __forceinline__ void lu_ld16_sys_n(const lu_u4* const (&p)[LU_XK], lu_u4 (&g)[LU_XK])
+__device__ __forceinline__ void lu_ld16_n(const lu_u4* const (&p)[LU_XK], lu_u4 (&g)[LU_XK], bool near)
 {
-    asm volatile("global_load_dwordx4 %0, %5, off sc0 sc1\n\tglobal_load_dwordx4 %1, %6, off sc0 sc1\n\tglobal_load_dwordx4 %2, %7, off sc0 sc1\n\t"
-                 "global_load_dwordx4 %3, %8, off sc0 sc1\n\tglobal_load_dwordx4 %4, %9, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]) : "memory");
+    if (near)
+        asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                     "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]) : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %5, off sc0 sc1\n\tglobal_load_dwordx4 %1, %6, off sc0 sc1\n\tglobal_load_dwordx4 %2, %7, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %3, %8, off sc0 sc1\n\tglobal_load_dwordx4 %4, %9, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]) : "memory");
 }
-__device__ __forceinline__ unsigned long long lu_get(const lu_u4* p, unsigned int stamp, int* __restrict__ status)
+// spin (bounded) until the granule carries this launch's stamp; returns its 8 value bytes
+__device__ __forceinline__ unsigned long long lu_get(const lu_u4* p, unsigned int stamp, int* __restrict__ status, bool near)
 {
-    lu_u4 g = lu_ld16_sys(p);
+    lu_u4 g = lu_ld16(p, near);
     int spins = 0;
     while (g.z != stamp) {
         __builtin_amdgcn_s_sleep(1);
-        g = lu_ld16_sys(p);
+        g = lu_ld16(p, near);
         if (++spins > (1 << 20)) { atomicOr(status, 4); break; }
     }
     return ((unsigned long long)g.y << 32) | g.x;
@@ -475,9 +487,22 @@ __global__ void __launch_bounds__(LU_NT) lu_panel_mw(double* __restrict__ A, int
     __shared__ unsigned long long xs[LU_MW_MAXG][LU_XG];           // wave 0's copy of the G records of a column
     __shared__ int ploc[LU_NB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+    // the grid has 8 G workgroups and only every eighth works: observed (not promised) placement is block b -> XCD b % 8, so the G
+    // working ones usually share an XCD and its L2
+    if ((blockIdx.x & 7) != 0) return;
+    const int G = (int)gridDim.x >> 3, wg = (int)blockIdx.x >> 3;
     const int row0 = k0 + wg * (R * LU_NT);                         // first physical row of this workgroup
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)sizeof(LuXchg), 0x00020000);
+    __shared__ int s_near;
+    if (wv == 0) {                                                  // who runs where: one hand-off that works under ANY placement
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) lu_put(&xb->hello[wg], (unsigned long long)(unsigned int)(xcc & 0xF), stamp, false);
+        const unsigned int other = lane < G ? (unsigned int)lu_get(&xb->hello[min(lane, G - 1)], stamp, status, false) : (unsigned int)(xcc & 0xF);
+        const bool same = __ballot(other != (unsigned int)(xcc & 0xF)) == 0ull;
+        if (lane == 0) s_near = same ? 1 : 0;
+    }
+    __syncthreads();
+    const bool near = s_near != 0;
     double a[R][W];
     int pos[R];
 #pragma unroll
@@ -554,7 +579,7 @@ __global__ void __launch_bounds__(LU_NT) lu_panel_mw(double* __restrict__ A, int
                         if (lane < W) bits = (unsigned long long)__double_as_longlong(cdat[buf][gw][lane]);
                         else if (lane == W) bits = (unsigned long long)__double_as_longlong(lk != 0ull ? cand[buf][gw].piv : 0.0);
                         else if (lane == W + 1) bits = (unsigned long long)(unsigned int)cand[buf][gw].pos | ((unsigned long long)(unsigned int)cand[buf][gw].phys << 32);
-                        if (lane < W + 2) lu_put(xr, (int)((((size_t)(c0 + j) * LU_MW_MAXG + wg) * LU_XG + lane) * 16), bits, stamp);
+                        if (lane < W + 2) lu_put(&xb->rec[c0 + j][wg][lane], bits, stamp, near);
                     }
                     {   // all G records (G (W + 2) <= 288 granules): every lane watches up to LU_XK of them, all loads of a look in flight together
                         const int ng = G * (W + 2);
@@ -567,7 +592,7 @@ __global__ void __launch_bounds__(LU_NT) lu_panel_mw(double* __restrict__ A, int
                         lu_u4 gv[LU_XK];
                         int spins = 0;
                         for (;;) {
-                            lu_ld16_sys_n(gp, gv);
+                            lu_ld16_n(gp, gv, near);
                             bool ok = true;
 #pragma unroll
                             for (int u = 0; u < LU_XK; ++u) ok = ok && (gv[u].z == stamp);
@@ -646,12 +671,12 @@ __global__ void __launch_bounds__(LU_NT) lu_panel_mw(double* __restrict__ A, int
                 if (pr >= row0 && pr < row0 + R * LU_NT) {       // mine: L entries of earlier sub-panels from my own stores, raw entries from the matrix
                     double t = A[(size_t)pr * ld + k0 + c];
                     for (int kk = 0; kk < c0; ++kk) t = fma(-A[(size_t)pr * ld + k0 + kk], Ub[kk][c], t);
-                    lu_put(xr, (int)(offsetof(LuXchg, trow) + (((size_t)sp * LU_MW_W + i) * LU_NB + c) * 16), (unsigned long long)__double_as_longlong(t), stamp);
+                    lu_put(&xb->trow[sp][i][c], (unsigned long long)__double_as_longlong(t), stamp, near);
                 }
             }
             for (int e = tid; e < W * ncr; e += LU_NT) {          // every entry waits for its own granule (its owner may be this workgroup)
                 const int i = e / ncr, c = cr0 + (e - i * ncr);
-                Tt[i][c] = __longlong_as_double((long long)lu_get(&xb->trow[sp][i][c], stamp, status));
+                Tt[i][c] = __longlong_as_double((long long)lu_get(&xb->trow[sp][i][c], stamp, status, near));
             }
             __syncthreads();
             if (tid < ncr) {
