@@ -71,11 +71,11 @@ void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, do
             // tall panel: G <= 16 workgroups, the pivot of every column agreed through global hand-off slots (lu_panel_mw); as few rows per
             // thread as 16 workgroups allow (the pivot chain's cost per column grows with them)
             const int m = n - K0;
-            const int Rw = m <= 2 * LU_NT * LU_MW_MAXG ? 2 : m <= 3 * LU_NT * LU_MW_MAXG ? 3 : m <= 4 * LU_NT * LU_MW_MAXG ? 4 : 6;
+            const int Rw = m <= 1 * LU_NT * LU_MW_MAXG ? 1 : m <= 2 * LU_NT * LU_MW_MAXG ? 2 : m <= 3 * LU_NT * LU_MW_MAXG ? 3 : m <= 4 * LU_NT * LU_MW_MAXG ? 4 : 6;
             const int G = (m + Rw * LU_NT - 1) / (Rw * LU_NT);
             hipLaunchKernelGGL(lu_perm_reset, dim3(1), dim3(64), 0, s, pl);
 #define LU_MW(RR) hipLaunchKernelGGL(lu_panel_mw<RR>, dim3(8 * G), dim3(LU_NT), 0, s, A, ld, n, K0, NBo, pl, status, (LuXchg*)xchg, epoch_ctr, pn)
-            if (Rw == 2) LU_MW(2); else if (Rw == 3) LU_MW(3); else if (Rw == 4) LU_MW(4); else LU_MW(6);
+            if (Rw == 1) LU_MW(1); else if (Rw == 2) LU_MW(2); else if (Rw == 3) LU_MW(3); else if (Rw == 4) LU_MW(4); else LU_MW(6);
 #undef LU_MW
             say(note, "lu_panel_mw");
             apply_perm(A, ld, pl, K0, K0 + NBo, s, note);                // the panel's own columns: rows into place
