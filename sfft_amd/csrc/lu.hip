@@ -14,16 +14,12 @@ static const char* panel(const char* name, double* A, int ld, int n, int k0, int
     return name;
 }
 
-// sub-panel width W x rows per thread R (256 threads): W R <= 96 doubles keeps the register tile in the 256 directly addressable
-// registers.  W = 16 is the widest sub-panel whose per-column candidate traffic (write the wave's row, read the winner's) stays
-// small beside the elimination itself; more rows than 16-wide tiles hold take narrower sub-panels.
+// One workgroup, 16-column sub-panels, R rows per thread (256 threads): panels of up to LU_ONE_KERNEL_ROWS rows
 static const char* launch_panel(double* A, int ld, int n, int k0, int nb, LuPerm* perm, int* status, hipStream_t s)
 {
     const int rpt = (n - k0 + LU_NT - 1) / LU_NT;           // rows per thread
-#define LU_CASE(W, R) if (rpt <= R) return panel<W, R>("lu_panel<" #W "," #R ">", A, ld, n, k0, nb, perm, status, s)
-    LU_CASE(16, 2); LU_CASE(16, 4); LU_CASE(16, 6); LU_CASE(8, 8); LU_CASE(8, 12); LU_CASE(4, 16); LU_CASE(4, 24); LU_CASE(2, 48);
-#undef LU_CASE
-    return panel<1, 96>("lu_panel<1,96>", A, ld, n, k0, nb, perm, status, s);
+    if (rpt <= 2) return panel<16, 2>("lu_panel<16,2>", A, ld, n, k0, nb, perm, status, s);
+    return panel<16, 4>("lu_panel<16,4>", A, ld, n, k0, nb, perm, status, s);
 }
 
 static inline void say(lu_note_fn note, const char* name) { if (note && name) note(name); }
@@ -48,12 +44,10 @@ static void apply_perm(double* A, int ld, const LuPerm* perm, int cbeg, int cend
     say(note, "lu_apply_perm");
 }
 
-// Panels of 64 columns.  Up to LU_ONE_KERNEL_ROWS rows the panel is ONE launch (16-column sub-panels inside the kernel, left-looking).
-// Taller panels would need sub-panels of 8, 4, 2 columns, whose left-looking updates re-read the panel's L columns 224 / 480 / 992 times
-// per row through one CU: they are factored in four GROUPS of 16 columns instead -- each group one panel launch on all rows, followed by
-// the update of the panel's remaining columns by the whole chip -- and the groups' row lists are then applied to the rest of the matrix.
-#define LU_ONE_KERNEL_ROWS (xchg && epoch_ctr ? 4 * LU_NT : 8 * LU_NT)
-#define LU_GROUP 16
+// Panels of 64 columns.  Up to LU_ONE_KERNEL_ROWS rows a panel is ONE workgroup (16-column sub-panels inside the kernel, left-looking);
+// taller panels run on G <= 16 workgroups (lu_panel_mw<R>, R rows per thread: as few as 16 workgroups allow -- the pivot chain's cost per
+// column grows with them; below 1024 rows one workgroup is faster: 5.5 vs 5.1 ms at n = 1735 with the threshold at 512).
+#define LU_ONE_KERNEL_ROWS (4 * LU_NT)
 size_t lu_xchg_bytes() { return sizeof(LuXchg); }
 
 void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, double* rd, void* xchg, const unsigned int* epoch_ctr, hipStream_t s, lu_note_fn note)
@@ -67,30 +61,19 @@ void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, do
             update(A, ld, n, K0, NBo, pl, n + 1, s, note);
             continue;
         }
-        if (xchg && epoch_ctr && n - K0 <= 6 * LU_NT * LU_MW_MAXG) {
-            // tall panel: G <= 16 workgroups, the pivot of every column agreed through global hand-off slots (lu_panel_mw); as few rows per
-            // thread as 16 workgroups allow (the pivot chain's cost per column grows with them)
-            const int m = n - K0;
+        {
+            const int m = n - K0;           // (m <= LU_MAX_ROWS = 6 x 256 x 16: the caller refuses larger systems)
             const int Rw = m <= 1 * LU_NT * LU_MW_MAXG ? 1 : m <= 2 * LU_NT * LU_MW_MAXG ? 2 : m <= 3 * LU_NT * LU_MW_MAXG ? 3 : m <= 4 * LU_NT * LU_MW_MAXG ? 4 : 6;
             const int G = (m + Rw * LU_NT - 1) / (Rw * LU_NT);
             hipLaunchKernelGGL(lu_perm_reset, dim3(1), dim3(64), 0, s, pl);
+            // (8 G workgroups of which every eighth works: see lu_panel_mw)
 #define LU_MW(RR) hipLaunchKernelGGL(lu_panel_mw<RR>, dim3(8 * G), dim3(LU_NT), 0, s, A, ld, n, K0, NBo, pl, status, (LuXchg*)xchg, epoch_ctr, pn)
             if (Rw == 1) LU_MW(1); else if (Rw == 2) LU_MW(2); else if (Rw == 3) LU_MW(3); else if (Rw == 4) LU_MW(4); else LU_MW(6);
 #undef LU_MW
             say(note, "lu_panel_mw");
             apply_perm(A, ld, pl, K0, K0 + NBo, s, note);                // the panel's own columns: rows into place
             update(A, ld, n, K0, NBo, pl, n + 1, s, note);
-            continue;
         }
-        const int ngrp = (NBo + LU_GROUP - 1) / LU_GROUP;
-        for (int g = 0; g < ngrp; ++g) {
-            const int k0 = K0 + LU_GROUP * g, nb = K0 + NBo - k0 < LU_GROUP ? K0 + NBo - k0 : LU_GROUP;
-            say(note, launch_panel(A, ld, n, k0, nb, pl + g, status, s));
-            apply_perm(A, ld, pl + g, K0, k0, s, note);                  // the panel's earlier columns: their rows follow
-            update(A, ld, n, k0, nb, pl + g, K0 + NBo, s, note);         // the panel's later columns
-        }
-        for (int g = 0; g < ngrp; ++g) apply_perm(A, ld, pl + g, K0 + NBo, n + 1, s, note);      // everything right of the panel, list after list
-        update(A, ld, n, K0, NBo, nullptr, n + 1, s, note);
     }
     hipLaunchKernelGGL(lu_transpose_upper, dim3((n + 1 + LU_NB - 1) / LU_NB, npan), dim3(256), 0, s, A, ld, n, rd, status);
     say(note, "lu_transpose_upper");

@@ -19,6 +19,7 @@
 //                    physical row `loc` and the (position -> loc) map travels with the register copy through the pivot exchanges;
 //                    the panel's own 64 columns are permuted into place at the end and the map goes out as a list of at most
 //                    128 (position, source) pairs.
+//   lu_panel_mw<R>   the same panel on G <= 16 workgroups (panels taller than 1024 rows): see there.
 //   lu_swap_trsm     one workgroup per 64-column slab right of the panel (the right-hand side included): applies the list (a
 //                    gather through registers: all reads, barrier, all writes), then U12 = L11^-1 A12 (unit lower, in LDS).
 //   lu_gemm          A22 -= L21 U12 on 64 x 64 tiles, v_mfma_f64_16x16x4_f64, one 32 x 32 quadrant per wave.

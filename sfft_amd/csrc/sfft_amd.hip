@@ -870,7 +870,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (p->NEQfs > LU_MAX_ROWS) {       // (the pivoted-LU panel keeps 64 rows per thread of one 512-thread workgroup in registers)
+    if (p->NEQfs > LU_MAX_ROWS) {       // (the pivoted-LU panel runs on at most 16 workgroups of 1536 rows)
         sfft_plan_destroy(p);
         return set_err(SFFT_ERR_UNSUPPORTED_SIZE, "linear system too large for the pivoted-LU panel of this build");
     }
