@@ -2715,7 +2715,7 @@ extern "C" int sfft_dbg_solve_dense(sfft_plan* p, const double* d_bordered, int 
     HIPCHK(hipStreamSynchronize(s));
     p->last_solver = use_lu ? 2 : 1;
     if (!use_lu) p->chol_status = *p->h_status;
-    if (*p->h_status != 0) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+    if (*p->h_status != 0) return set_err(SFFT_ERR_SINGULAR, std::string("Singular matrix") + ((*p->h_status & 4) ? " (a hand-off of the solver timed out: status " + std::to_string(*p->h_status) + ")" : ""));
     return SFFT_OK;
 }
 
