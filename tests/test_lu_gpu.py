@@ -148,3 +148,38 @@ def test_large_systems_by_residual(dev, geom):
     assert float((x - xt).abs().max() / xt.abs().max()) <= 1e-7
     _PLANS.pop(geom, None)
     plan.close()
+
+
+def test_two_plans_factor_at_the_same_time(dev):
+    """Two plans (own hand-off slots, own streams, own host threads) run the multi-workgroup panel side by side: the spinning workgroups of one
+    launch must neither starve nor read the other's slots.  Each result must equal the one the same plan gives alone, bit for bit (the pivot
+    agreement is deterministic: largest magnitude, lowest workgroup among ties)."""
+    import threading
+    from sfft_amd.plan import Plan
+    geom = (8, 3, 3, False)                      # n = 2900: three multi-workgroup panel shapes per solve
+    plans = [Plan(68, 68, *geom, device=dev.index) for _ in range(2)]
+    n = plans[0].query("SOLVER_N")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    As = [torch.randn((n, n), dtype=torch.float64, device=dev, generator=g) for _ in range(2)]
+    bs = [torch.randn(n, dtype=torch.float64, device=dev, generator=g) for _ in range(2)]
+    alone = [plans[k].solve_dense(As[k], bs[k], use_lu=True).clone() for k in range(2)]
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    out = [[None] * 6 for _ in range(2)]
+
+    def worker(k):
+        torch.cuda.set_device(dev.index)
+        with torch.cuda.stream(streams[k]):
+            for r in range(6):
+                out[k][r] = plans[k].solve_dense(As[k], bs[k], use_lu=True).clone()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize(dev)
+    for k in range(2):
+        r = (As[k] @ alone[k] - bs[k]).abs().max() / (As[k].abs().max() * alone[k].abs().max() * n)
+        assert float(r) <= 1e-14
+        for rr in range(6):
+            assert torch.equal(out[k][rr], alone[k]), (k, rr)
+    for p in plans:
+        p.close()
