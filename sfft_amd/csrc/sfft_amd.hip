@@ -2323,6 +2323,27 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     struct ScopedInt { int& r; int old; ScopedInt(int& ref, int v) : r(ref), old(ref) { r = v; } ~ScopedInt() { r = old; } }
         rowmom_scope(p->rowmom_fused, d_I == d_J ? 0 : p->rowmom_fused);
     const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !p->no_gamma_aside;
+    // Without the fused row moments (every shape but 4096^2, and solve(I, I)) the Gamma block needs nothing but the image itself: its three
+    // kernels (row moments of I, gamma_rows, gamma_patches: 0.42 ms at config 3, 0.60 ms at config 5, a few workgroups each) go to the second
+    // stream right at the start of the solve, beside the forward transforms, instead of sitting on the main stream behind the Omega launch
+    const bool gamma_early = p->gamma_analytic && !p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !p->no_gamma_aside;
+    if (gamma_early) {
+        const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
+        HIPCHK(hipEventRecord(p->ev_mom, s));                      // (behind the previous pair's fill_system, which reads the patches)
+        HIPCHK(hipStreamWaitEvent(p->s2, p->ev_mom, 0));
+#define ROWMOM_I(NQT) SFFT_LAUNCH(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, p->s2, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
+        switch (nd) {
+            case 1: ROWMOM_I(1); break; case 2: ROWMOM_I(2); break; case 3: ROWMOM_I(3); break; case 4: ROWMOM_I(4); break;
+            case 5: ROWMOM_I(5); break; case 6: ROWMOM_I(6); break; case 7: ROWMOM_I(7); break; default: ROWMOM_I(SFFT_MAX_BQ); break;
+        }
+#undef ROWMOM_I
+        SFFT_LAUNCH(gamma_rows, dim3((p->N0 + 255) / 256, NJ * NQB), dim3(256), 0, p->s2, d_I, p->d_rowmomI, p->d_tby,
+                           p->gam_tab ? p->d_kby : (const double*)nullptr, nd, p->gam_db, p->w, p->N0, p->N1, p->d_gamR);
+        SFFT_LAUNCH(gamma_patches, dim3(p->Fij * p->Fpq, 2 * p->w + 1), dim3(256), 0, p->s2, p->d_gamR, p->d_kbx, p->d_tbx, p->ga, NQB,
+                           p->N0, p->d_patches + p->fa.gam_off, p->scale * p->scale);
+        LAUNCH_CHECK();
+        HIPCHK(hipEventRecord(p->ev_gam, p->s2));
+    }
     {
         StageTimer t(p, SFFT_ST_PRELIM_SOLVE, s);
         p->want_mom_event = gamma_aside; p->mom_event_recorded = false;
@@ -2370,7 +2391,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
             const int fused = ((p->theta_in_groups || p->theta_slots) && p->g1_mfma >= 3) ? p->n_the_fused : 0;      // (the rest: a vector launch of their own)
             if (fused < p->n_dense_w && (rc = greek_g1_group(p, p->n_omg_rec + fused, p->n_dense_w - fused, p->w, s))) return rc;
         }
-        if (p->gamma_analytic && !gamma_aside) {     // Gamma block: row moments of I, then the patches (no spectra involved)
+        if (p->gamma_analytic && !gamma_aside && !gamma_early) {     // Gamma block: row moments of I, then the patches (no spectra involved)
             const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
 #define ROWMOM_I(NQT) SFFT_LAUNCH(row_moments<NQT>, dim3((p->N0 + ROWMOM_R - 1) / ROWMOM_R), dim3(256), 0, s, d_I, p->d_rowmomI, p->N0, p->N1, p->d_cyp, nd)
             if (!p->rowmom_fused)
@@ -2403,7 +2424,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
                                p->Nh, p->Nhp, p->N1, p->S, p->ax1.root, p->d_Yq, p->scale);
         LAUNCH_CHECK();
     }
-    if (gamma_aside) HIPCHK(hipStreamWaitEvent(s, p->ev_gam, 0));
+    if (gamma_aside || gamma_early) HIPCHK(hipStreamWaitEvent(s, p->ev_gam, 0));
     p->have_system = true;
     if (p->overlap_I) {      // sfft_subtract: start the full pair's forward transforms now, beside the dense solve
         const double* dI = p->overlap_I;
