@@ -190,6 +190,10 @@ ORACLE_CASES = [
     (192, 176, 12, 1, 1, True, "SCI", True),    # h = 24 (config 5's KerHW): decimated, second launch at half the matrix instructions
     (130, 140, 16, 1, 0, False, "REF", True),   # h = 32, N0 not a multiple of 16: undecimated launches with the row mask, both full
     (256, 96, 14, 0, 1, True, "REF", False),    # h = 28, a single kernel plane: one diagonal pass, no groups of three
+    # sides with a prime factor above the on-chip Bluestein limit (round 5): Bluestein through the four-step transform, forward AND inverse,
+    # column axis / row axis, the whole subtraction against the oracle
+    (4621, 40, 2, 1, 1, True, "REF", False),    # 4621 is prime: 16384-point four-step transforms on the column axis
+    (48, 10006, 2, 2, 1, False, "SCI", True),   # 10006 = 2 x 5003 on the row axis (packed row pairs): 32768-point transforms
 ]
 
 
