@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
                                                      const unsigned int* __restrict__ epoch_ctr, int* __restrict__ status,
                                                      double* __restrict__ rd, double* __restrict__ w16, double* __restrict__ winv, unsigned long long* __restrict__ trace)
 {
-    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB + 4 * 16 * W16_LD];
+    __shared__ double smem[2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB];
     __shared__ int s_task;
 #define DF_TRACE(slot) do { if (trace && tid == 0) trace[(size_t)bj * 16 + (slot)] = wall_clock64(); } while (0)
     double (*Li)[CB + 1] = reinterpret_cast<double (*)[CB + 1]>(smem);                       // operand tile / the accumulated tile T
@@ -787,7 +787,10 @@ __global__ void __launch_bounds__(256) chol_dataflow(double* __restrict__ A, int
     PanelLds& L = *reinterpret_cast<PanelLds*>(smem + CB * (CB + 1));
     double (*W16t)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16);
     double (*Vd)[4] = reinterpret_cast<double (*)[4]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD);
-    double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(smem + 2 * CB * (CB + 1) + CB + 16 * CB + 16 + 4 * 16 * W16_LD + 4 * CB);
+    // chol_inv64_mfma's per-wave scratch (waves 0..2 only: 3 x 16 x 17 doubles) lies over the panel's Rw/Fw (2 x 512 doubles), which are
+    // dead once chol_factor_diag has returned; keeping it out of the static size leaves room for a row-pass workgroup beside this one on a CU
+    static_assert(3 * 16 * W16_LD <= 2 * 2 * CB * 4, "Sm64 overlay does not fit into PanelLds::Rw + Fw");
+    double (*Sm64)[16][W16_LD] = reinterpret_cast<double (*)[16][W16_LD]>(&L.Rw[0][0][0]);
     const unsigned int epoch = (*epoch_ctr << 8) | DF_EPOCH_TAG;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lk = lane >> 4;
     const int ti = 16 * wv + ln, cg = lk;                    // element ownership of chol_factor_diag<true>
