@@ -13,15 +13,20 @@ LIB = os.path.join(PKG_DIR, "libsfft_amd.so")
 OBJ_DIR = os.path.join(os.path.dirname(PKG_DIR), "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# csrc/sfft_amd.hip only: matrix instructions take their accumulators in ordinary registers.  chol_dataflow needs more than 256 registers, and the
+# compiler's default for such a kernel is the accumulation-register form of EVERY matrix instruction -- 16 v_accvgpr moves and a full-latency
+# wait around each rank-4 update of chol_factor_diag (981 moves in the kernel, 177 with the flag): block step 19.7 -> 18.3 us (docs/LOG.md).
+# Kernels that fit 256 registers (the Omega launches, vconv_tensor) are in this form already and compile to the same code.
+MAIN_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "sfft_amd.h")
 LU_ONLY = ("lu.hip", "lu.hpp")                      # sources only csrc/lu.hip sees; lu_api.hpp is seen by both units
 
 
 def _units():
     every = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
-    main_deps = [f for f in every if os.path.basename(f) not in LU_ONLY] + ([HEADER] if os.path.exists(HEADER) else [])
+    main_deps = [f for f in every if os.path.basename(f) not in LU_ONLY] + ([HEADER] if os.path.exists(HEADER) else []) + [os.path.abspath(__file__)]      # (this file: MAIN_FLAGS)
     lu_deps = [os.path.join(CSRC, f) for f in ("lu.hip", "lu.hpp", "lu_api.hpp")]
-    return [(SRC, os.path.join(OBJ_DIR, "sfft_amd.o"), main_deps), (os.path.join(CSRC, "lu.hip"), os.path.join(OBJ_DIR, "lu.o"), lu_deps)]
+    return [(SRC, os.path.join(OBJ_DIR, "sfft_amd.o"), main_deps, MAIN_FLAGS), (os.path.join(CSRC, "lu.hip"), os.path.join(OBJ_DIR, "lu.o"), lu_deps, [])]
 
 
 def _stale(target, deps):
@@ -30,23 +35,23 @@ def _stale(target, deps):
 
 def needs_build():
     units = _units()
-    return any(_stale(o, d) for _, o, d in units) or _stale(LIB, [o for _, o, _ in units if os.path.exists(o)] or [SRC])
+    return any(_stale(o, d) for _, o, d, _ in units) or _stale(LIB, [o for _, o, _, _ in units if os.path.exists(o)] or [SRC])
 
 
 def build_library(force=False, verbose=True):
     units = _units()
     os.makedirs(OBJ_DIR, exist_ok=True)
     procs = []
-    for src, obj, deps in units:
+    for src, obj, deps, extra in units:
         if force or _stale(obj, deps):
-            cmd = [HIPCC] + CFLAGS + ["-c", "-o", obj, src]
+            cmd = [HIPCC] + CFLAGS + extra + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    objs = [o for _, o, _ in units]
+    objs = [o for _, o, _, _ in units]
     if procs or force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

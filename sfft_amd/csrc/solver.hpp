@@ -108,17 +108,19 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         if (jq >= 1 && jq < 15) {
             double (&Fp)[CB][4] = L.Fw[(jq - 1) & 1];
             if (MF) {
-                const int wvm = tid >> 6, l15 = tid & 15;
+                // every wave updates every tile from the round's first one on -- also the tiles right of its own diagonal tile, whose entries lie
+                // above the diagonal and are never read: the barrier waits for wave 3 (which needs them all) anyway, each wave has its own matrix
+                // pipe, and without the wave test the round is straight-line code (with it: exec-mask or branch bookkeeping and ~30 register
+                // copies per round around the branches)
+                const int l15 = tid & 15;
 #pragma unroll
                 for (int t = (jq + 1) / 4; t < 4; ++t) {
-                    if (t <= wvm) {                  // (wave uniform) tiles right of the wave's diagonal tile are never read
-                        const int col = 16 * t + l15;
-                        const double fc = Fp[col][cg];
-                        const double aop = (col > j0 + 3) ? -fc : 0.0;
-                        d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-                        acc = mfma16(aop, pl, acc);
-                        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-                    }
+                    const int col = 16 * t + l15;
+                    const double fc = Fp[col][cg];                 // (MF: Fw holds -L)
+                    const double aop = (col > j0 + 3) ? fc : 0.0;
+                    d4s acc = (d4s){a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+                    acc = mfma16(aop, pl, acc);
+                    a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
                 }
             } else {
 #pragma unroll
@@ -146,7 +148,7 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         const double t32 = fma(-t31, t21, fma(-t30, t20, r32)) * rs2;
         const double d3 = fma(-t32, t32, fma(-t31, t31, fma(-t30, t30, r33)));
         const double rs3 = rsqrt_nr(d3);
-        if (tid == 0 && report && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);
+        if (!MF && tid == 0 && report && j0 < nb && !(r00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) atomicOr(status, 1);      // (MF: checked once, below)
         // c. own row and the look-ahead row through T
         const double l0 = x0 * rs0;
         const double m0 = y0 * rs0;
@@ -156,16 +158,24 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         const double m2 = fma(-m1, t21, fma(-m0, t20, y2)) * rs2;
         const double l3 = fma(-l2, t32, fma(-l1, t31, fma(-l0, t30, x3))) * rs3;
         const double m3 = fma(-m2, t32, fma(-m1, t31, fma(-m0, t30, y3))) * rs3;
-        const double lf = (cg == 0) ? l0 : (cg == 1) ? l1 : (cg == 2) ? l2 : l3;
+        double lf;
+        if (MF) {       // cg = lane >> 4 is the DPP row: three row-masked moves instead of three selects on masks that live in spilled scalar registers
+            int lo = __double2loint(l0), hi = __double2hiint(l0);
+            lo = __builtin_amdgcn_update_dpp(lo, __double2loint(l1), 0xE4, 0x2, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(l1), 0xE4, 0x2, 0xF, false);
+            lo = __builtin_amdgcn_update_dpp(lo, __double2loint(l2), 0xE4, 0x4, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(l2), 0xE4, 0x4, 0xF, false);
+            lo = __builtin_amdgcn_update_dpp(lo, __double2loint(l3), 0xE4, 0x8, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(l3), 0xE4, 0x8, 0xF, false);
+            lf = __hiloint2double(hi, lo);
+        } else lf = (cg == 0) ? l0 : (cg == 1) ? l1 : (cg == 2) ? l2 : l3;
         // d. look-ahead: column cg + 4 (jq + 1) of this row, then publish it as the next round's raw block
         if (jq < 15) {
             a[jq + 1] = fma(-l3, m3, fma(-l2, m2, fma(-l1, m1, fma(-l0, m0, a[jq + 1]))));
             L.Rw[(jq + 1) & 1][i][cg] = a[jq + 1];
         }
         a[jq] = lf;                                      // final L[i][4 jq + cg] (entries above the diagonal: unused garbage)
-        Fw[i][cg] = lf;
+        Fw[i][cg] = MF ? -lf : lf;
         pl = lf; pf0 = l0; pf1 = l1; pf2 = l2; pf3 = l3;
-        if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
+        if (MF) { if (tid == 0) { rdiag[j0] = rs0; rdiag[j0 + 1] = rs1; rdiag[j0 + 2] = rs2; rdiag[j0 + 3] = rs3; } }      // (every thread has all four)
+        else if (tid < 4) rdiag[j0 + tid] = (tid == 0) ? rs0 : (tid == 1) ? rs1 : (tid == 2) ? rs2 : rs3;
         if (!MF && Vd && (tid >> 4) == 4) {         // sixteen lanes of wave 1 (off the stores above): element (k, c) of the inverse of the pivot block
             // [[1/rs0], [t10, 1/rs1], [t20, t21, 1/rs2], [t30, t31, t32, 1/rs3]]
             const int k = (tid >> 2) & 3, c = tid & 3;
@@ -180,6 +190,12 @@ __device__ __forceinline__ void chol_factor_diag(double (&a)[16], PanelLds& L, i
         }
     }
     __syncthreads();                                     // (rdiag of the last round)
+    if (MF && report && tid < nb) {
+        // a pivot that is not positive (or not a number) leaves NaN in its reciprocal square root -- v_rsq_f64 of d <= 0 is NaN or infinite and
+        // the Newton steps turn both into NaN -- so one look at rdiag replaces four compares per round
+        const double rsd = rdiag[tid];
+        if (!(rsd > 0.0 && rsd < __builtin_huge_val())) atomicOr(status, 1);
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = cg + 4 * q;
