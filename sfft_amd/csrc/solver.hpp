@@ -39,12 +39,14 @@ __device__ __forceinline__ d4s mfma16(double av, double bv, d4s acc)
 
 // 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no IEEE division / sqrt sequences on the
 // critical path of the factorisation)
+// 1 / sqrt(d): v_rsq_f64 is good to about 2^-23 (ISA guide: 2^29 ulp); ONE third-order step -- r (1 + e/2 + 3 e^2/8), e = 1 - d r^2 -- takes that
+// below the rounding error in 5 instructions (4 in sequence) where two Newton steps took 7 (6 in sequence): these sit four deep in every
+// pivot round of chol_factor_diag, whose time is its instruction count.  d <= 0 or NaN still comes out NaN (rsq: NaN or inf, e: NaN).
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
-    double r = __builtin_amdgcn_rsq(d);
-    r = r * fma(-0.5 * d, r * r, 1.5);
-    r = r * fma(-0.5 * d, r * r, 1.5);
-    return r;
+    const double r = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * r), r, 1.0);
+    return fma(r * e, fma(e, 0.375, 0.5), r);
 }
 
 // first node of a solve: a new stamp for this solve's flag hand-offs (never 0 in its upper 24 bits)
