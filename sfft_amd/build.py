@@ -50,6 +50,11 @@ def build_library(force=False, verbose=True):
             procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, pr in procs:
         if pr.wait() != 0:
+            plain = [c for c in cmd if c not in MAIN_FLAGS]
+            if plain != cmd:        # a toolchain that does not know the -mllvm option: the sources are the same without it, only slower
+                print("sfft_amd.build: retrying without %s" % " ".join(MAIN_FLAGS), flush=True)
+                subprocess.run(plain, check=True)
+                continue
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     objs = [o for _, o, _, _ in units]
     if procs or force or _stale(LIB, objs):
