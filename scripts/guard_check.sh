@@ -2,7 +2,7 @@
 # its own mapping; 2: starts flush with it; unmapped address space on both sides), in separate processes because guarded buffers
 # are never freed.  An out-of-bounds access of a kernel -- even a masked, "harmless" read -- is a GPU memory fault here.
 for g in 1 2; do
-  for k in "forward_spectrum" "golden or reference" "oracle and not large" "solver or outer_blocked or lu_redo or graph" \
+  for k in "forward_spectrum" "golden or reference" "oracle and not large" "solver or outer_blocked or lu_redo or graph or lu_gpu" \
            "generic_fft_variants or rfft2" "regularisation or (varying_scaling and not large)" "varying_scaling_large" \
            "decorrelation or pcdc or grid_convolve or matching_kernel" "error_behaviour or same_tensor or contamination" \
            "mixed_domain or baseline_size or full_size or variants_agree" "bspline or BSpline or sv_ or separate or config3" "large_shapes" "random_packet or random_bspline" "config5 or strip_matches" "nircam or sharding"; do

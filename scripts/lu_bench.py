@@ -40,3 +40,22 @@ for (w, DK, DB, cpr) in geoms:
         out[name] = (sorted(ms[1:])[len(ms[1:]) // 2], min(wall[1:]), r)
     print("n = %5d  cholesky %8.3f ms  lu %8.3f ms  ratio %5.2f   (residuals %.1e / %.1e)" % (n, out["cholesky"][0], out["lu"][0], out["lu"][0] / out["cholesky"][0], out["cholesky"][2], out["lu"][2]), flush=True)
     plan.close()
+    if os.environ.get("LU_BENCH_VENDOR", "1") != "0":
+        # yardstick, not product: what the platform's own dense solvers (torch.linalg on ROCm: rocSOLVER / hipSOLVER / MAGMA behind it) take for
+        # the SAME system on this GPU -- the reference's solver is the CUDA counterpart of the first line (cupy.linalg.solve = getrf + getrs)
+        def timed(fn, reps=6):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                y = fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts[1:])[len(ts[1:]) // 2], y
+        t_lu, x1 = timed(lambda: torch.linalg.solve(A, b))
+        t_ch, x2 = timed(lambda: torch.cholesky_solve(b[:, None], torch.linalg.cholesky_ex(A)[0])[:, 0])
+        r1 = float((A @ x1 - b).abs().max() / (A.abs().max() * x1.abs().max() * n))
+        r2 = float((A @ x2 - b).abs().max() / (A.abs().max() * x2.abs().max() * n))
+        print("           torch.linalg.solve (vendor LU) %8.3f ms   torch cholesky + cholesky_solve %8.3f ms   (residuals %.1e / %.1e)" % (t_lu, t_ch, r1, r2), flush=True)
