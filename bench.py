@@ -176,6 +176,8 @@ def compact(full):
     if "pipeline" in full:
         out["pipeline"] = _pick(full["pipeline"], ("bound", "achieved", "peak", "unit", "frac", "alg_bytes_per_pair"))
     out.update(_pick(full, ("ranks_seen", "launch", "solve_lu_ms")))
+    if isinstance(full.get("solve_lu"), dict) and full["solve_lu"].get("vendor_getrf_getrs_ms") is not None:
+        out["solve_vendor_lu_ms"] = round(full["solve_lu"]["vendor_getrf_getrs_ms"], 3)
     if "single_pair" in full:
         out["single_pair_ms"] = full["single_pair"]["ms"]
     if "prelim_apply_alone" in full:      # [alone, beside the solve] (ms): the apply pass's forward transforms
@@ -184,9 +186,9 @@ def compact(full):
         cb = full["cpu_baseline"]
         out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "seconds_per_pair", "spread_s", "protocol", "cpu_model", "physical_cores",
                                          "all_cores_s_per_pair", "full_protocol"))
-        out["cpu_baseline"]["sample"] = "one full GSS of the 4096x4096 seed-1234 pair (pair 0 of the GPU batch), no size scaling"
+        out["cpu_baseline"]["sample"] = "one full GSS of the 4096x4096 seed-1234 pair (pair 0 of the GPU batch)"
         if isinstance(out["cpu_baseline"].get("protocol"), str):        # (the full wording is in the full object)
-            out["cpu_baseline"]["protocol"] = out["cpu_baseline"]["protocol"][:96]
+            out["cpu_baseline"]["protocol"] = out["cpu_baseline"]["protocol"][:64]
         if isinstance(out["cpu_baseline"].get("full_protocol"), dict):
             out["cpu_baseline"]["full_protocol"] = _pick(out["cpu_baseline"]["full_protocol"], ("threads_8_s_per_pair", "all_cores_s_per_pair", "runs_each", "warmups_each"))
     if "post_check" in full:
@@ -207,6 +209,7 @@ def compact(full):
                      "prelim_apply_ms": [leg.get("prelim_apply_alone", {}).get("ms"), leg.get("prelim_apply_alone", {}).get("ms_beside_the_solve")],
                      "dominant": _pick(dom, ("kernel", "bound", "frac", "hbm_frac", "mfma_frac", "avg_ms", "traffic_ratio")),
                      "pipeline_frac": leg.get("pipeline", {}).get("frac"), "solve_lu_ms": leg.get("solve_lu_ms"),
+                     "solve_vendor_lu_ms": (leg.get("solve_lu") or {}).get("vendor_getrf_getrs_ms"),
                      "bitwise_equal": leg.get("post_check", {}).get("bitwise_equal"),
                      "gathered_pairs": leg.get("gathered_pairs"), "failed_pairs": leg.get("failed_pairs")}
     if legs:
@@ -484,6 +487,23 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             used_lu = plans[0].query("LAST_SOLVER") == 2
             rel = float(((fresh_d - diffs[check_ids[0]]).abs().max() / diffs[check_ids[0]].abs().max()).item())
             solve_lu = {"ms": float(np.median(lu_ms[1:])), "used_lu": bool(used_lu), "diff_max_rel_vs_cholesky": rel}
+            try:
+                # yardstick (never part of the product path): the platform's own getrf + getrs on the SAME system -- the ROCm counterpart of
+                # the reference's cupy.linalg.solve (SFFTSubtract.py:15-23) -- timed with events on the current stream
+                A_sys, b_sys, _ = plans[0].get_solver_system()
+                ven = []
+                for _ in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    torch.linalg.solve(A_sys, b_sys)
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    ven.append(e0.elapsed_time(e1))
+                solve_lu["vendor_getrf_getrs_ms"] = float(np.median(ven[1:]))
+                del A_sys, b_sys
+            except Exception as e:
+                solve_lu["vendor_getrf_getrs_ms"] = None
+                solve_lu["vendor_error"] = "%s: %s" % (type(e).__name__, e)
         except Exception as e:      # (a failing LU leg must not take the line with it; it is reported)
             solve_lu = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
