@@ -129,6 +129,33 @@ def test_spd_system_cholesky_and_lu_agree(dev):
     assert _rel(x_lu, x_np) <= 1e-11 and _rel(x_ch, x_np) <= 1e-11
 
 
+@pytest.mark.parametrize("geom", [(3, 2, 2, False), (8, 2, 2, True), (9, 3, 3, False)], ids=["n300", "n1735_dataflow", "n3620_outer_blocks"])
+def test_cholesky_path_reports_a_non_positive_pivot_wherever_it_is(dev, geom):
+    """The Cholesky path checks the pivots of a 64 x 64 diagonal block once per block (a non-positive pivot leaves NaN in the block's
+    reciprocal diagonal, solver.hpp chol_factor_diag<true>): an indefinite matrix must come back as LinAlgError from it -- first column,
+    inside a block, on block boundaries, in the last (partial) block -- and be solved by the LU; the plan works afterwards."""
+    plan = _plan(dev, *geom)
+    n = plan.query("SOLVER_N")
+    rng = np.random.default_rng(11 + n)
+    G = rng.standard_normal((n, n + 30))
+    A0 = G @ G.T / n + 0.5 * np.eye(n)
+    b = rng.standard_normal(n)
+    bt = torch.from_numpy(b).to(dev)
+    for k in sorted({0, 37, 63, 64, n // 2, 64 * ((n - 1) // 64), n - 1}):
+        A = A0.copy()
+        A[k, k] = -A[k, k] - 1.0                # indefinite: the Schur complement's pivot k is negative whatever came before
+        At = torch.from_numpy(A).to(dev)
+        with pytest.raises(np.linalg.LinAlgError):
+            plan.solve_dense(At, bt, use_lu=False)
+        assert plan.query("CHOL_STATUS") & 1, (k, plan.query("CHOL_STATUS"))
+        if k in (0, n - 1):                     # ... and the reference's solver takes it
+            x = plan.solve_dense(At, bt, use_lu=True).cpu().numpy()
+            assert np.max(np.abs(A @ x - b)) <= 1e-11 * np.max(np.abs(A)) * np.max(np.abs(x)) * n
+    x = plan.solve_dense(torch.from_numpy(A0).to(dev), bt, use_lu=False).cpu().numpy()
+    assert plan.query("CHOL_STATUS") == 0
+    assert np.max(np.abs(A0 @ x - b)) <= 1e-12 * np.max(np.abs(A0)) * np.max(np.abs(x)) * n
+
+
 @pytest.mark.parametrize("geom", [(12, 3, 3, True), (16, 3, 3, False), (20, 3, 3, False)], ids=["n6251", "n10900", "n16820"])
 def test_large_systems_by_residual(dev, geom):
     """n = 6251 (config 5's system), 10 900 and 16 820 unknowns: panels of 8 / 4 / 2 / 1 column sub-panels with 8 .. 64 rows per thread.
