@@ -572,11 +572,6 @@ __global__ void copy_spectrum_scaled(const cplx* __restrict__ src, cplx* __restr
     const int m = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
     if (m < Nh) { const cplx v = src[sl.at(l, m)]; dst[dl.at(l, m)] = make_double2(v.x * f, v.y * f); }
 }
-__global__ void scale_real(double* __restrict__ a, double f, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) a[i] *= f;
-}
 // acc[i] += coeff * |a[i]|^2 * (b ? |b[i]|^2 : 1)
 __global__ void spec_abs2_acc(const cplx* __restrict__ a, const cplx* __restrict__ b, double coeff, double* __restrict__ acc, size_t n)
 {

@@ -2778,10 +2778,11 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
         SFFT_LAUNCH(zero_f64, dim3((p->NEQ + 255) / 256), dim3(256), 0, s, p->d_zsol, (size_t)p->NEQ);
     }
     cplx* FD = p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp;
+    // reuse the inverse path of the subtraction: with J = 0 and b = 0 it returns -IDFT2(FD); the caller's factor (and that sign) rides on
+    // the copy into the panel layout -- the transform is linear -- instead of a pass of its own over the image afterwards
     SFFT_LAUNCH(copy_spectrum_scaled, dim3((p->Nh + 255) / 256, p->N0), dim3(256), 0, s, (const cplx*)d_spec, FD, p->N0, p->Nh,
-                       rowmajor_layout(p->Nh), p->lay, 1.0);
+                       rowmajor_layout(p->Nh), p->lay, -scale);
     LAUNCH_CHECK();
-    // reuse the inverse path of the subtraction: with J = 0 and b = 0 it returns -IDFT2(FD)
     launch_cols(p, FD, 1, 1, s);
     if (p->ax1.big) {
         const int npr = (p->N0 + 1) / 2;
@@ -2792,11 +2793,15 @@ extern "C" int sfft_ifft2_c2r(sfft_plan* p, const double* d_spec, double* d_real
     } else if (fast_axis(p->ax1) && !p->no_fast_fft)
         SFFT_LAUNCH(rows_c2r_diff_4096<4>, dim3((p->N0 + 1) / 2), dim3(256), F4K_LDS * sizeof(cplx), s, FD, p->d_zero,
                            p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->lay, p->ax1.tw);
+    else if (p->rows_r24 == 16 && p->inv_r24 != 0)         // (nothing else is in flight here: the register-resident pass wins alone at both sizes)
+        SFFT_LAUNCH((rows_c2r_diff_r24<16, 4>), dim3((p->N0 + 1) / 2), dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s, FD, p->d_zero,
+                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->lay, p->ax1.tw);
+    else if (p->rows_r24 == 24 && p->inv_r24 != 0)
+        SFFT_LAUNCH((rows_c2r_diff_r24<24, 4>), dim3((p->N0 + 1) / 2), dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s, FD, p->d_zero,
+                           p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->lay, p->ax1.tw);
     else
         SFFT_LAUNCH(rows_c2r_diff<4>, dim3((p->N0 + 1) / 2), dim3(p->nt_rows), p->lds_rows, s, FD, p->d_zero,
                            p->d_zsol + p->Fijab, p->bk, d_real, p->N0, p->N1, p->Nh, p->Nhp, p->lay, axis_dev(p->ax1));
-    const size_t n = (size_t)p->N0 * p->N1;
-    SFFT_LAUNCH(scale_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_real, -scale, n);
     LAUNCH_CHECK();
     return SFFT_OK;
 }

@@ -1025,7 +1025,7 @@ def test_varying_scaling_large_shape_properties(dev):
 # ------------------------------------------------------------------------------------------------
 # (f) FFT utilities / noise decorrelation
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(64, 64), (276, 300), (4096, 128), (100, 4100), (6144, 48), (72, 9216)])
+@pytest.mark.parametrize("shape", [(64, 64), (276, 300), (4096, 128), (100, 4100), (6144, 48), (72, 9216), (40, 6144), (24, 4096), (16, 9232)])
 def test_rfft2_irfft2_roundtrip_and_numpy(dev, shape):
     from sfft_amd.fftkit import get_fft_plan
     rng = np.random.default_rng(shape[0])
@@ -1036,6 +1036,11 @@ def test_rfft2_irfft2_roundtrip_and_numpy(dev, shape):
     assert np.max(np.abs(F.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
     back = plan.irfft2(F).cpu().numpy()
     assert np.max(np.abs(back - x)) <= 1e-12 * np.max(np.abs(x))
+    # the caller's factor rides on the spectrum copy (no pass of its own): unnormalised and an arbitrary one
+    back1 = plan.irfft2(F, scale=1.0).cpu().numpy()
+    assert np.max(np.abs(back1 - x * (shape[0] * shape[1]))) <= 1e-12 * np.max(np.abs(x)) * shape[0] * shape[1]
+    back2 = plan.irfft2(F, scale=-2.5).cpu().numpy()
+    assert np.max(np.abs(back2 + 2.5 * x * (shape[0] * shape[1]))) <= 1e-12 * np.max(np.abs(x)) * 2.5 * shape[0] * shape[1]
 
 
 def test_decorrelation_kernel_matches_reference(dev):
