@@ -27,6 +27,14 @@ struct SpecLayout {
 #ifndef SFFT_NT
 #define SFFT_NT 0
 #endif
+// SFFT_CACHE_RESIDENT (build flag of scripts/cache_resident.sh, never of the product library): every workgroup of the 4096-point passes
+// touches the memory of the same n rows / column tiles -- the same instructions, LDS exchanges and L1 requests with next to no HBM traffic;
+// results are wrong by construction.  What remains of a pass is its on-chip time.
+#ifdef SFFT_CACHE_RESIDENT
+#define SFFT_CR(i, n) ((i) & ((n) - 1))
+#else
+#define SFFT_CR(i, n) (i)
+#endif
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_stream(cplx* p, cplx z)
 {

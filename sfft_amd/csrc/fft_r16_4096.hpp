@@ -49,6 +49,17 @@ __device__ __forceinline__ void fft4096_core(cplx (&u)[16], int j, cplx* lds, co
     dft16(u);
 }
 
+// 2 x 2 exchange between the lane pairs of a quad (DPP quad_perm): see cols_fwd_weighted_4096_q and the pair-major stores of rows_r2c_4096
+__device__ __forceinline__ double dpp_swap2(double x)          // the value held by lane ^ 2
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cplx dpp_swap2(cplx v) { return make_double2(dpp_swap2(v.x), dpp_swap2(v.y)); }
+__device__ __forceinline__ cplx csel(bool p, cplx a, cplx b) { return make_double2(p ? a.x : b.x, p ? a.y : b.y); }
+
 // rows, real -> half complex (N1 = 4096), two image rows per transform, spatial factors fused.  Planes [first, first +
 // count) of a launch group share their source image: the workgroup reads its two rows once and produces every plane.
 #define ROWMOM_FUSED_MAX 8                           // most moments per row the row pass computes itself (polynomial bases: DK + DB + 1 <= 7)
@@ -62,8 +73,10 @@ struct RowGroups {
 
 // Workgroup b takes row pair (b % 8) * pairs_per_xcd + b / 8: consecutive row pairs run on one XCD, so that with a panel
 // layout the pieces of a 128-byte line written by neighbouring row pairs merge in that XCD's L2.
+// pm (pair-major lines, the stage planes of cols_fwd_weighted_4096_z): the 128-byte line of rows 2p, 2p + 1 of a 4-column panel is stored as
+// [column pair h][row parity][column c] instead of [row parity][4 columns]; this kernel writes whole lines either way.
 __global__ void __launch_bounds__(256, 2) rows_r2c_4096(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp, SpecLayout lay,
-                                                     const cplx* __restrict__ tw, double scale, int pairs_per_xcd)
+                                                     const cplx* __restrict__ tw, double scale, int pairs_per_xcd, int pm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* lds = reinterpret_cast<cplx*>(smem_raw);
@@ -74,9 +87,10 @@ __global__ void __launch_bounds__(256, 2) rows_r2c_4096(RowsArgs a, RowGroups gr
     if ((int)(blockIdx.x >> 3) >= pairs_per_xcd || 2 * rp >= N0) return;
     const int l0 = 2 * rp, l1 = l0 + 1;
     const bool has1 = l1 < N0;
+    const int m0 = SFFT_CR(l0, 32), m1 = SFFT_CR(l1, 32);            // (the rows whose memory is touched: l0, l1 in the product)
     const double* __restrict__ src = a.src[pfirst];
-    const double* r0p = src + (size_t)l0 * N1;
-    const double* r1p = src + (size_t)(has1 ? l1 : l0) * N1;
+    const double* r0p = src + (size_t)m0 * N1;
+    const double* r1p = src + (size_t)(has1 ? m1 : m0) * N1;
     // (selects on wave-uniform conditions inside these unrolled loops become one scalar branch per element: the second row
     //  is read unconditionally -- r1p falls back to row l0 -- and scaled by 0, and missing weights point at a table of ones)
     const double h1 = has1 ? 1.0 : 0.0;
@@ -140,8 +154,27 @@ __global__ void __launch_bounds__(256, 2) rows_r2c_4096(RowsArgs a, RowGroups gr
 #pragma unroll
         for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)];
         __syncthreads();
-        cplx* o0 = out + (size_t)plane * N0 * Nhp + (size_t)l0 * lay.rstride;
-        cplx* o1 = out + (size_t)plane * N0 * Nhp + (size_t)l1 * lay.rstride;
+        cplx* o0 = out + (size_t)plane * N0 * Nhp + (pm ? (size_t)(m0 >> 1) * 8 : (size_t)m0 * lay.rstride);
+        cplx* o1 = out + (size_t)plane * N0 * Nhp + (size_t)m1 * lay.rstride;
+        if (pm) {       // (launch uniform) pair-major lines: a lane quad stores the 64-byte sector [row l0: c, c + 1][row l1: c, c + 1] of column pair 0, then of pair 1
+            const bool even = (j & 2) == 0;
+            cplx* ob = o0 + (j & 3);
+#pragma unroll
+            for (int sx = 0; sx <= 8; ++sx) {
+                const int m = j + 256 * sx;
+                if (sx < 8 || j < 4) {              // (sx = 8: the quad of column N1 / 2; its other three columns are the panel's padding)
+                    const cplx z = u[R16_OUT(sx)];
+                    const cplx zp = lds[(N1 - m) & (N1 - 1)];
+                    const cplx zc = make_double2(zp.x, -zp.y);
+                    const cplx X0 = make_double2(hs * (z.x + zc.x), hs * (z.y + zc.y)), X1 = make_double2(hs * (z.y - zc.y), -hs * (z.x - zc.x));
+                    const cplx got = dpp_swap2(csel(even, X1, X0));
+                    cplx* oq = ob + (size_t)(m >> 2) * (size_t)lay.pstride;
+                    st_stream(oq, csel(even, X0, got));
+                    st_stream(oq + 4, csel(even, got, X1));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int sx = 0; sx <= 8; ++sx) {
             const int m = j + 256 * sx;
@@ -232,16 +265,6 @@ __global__ void __launch_bounds__(512) cols_fwd_weighted_4096(const cplx* __rest
 // 2p and 2p + 1 in two instructions -- and a 2 x 2 exchange between lane pairs (DPP quad_perm) turns that into the
 // (row, column pair) ownership of the transform: lane pair (4p, 4p + 1) owns row 2p, pair (4p + 2, 4p + 3) row 2p + 1, first of
 // columns (0, 1), then of columns (2, 3).  The two column pairs are transformed one after the other through the same LDS.
-__device__ __forceinline__ double dpp_swap2(double x)          // the value held by lane ^ 2
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ cplx dpp_swap2(cplx v) { return make_double2(dpp_swap2(v.x), dpp_swap2(v.y)); }
-__device__ __forceinline__ cplx csel(bool p, cplx a, cplx b) { return make_double2(p ? a.x : b.x, p ? a.y : b.y); }
-
 __global__ void __launch_bounds__(512) cols_fwd_weighted_4096_q(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int Nhp,
                                                                 SpecLayout lay, const cplx* __restrict__ tw, int nquads)
 {
@@ -256,7 +279,7 @@ __global__ void __launch_bounds__(512) cols_fwd_weighted_4096_q(const cplx* __re
     if ((int)(blockIdx.x >> 3) >= per || logical >= total) return;
     const int cq = logical / g.nout, o = logical - cq * g.nout;
     // (the panel's padding columns beyond Nh exist in memory: they are transformed and stored like the others, nobody reads them)
-    const size_t plane_sz = (size_t)N0 * Nhp, cofs = (size_t)cq * (size_t)lay.pstride + q4;
+    const size_t plane_sz = (size_t)N0 * Nhp, cofs = (size_t)SFFT_CR(cq, 8) * (size_t)lay.pstride + q4;
     const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * plane_sz + cofs;
     const double* __restrict__ w = g.wx[o];
     const int rowA = 2 * (j >> 1);
@@ -294,6 +317,99 @@ __global__ void __launch_bounds__(512) cols_fwd_weighted_4096_q(const cplx* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward column pass, round 6: TWO workgroups per CU.  Where cols_fwd_weighted_4096_q's time goes (scripts/micro/cols_q_ablate.hip, one launch of
+// config 2): the kernel 0.40 ms; a pure mover with its loads and stores 0.27 - 0.30; its transforms alone (tile from L2, nothing stored) 0.26 -- one
+// 512-thread workgroup holds a CU's whole register file (4 columns x 4096 points = 256 KB) and both 69.6 KB exchange buffers, so load, transform
+// and store of a tile run one after the other and nothing overlaps them.  Here a 512-thread workgroup (lane = 2 j + c, 16 points per thread,
+// <= 128 registers) transforms ONE column pair; real and imaginary parts go through the LDS one after the other (2 x 34 KB per workgroup), so two
+// workgroups -- 16 waves, two tiles in different phases -- fit a CU.  What makes a column pair affordable is the layout on both sides:
+//   in   the stage planes keep their 4-column panels, with every 128-byte line (rows 2p, 2p + 1 x columns 0..3) stored pair-major,
+//        [pair h][row parity][column c]: a lane quad reads one whole 64-byte sector; the sibling pair's workgroup (next in the grid, same XCD)
+//        takes the other half of the line out of the L2.  The row pass writes whole lines either way (rows_r2c_4096, pm = 1).
+//   out  the spectra go out in 2-column panels [Nhp / 2][N0][2]: a wave stores 1 KB contiguous.  The Omega / Theta launches read a 16-column
+//        tile of 4 rows per step -- 8 full lines in either panel width (measured + 5 % for them, - 20 % for this pass).
+// Measured in the micro-benchmark: 0.305 - 0.34 ms against 0.40 (transforms alone 0.16 against 0.26).
+// Region c of the LDS starts at c * Z4K_LDS doubles and holds element x at pad16(x ^ 8 c): every 8-byte access is conflict free
+// (scripts/lds_conflicts.py).
+// ------------------------------------------------------------------------------------------------
+#define Z4K_LDS 4368
+__device__ __forceinline__ void fft4096_core_split2(cplx (&u)[16], int j, double* lds, const cplx* __restrict__ tw, int sw)     // sw = 0 or 8
+{
+    dft16(u);
+    double* wA = lds + 17 * j + sw;                  // slot sx ^ sw
+    double* wB = lds + 17 * j - sw;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) ((sx & 8) ? wB : wA)[sx] = u[R16_OUT(sx)].x;
+    __syncthreads();
+    const double* rd = lds + pad16(j ^ sw);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r].x = rd[272 * r];              // (the real parts are dead once written: overwritten in place)
+    __syncthreads();
+    // the imaginary parts still sit in dft16's output order, u[R16_OUT(sx)].y, untouched by the reads above
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) ((sx & 8) ? wB : wA)[sx] = u[R16_OUT(sx)].y;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r].y = rd[272 * r];
+    __syncthreads();
+    const int k = j & 15;
+    twiddle16(u, tw, 16 * k);
+    dft16(u);
+    double* w2 = lds + pad16((j - k) * 16 + (k ^ sw));
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) w2[17 * sx] = u[R16_OUT(sx)].x;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r].x = rd[272 * r];
+    __syncthreads();
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) w2[17 * sx] = u[R16_OUT(sx)].y;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r].y = rd[272 * r];
+    twiddle16(u, tw, j);
+    dft16(u);
+}
+
+// pstride4: elements between the 4-column panels of a stage plane.  Workgroup order: output fastest, then the two pairs of a panel --
+// the 2 * nout workgroups that touch one stage panel run back to back on one XCD.
+__global__ void __launch_bounds__(512, 4) cols_fwd_weighted_4096_z(const cplx* __restrict__ stage, cplx* __restrict__ out, ColOuts g, int Nhp,
+                                                                   long long pstride4, const cplx* __restrict__ tw, int npairs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    const int N0 = 4096;
+    const int tid = threadIdx.x, c = tid & 1, j = tid >> 1;
+    const int total = npairs * g.nout;
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || logical >= total) return;
+    const int cp = logical / g.nout, o = logical - cp * g.nout;
+    const int cpm = SFFT_CR(cp, 16);                 // (the pair whose memory is touched: cp in the product)
+    const size_t plane_sz = (size_t)N0 * Nhp;
+    // element (row l, pair h of panel P, column c) of a stage plane: P * pstride4 + (l >> 1) * 8 + h * 4 + (l & 1) * 2 + c;  row j + 256 r of
+    // lane 2 j + c: (tid >> 2) * 8 + (tid & 3) + 1024 r
+    const cplx* __restrict__ src = stage + (size_t)g.stage_plane[o] * plane_sz + (size_t)(cpm >> 1) * (size_t)pstride4 + (size_t)((cpm & 1) * 4)
+                                   + (size_t)((tid >> 2) * 8 + (tid & 3));
+    const double* __restrict__ w = g.wx[o];
+    cplx u[16];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {            // two batches of 8 rows: bounds the registers of the load phase
+        double f[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { u[8 * hb + r] = ld_stream(src + (size_t)(1024 * (8 * hb + r))); f[r] = w[j + 256 * (8 * hb + r)]; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { u[8 * hb + r].x *= f[r]; u[8 * hb + r].y *= f[r]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    fft4096_core_split2(u, j, lds + c * Z4K_LDS, tw, 8 * c);
+    // 2-column panels: element (row l, column c of pair cp) at cp * N0 * 2 + l * 2 + c;  row j + 256 sx of lane 2 j + c: tid + 512 sx
+    cplx* __restrict__ dst = out + (size_t)g.out_plane[o] * plane_sz + (size_t)cpm * (size_t)(N0 * 2) + tid;
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) st_stream(dst + 512 * sx, u[R16_OUT(sx)]);
+}
+
 // rows, half complex -> real (N1 = 4096), two rows per transform, DIFF epilogue (see rows_c2r_diff)
 template <int NQ>
 __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict__ FD, const double* __restrict__ J,
@@ -306,8 +422,9 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
     const int j = threadIdx.x;
     const int l0 = 2 * blockIdx.x, l1 = l0 + 1;
     const bool has1 = l1 < N0;
-    const cplx* f0 = FD + (size_t)l0 * lay.rstride;
-    const cplx* f1 = FD + (size_t)(has1 ? l1 : l0) * lay.rstride;
+    const int m0 = SFFT_CR(l0, 32), m1 = SFFT_CR(l1, 32);            // (the rows whose memory is touched: l0, l1 in the product)
+    const cplx* f0 = FD + (size_t)m0 * lay.rstride;
+    const cplx* f1 = FD + (size_t)(has1 ? m1 : m0) * lay.rstride;
     cplx u[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -325,10 +442,10 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
     double c0[NQ], c1[NQ];
     bkg_row_coeffs<NQ>(bk, bpq, l0, N0, c0);
     bkg_row_coeffs<NQ>(bk, bpq, has1 ? l1 : l0, N0, c1);
-    const double* j0 = J + (size_t)l0 * N1;
-    const double* j1 = J + (size_t)(has1 ? l1 : l0) * N1;
-    double* d0 = DIFF + (size_t)l0 * N1;
-    double* d1 = DIFF + (size_t)(has1 ? l1 : l0) * N1;
+    const double* j0 = J + (size_t)m0 * N1;
+    const double* j1 = J + (size_t)(has1 ? m1 : m0) * N1;
+    double* d0 = DIFF + (size_t)m0 * N1;
+    double* d1 = DIFF + (size_t)(has1 ? m1 : m0) * N1;
     // The epilogue in batches: all J and background-table loads of a batch first, then its arithmetic and stores.  Written
     // element by element, every table load waits for the previous DIFF store (the table pointer may alias DIFF for all the
     // compiler knows): 32 dependent round trips per thread, 136 us for the kernel instead of 85.

@@ -250,6 +250,9 @@ struct sfft_plan {
     int g1_dit = 1;                     // env SFFT_G1_DIT=0: grouped Omega launch without the radix-2 decimation step along the rows
     int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
     int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
+    int colz = 1;                       // solve pass of the 4096^2 path: cols_fwd_weighted_4096_z (two workgroups per CU; pair-major stage lines in, 2-column
+                                        // panels out).  env SFFT_COLZ=0: cols_fwd_weighted_4096_q.  Set to 0 by the plan when its conditions do not hold.
+    SpecLayout lay_spec;                // layout of the solve pass's spectra in d_spec (= lay unless colz)
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 3;                    // Omega passes on the matrix cores: 3 = greek_g1_mfma4g (pass groups that share plane loads, v_mfma_f64_4x4x4_4b_f64),
                                         // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 0: vector kernel (A/B testing)
@@ -681,6 +684,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     if (const char* ev = getenv("SFFT_NO_WX_SUPPORT")) p->no_wx_support = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
     if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
+    if (const char* ev = getenv("SFFT_COLZ")) p->colz = atoi(ev);
     if (getenv("SFFT_NO_GRAPH")) p->use_graph = 0;
     if (getenv("SFFT_TEST_FAIL_CHOL")) p->test_fail_chol = 1;
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
@@ -792,6 +796,9 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         // polynomial plans (DK >= 0: made by sfft_plan_create, REF_ij term order) with a stamp of at most 25 x 25 take the
         // mixed-domain apply, whatever the image shape: it needs the row pass only, and no transform along axis 0 at all
         p->staged_solve = both_fast && !p->no_staged;
+        // (the pair-per-workgroup column pass: the staged 4096^2 solve pass on 4-column panels; its 2-column spectra are read by the Greek launches only --
+        //  plans whose apply pass reads d_spec keep the four-column kernel, see below)
+        if (!(both_fast && !p->no_staged && p->colq && p->lay.mask == 3 && p->lay.rstride == 4)) p->colz = 0;
         if (DK >= 0 && DK <= 3 && p->mode != 3 && KerHW >= 1 && KerHW <= 12 && !getenv("SFFT_NO_VCONV")) {
             p->use_vconv = 1;
             p->vncf = DK + 1;
@@ -828,6 +835,11 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             }
         }
     }
+    // the solve pass's spectra: 2-column panels behind cols_fwd_weighted_4096_z, the plan's layout otherwise.  Without the mixed-domain apply
+    // the apply pass transforms into (and Construct_FDIFF reads) d_spec in the plan's layout, and a call with I as its own mask reuses the solve pass's spectra.
+    if (!p->use_vconv) p->colz = 0;
+    p->lay_spec = p->lay;
+    if (p->colz) { p->lay_spec.shift = 1; p->lay_spec.mask = 1; p->lay_spec.rstride = 2; p->lay_spec.pstride = (long long)N0 * 2; }
     // launch geometry of the on-chip FFT kernels (axes that need the four-step path use strided_dft instead)
     if (!p->ax1.big) {
         p->nt_rows = fft_threads(p->ax1.M);
@@ -863,6 +875,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_c2c_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096_q, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096_z, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_4096, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_4096<SFFT_MAX_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1764,7 +1777,7 @@ static int forward_planes(sfft_plan* p, const RowsArgs& ra, int nplanes, cplx* d
         }
         const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
         SFFT_LAUNCH(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, rw, grp, dst,
-                           p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
+                           p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per, 0);
     }
     else if (p->rows_r24) {
         RowsArgs rw = ra;
@@ -1888,6 +1901,8 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
         return SFFT_OK;
     }
     const int rp_per = ((p->N0 + 1) / 2 + 7) / 8;
+    // the solve pass (its spectra go to the Greek launches, which read d_spec in lay_spec): one column pair per workgroup, pair-major stage lines
+    const bool zpath = p->colz && d_J != nullptr && dst == p->d_spec;
     if (p->timing && st_rows >= 0) { hipEventRecord(p->ev[st_rows][0], s); tl_klog = &p->stage_kernels[st_rows]; }
     for (int k0 = 0; k0 < nst; k0 += SFFT_MAX_PLANES) {
         const int n = std::min(SFFT_MAX_PLANES, nst - k0);
@@ -1907,7 +1922,7 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                 else if (src == d_I) { grp.mom_out[gI] = p->d_rowmomI; grp.mom_nq[gI] = p->gam_nmu; }
             }
         SFFT_LAUNCH(rows_r2c_4096, dim3(8 * rp_per, grp.ngroups), dim3(256), F4K_LDS * sizeof(cplx), s, ra, grp,
-                           p->d_stage + (size_t)k0 * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per);
+                           p->d_stage + (size_t)k0 * plane_sz, p->N0, p->Nhp, p->lay, p->ax1.tw, p->scale, rp_per, zpath ? 1 : 0);
     }
     LAUNCH_CHECK();
     if (p->want_mom_event && p->rowmom_fused && d_J) { HIPCHK(hipEventRecord(p->ev_mom, s)); p->mom_event_recorded = true; }     // the row moments exist from here on
@@ -1922,6 +1937,12 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             ++k;
         }
         if (g.nout == 0) return set_err(SFFT_ERR_INVALID_ARG, "too many planes share one column factor for the weighted column pass");
+        if (zpath) {
+            const int total = npairs * g.nout;
+            SFFT_LAUNCH(cols_fwd_weighted_4096_z, dim3(8 * ((total + 7) / 8)), dim3(512), 2 * Z4K_LDS * sizeof(double), s, p->d_stage, dst, g,
+                               p->Nhp, p->lay.pstride, p->ax0.tw, npairs);
+            continue;
+        }
         if (p->colq && p->lay.rstride == 4 && p->lay.mask == 3) {      // four columns per workgroup: whole 64-byte pieces per lane quad
             const int nquads = (p->Nh + 3) / 4;
             const int total = nquads * g.nout;
@@ -1981,9 +2002,9 @@ static void launch_g1(sfft_plan* p, int pass0, int npass, int h, hipStream_t s)
     const int rpc2 = (p->N0 / 2 + p->S - 1) / p->S;
     for (int rb = 0; rb < h || rb == 0; rb += HBW) {
         if (dit) SFFT_LAUNCH((greek_g1<HBW, U, true>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
-                                    p->Nhp, p->lay, rpc2, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+                                    p->Nhp, p->lay_spec, rpc2, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
         else SFFT_LAUNCH((greek_g1<HBW, U>), g, dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0, p->Nh,
-                                p->Nhp, p->lay, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+                                p->Nhp, p->lay_spec, p->rows_per_chunk, rb, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
     }
 }
 
@@ -2034,16 +2055,16 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             const int totl = ncb16 * p->S * ngl;
             if (dit && lag0 > 0 && h - lag0 <= 8)
                 SFFT_LAUNCH((greek_g1_mfma4g<false, true, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
+                                   p->N0, p->Nh, p->Nhp, p->lay_spec, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else if (dit)
                 SFFT_LAUNCH((greek_g1_mfma4g<false, true>), dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
+                                   p->N0, p->Nh, p->Nhp, p->lay_spec, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else if (whole)
                 SFFT_LAUNCH(greek_g1_mfma4g<false>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
+                                   p->N0, p->Nh, p->Nhp, p->lay_spec, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             else
                 SFFT_LAUNCH(greek_g1_mfma4g<true>, dim3(8 * ((totl + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, p->d_groups, ngl, p->d_gp,
-                                   p->N0, p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
+                                   p->N0, p->Nh, p->Nhp, p->lay_spec, p->rows_per_chunk, p->d_w0tab, p->hm, ncb16, p->S, p->d_g1trace, lag0);
             }
             if (p->d_g1trace) {     // development aid (SFFT_G1_TRACE=file): dump the wave stamps of this launch
                 hipStreamSynchronize(s);
@@ -2053,7 +2074,7 @@ static int greek_g1_group(sfft_plan* p, int pass0, int npass, int h, hipStream_t
             }
         } else
             SFFT_LAUNCH((greek_g1_mfma4<2>), dim3(8 * ((total + 7) / 8)), dim3(64), 0, s, p->d_spec, p->d_passes, pass0, p->d_gp, p->N0,
-                               p->Nh, p->Nhp, p->lay, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
+                               p->Nh, p->Nhp, p->lay_spec, p->rows_per_chunk, p->d_w0tab, p->hm, p->d_Xp, ncb, p->S, npass);
         LAUNCH_CHECK();
         return SFFT_OK;
     }
@@ -2408,7 +2429,7 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
         }
         if (p->n_row0 > 0) {
             SFFT_LAUNCH(greek_g1_row0, dim3((p->Nh + 255) / 256, p->n_row0), dim3(256), 0, s, p->d_spec, p->d_passes,
-                               p->n_omg_rec + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->lay, p->S);
+                               p->n_omg_rec + p->n_dense_w, p->d_gp, p->N0, p->Nh, p->Nhp, p->lay_spec, p->S);
             LAUNCH_CHECK();
         }
     }
@@ -2647,8 +2668,10 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
         // SFFTSubtract.py:849): the spectra of the solve pass are the spectra of the apply pass
         if ((rc = solve_impl(p, d_mI, d_mJ, d_solution, s, true))) return rc;
         // (mixed-domain apply: a staged solve pass left the stage planes of I first in d_stage; otherwise they are made now)
-        if (p->use_vconv && !p->staged_solve && (rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
-        const cplx* FIa = p->use_vconv ? (p->staged_solve ? p->d_stage : p->d_stage_a) : p->d_spec;
+        // (colz: those stage planes have pair-major lines, which only the column pass reads)
+        const bool reuse_stage = p->staged_solve && !p->colz;
+        if (p->use_vconv && !reuse_stage && (rc = apply_prelim(p, d_I, p->d_spec, s))) return rc;
+        const cplx* FIa = p->use_vconv ? (reuse_stage ? p->d_stage : p->d_stage_a) : p->d_spec;
         if ((rc = apply_finish(p, FIa, p->d_spec + (size_t)p->Fij * p->N0 * p->Nhp, d_I, d_J, d_solution, d_diff, s))) return rc;
         HIPCHK(hipStreamSynchronize(s));
         if ((rc = solve_check(p, d_solution, s, &redone))) return rc;

@@ -1176,10 +1176,12 @@ def test_mixed_domain_apply_equals_fourier_apply_4096(dev, w, DK, DB, cpr):
             os.environ["SFFT_NO_VCONV"] = "1"
         else:
             os.environ.pop("SFFT_NO_VCONV", None)
+        os.environ["SFFT_COLZ"] = "0"       # (the pair-per-workgroup column pass belongs to mixed-domain plans only: here both plans take the four-column kernel)
         try:
             plan = Plan(N, N, w, DK, DB, cpr, device=dev.index)
         finally:
             os.environ.pop("SFFT_NO_VCONV", None)
+            os.environ.pop("SFFT_COLZ", None)
         rng = np.random.default_rng(5)
         sol = rng.normal(size=plan.NEQ)
         sol[:plan.Fijab] *= float(N) * float(N) * 0.01
@@ -1245,6 +1247,47 @@ def _subtract_with_env(dev, env, shape, w, DK, DB, pair):
     out = (sol.cpu().numpy(), diff.cpu().numpy(), LH.cpu().numpy(), rhs.cpu().numpy())
     plan.close()
     return out
+
+
+@pytest.mark.parametrize("w,DK,DB,same", [(8, 2, 2, False), (4, 1, 0, False), (8, 2, 2, True)])
+def test_pair_column_pass_equals_quad_column_pass_4096(dev, w, DK, DB, same):
+    """Round 6: the solve pass of the 4096^2 path transforms one column PAIR per workgroup (cols_fwd_weighted_4096_z: two workgroups per CU,
+    stage planes with pair-major lines, spectra in 2-column panels read by the Greek launches) -- against the four-column kernel
+    (SFFT_COLZ=0, the round-1..5 path, itself held to the oracle by test_config2_full_size_matches_oracle): the same linear system block by
+    block to 1e-12, the same difference image.  `same`: I passed as its own mask (the apply pass then must NOT reuse the solve pass's
+    pair-major stage planes).  A self-comparison of two HIP paths: a regression guard, not parity evidence."""
+    from sfft_amd.utils.synthetic import make_pair
+    shape = (4096, 4096)
+    pair = make_pair(*shape, seed=77 + w, mask=True)
+    if same:
+        pair = dict(pair); pair["mREF"] = pair["REF"]
+    def run(env):
+        from sfft_amd.plan import Plan
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            plan = Plan(shape[0], shape[1], w, DK, DB, True, device=dev.index)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        I, J, mJ = _to(dev, pair["REF"]), _to(dev, pair["SCI"]), _to(dev, pair["mSCI"])
+        mI = I if same else _to(dev, pair["mREF"])
+        plan.set_timing(True)
+        sol, diff = plan.subtract(I, J, mI, mJ)
+        LH, rhs = plan.get_system()
+        kernels = plan.stage_kernels()["fwd_cols"]
+        out = (sol.cpu().numpy(), diff.cpu().numpy(), LH.cpu().numpy(), rhs.cpu().numpy(), kernels)
+        plan.close()
+        return out
+    a = run({})
+    b = run({"SFFT_COLZ": "0"})
+    assert a[4] == ["cols_fwd_weighted_4096_z"] and b[4] == ["cols_fwd_weighted_4096_q"], (a[4], b[4])
+    nk = (DK + 1) * (DK + 2) // 2 * (2 * w + 1) ** 2
+    for blk in (np.s_[:nk, :nk], np.s_[:nk, nk:], np.s_[nk:, nk:]):
+        assert np.abs(a[2][blk] - b[2][blk]).max() <= 1e-12 * np.abs(b[2][blk]).max()
+    for blk in (np.s_[:nk], np.s_[nk:]):
+        assert np.abs(a[3][blk] - b[3][blk]).max() <= 1e-12 * np.abs(b[3][blk]).max()
+    assert rms(a[1] - b[1]) <= 1e-8 * rms(b[1])
 
 
 def test_outer_blocked_cholesky_equals_plain_blocked(dev):
