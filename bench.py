@@ -195,7 +195,10 @@ def compact(full):
         out["post_check"] = _pick(full["post_check"], ("pairs_checked", "bitwise_equal", "max_rel_diff"))
     if "host_arrays" in full:
         out["host_arrays"] = _pick(full["host_arrays"], ("value", "pcie_GBs"))
-    out.update(_pick(full, ("gathered_pairs", "failed_pairs")))
+    out.update(_pick(full, ("gathered_pairs", "failed_pairs", "solves_timed", "lu_fallback_pairs", "chol_stall_events")))
+    if "per_rank" in full:      # one short row per rank: an imbalanced or mis-placed rank must be visible in the line the driver keeps
+        out["per_rank"] = [[r["rank"], r["device"], r["pairs"], round(r["pairs_per_s"], 1), r["numa_node"], r["cpus_allowed"]] for r in full["per_rank"]]
+        out["per_rank_keys"] = "rank,device,pairs,pairs_per_s,numa_node,cpus_allowed"
     legs = {}
     for cid, leg in (full.get("other_configs") or {}).items():
         if not isinstance(leg, dict):
@@ -204,14 +207,16 @@ def compact(full):
             legs[cid] = {"error": str(leg["error"])[:160]}
             continue
         dom = leg.get("roofline", {})
-        legs[cid] = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"), "timed_region_s": leg.get("config", {}).get("timed_region_s"),
+        legs[cid] = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"),
                      "single_pair_ms": leg.get("single_pair", {}).get("ms"), "pairs_per_step": leg.get("config", {}).get("pairs_per_step"),
                      "prelim_apply_ms": [leg.get("prelim_apply_alone", {}).get("ms"), leg.get("prelim_apply_alone", {}).get("ms_beside_the_solve")],
-                     "dominant": _pick(dom, ("kernel", "bound", "frac", "hbm_frac", "mfma_frac", "avg_ms", "traffic_ratio")),
+                     "dominant": _pick(dom, ("kernel", "bound", "frac", "avg_ms", "traffic_ratio")),
                      "pipeline_frac": leg.get("pipeline", {}).get("frac"), "solve_lu_ms": leg.get("solve_lu_ms"),
                      "solve_vendor_lu_ms": (leg.get("solve_lu") or {}).get("vendor_getrf_getrs_ms"),
                      "bitwise_equal": leg.get("post_check", {}).get("bitwise_equal"),
                      "gathered_pairs": leg.get("gathered_pairs"), "failed_pairs": leg.get("failed_pairs")}
+        if leg.get("lu_fallback_pairs") is not None:        # [LU fallbacks, Cholesky hand-off stalls] of the leg's timed region
+            legs[cid]["lu_stall"] = [leg.get("lu_fallback_pairs"), leg.get("chol_stall_events")]
     if legs:
         out["other_configs"] = legs
     out["full_line"] = "profiles/bench_last_full.json"
@@ -417,19 +422,39 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         if dist.is_initialized():
             dist.barrier()
 
+    def solver_counters():
+        """[solves, LU fallbacks, Cholesky hand-off stalls] of this rank's plans since they were created (sfft_plan_query)"""
+        return [sum(pl.query(k) for pl in plans) for k in ("SOLVES", "LU_FALLBACKS", "CHOL_STALLS")]
+
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
+    c0 = solver_counters()
     barrier()
     t_start = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize(dev)
+    t_own = time.perf_counter() - t_start          # this rank's own time for its shard (before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t_start
+    # what the TIMED region ran on, read before anything else touches the plans: which solver its pairs took (the reference always runs LU,
+    # SFFTSubtract.py:15-23; here a failed Cholesky attempt silently costs a second, 7x slower solve) and how often a hand-off poll ran out
+    c1 = solver_counters()
+    timed_solver = {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")
+    solver_delta = [b - a for a, b in zip(c0, c1)]
     comm_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
+    # one row per rank: [rank, device, pairs per step, own seconds, solves, LU fallbacks, stalls, NUMA node of the GPU, CPUs the rank's threads may run on]
+    my_row = torch.tensor([rank, local_rank, len(my_ids), t_own] + solver_delta + list(AFFINITY), dtype=torch.float64, device=comm_dev)
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rows = [torch.zeros_like(my_row) for _ in range(world)]
+        dist.all_gather(rows, my_row)
+    else:
+        rows = [my_row]
+    per_rank = [{"rank": int(r[0]), "device": int(r[1]), "pairs": int(r[2]) * args.steps, "seconds": float(r[3]),
+                 "pairs_per_s": int(r[2]) * args.steps / max(float(r[3]), 1e-9), "solves": int(r[4]), "lu_fallback_pairs": int(r[5]),
+                 "chol_stall_events": int(r[6]), "numa_node": int(r[7]), "cpus_allowed": int(r[8])} for r in (x.cpu() for x in rows)]
 
     # ---- post-run check + isolated per-kernel durations: ONE pair in flight, fresh output buffers -----------------------
     check_ids = sorted(set([0, len(my_ids) // 2, len(my_ids) - 1]))
@@ -642,7 +667,12 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
             "config": {"workload": workload, "baseline_config": 4 if batch_mode else args.config,
                        "pairs_per_step": n_total, "pairs_in_flight_per_gpu": S, "timed_region_s": elapsed,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "plan_create_s": plan_s, "NEQ": NEQ,
-                       "solver": {1: "cholesky", 2: "lu"}.get(plans[0].query("LAST_SOLVER"), "?")},
+                       "solver": timed_solver if sum(r["lu_fallback_pairs"] for r in per_rank) == 0 else "cholesky, LU fallback on %d of %d solves" % (
+                           sum(r["lu_fallback_pairs"] for r in per_rank), sum(r["solves"] for r in per_rank))},
+            # the timed region's solver accounting over all ranks (SFFT_Q_SOLVES / _LU_FALLBACKS / _CHOL_STALLS before and after it)
+            "solves_timed": sum(r["solves"] for r in per_rank), "lu_fallback_pairs": sum(r["lu_fallback_pairs"] for r in per_rank),
+            "chol_stall_events": sum(r["chol_stall_events"] for r in per_rank),
+            "per_rank": per_rank,
             "roofline": dict(roofline,
                              measured="HIP events on the launch stream around the stage's kernels, %d launches with one pair in flight right after "
                              "the timed region (same process, same buffers); the stage with the most kernel time per pair" % n_iso,
@@ -699,6 +729,38 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
     return out
 
 
+AFFINITY = (-1, 0)       # (NUMA node of this rank's GPU, CPUs its threads may run on): set by pin_to_gpu_numa_node()
+
+
+def pin_to_gpu_numa_node(local_rank, world):
+    """One process per GPU: keep this rank's host threads (one per pair in flight, plus the runtime's) on the CPUs of the NUMA node its GPU hangs
+    off, so that eight ranks do not all submit from node 0 (the reference pins nothing: one thread per device queue in ONE process,
+    sfft/MultiEasyCrowdedPacket.py:361-399).  Linux sysfs only; anything missing leaves the affinity as it is.  SFFT_BENCH_NO_PIN=1: off."""
+    global AFFINITY
+    try:
+        import torch
+        allowed = len(os.sched_getaffinity(0))
+        AFFINITY = (-1, allowed)
+        if os.environ.get("SFFT_BENCH_NO_PIN"):
+            return
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        AFFINITY = (node, allowed)
+        if node < 0 or world <= 1:
+            return            # (a single rank keeps every core: its cpu_baseline leg wants them)
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            AFFINITY = (node, len(cpus))
+    except Exception as e:      # (no sysfs, no pci ids, a container without the node files ...)
+        sys.stderr.write("bench.py: not pinning rank threads: %s: %s\n" % (type(e).__name__, e))
+
+
 def _free_port():
     import socket
     sk = socket.socket()
@@ -730,7 +792,7 @@ def self_launch(args):
 def main():
     args = parse_args()
     import copy
-    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+    if ("WORLD_SIZE" not in os.environ or ("RANK" not in os.environ and int(os.environ["WORLD_SIZE"]) == 1)) and (args.gpus > 1 or args.spawn):
         self_launch(args)        # does not return
     import torch
     import torch.distributed as dist
@@ -749,7 +811,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    launched = "WORLD_SIZE" in os.environ      # started by torch.distributed.run (the driver's or self_launch's): a process group even at N = 1
+    pin_to_gpu_numa_node(local_rank, world)
+    # started by torch.distributed.run (the driver's or self_launch's): a process group even at N = 1.  A bare WORLD_SIZE=1 that some schedulers
+    # and containers export without a rendezvous (no RANK / MASTER_PORT) is NOT a launch: the process runs directly instead of failing in init.
+    launched = "WORLD_SIZE" in os.environ and (world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ) or bool(os.environ.get("SFFT_BENCH_SELF_LAUNCHED")))
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":

@@ -33,7 +33,9 @@ enum {
     SFFT_ERR_UNSUPPORTED_SIZE = -2, /* an image side above 16384 with no factorisation into on-chip transforms, or more than 24 576 unknowns */
     SFFT_ERR_HIP = -3,              /* a HIP runtime call failed (message has the HIP error string) */
     SFFT_ERR_SINGULAR = -4,         /* linear system could not be solved (the pivoted LU found no nonzero pivot in a column) */
-    SFFT_ERR_NOMEM = -5
+    SFFT_ERR_NOMEM = -5,
+    SFFT_ERR_STALL = -6             /* the pivoted LU's workgroups did not get through a hand-off twice in a row (bounded polls ran out: the GPU was too
+                                       busy to keep them co-resident); nothing is known about the system -- call again.  Never raised for a singular system */
 };
 
 /* fields for sfft_plan_query(); the dict keys callers read from SFFTConfig[0]
@@ -61,6 +63,10 @@ enum {
     SFFT_Q_CHOL_STATUS,             /* status bits the most recent Cholesky attempt left (0 = factorised): 1 | 2 = a pivot was not positive (the
                                        reference's LU, SFFTSubtract.py:15-23, then takes the system), 4 = a dataflow hand-off poll ran out (a
                                        scheduling stall, not a property of the system), 8 = launched on fewer than two workgroups */
+    SFFT_Q_SOLVES,                  /* dense solves this plan has completed since it was created (cumulative; the three counters let a caller that
+                                       keeps several pairs in flight say what its timed region ran on: difference before / after) */
+    SFFT_Q_LU_FALLBACKS,            /* ... of which the Cholesky attempt failed and the pivoted LU redid the system (forced LU runs are not counted) */
+    SFFT_Q_CHOL_STALLS,             /* ... Cholesky attempts that ended with status bit 4 (a hand-off poll ran out: a scheduling stall) */
     SFFT_Q_COUNT
 };
 

@@ -16,11 +16,12 @@ SFFT_ERR_UNSUPPORTED_SIZE = -2
 SFFT_ERR_HIP = -3
 SFFT_ERR_SINGULAR = -4
 SFFT_ERR_NOMEM = -5
+SFFT_ERR_STALL = -6
 
 QUERY_FIELDS = ["N0", "N1", "w0", "w1", "DK", "DB", "ConstPhotRatio", "L0", "L1", "Fab", "Fij", "Fpq", "NEQ", "Fijab",
                 "NEQ_FSfree", "FOMG", "FGAM", "FTHE", "FPSI", "FPHI", "FDEL", "WORKSPACE_BYTES", "LAST_SOLVER",
                 "NUM_GREEK_PAIRS", "ScaFij", "SOLVE_GRAPH", "THETA_FUSED", "OMG_OFFDIAG", "OMG_DIAG", "G1_DECIMATED", "G1_CHUNKS", "G1_MFMA",
-                "CHOL_DATAFLOW", "SOLVER_N", "OMG_SPARSE", "CHOL_STATUS"]
+                "CHOL_DATAFLOW", "SOLVER_N", "OMG_SPARSE", "CHOL_STATUS", "SOLVES", "LU_FALLBACKS", "CHOL_STALLS"]
 STAGES = ["prelim_solve", "greek_g1", "greek_g2", "fill", "solve", "prelim_apply", "construct", "inverse", "greek_g1b",
           "fwd_rows", "fwd_cols"]
 

@@ -10,7 +10,15 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 SRC = os.path.join(CSRC, "sfft_amd.hip")
 LIB = os.path.join(PKG_DIR, "libsfft_amd.so")
-OBJ_DIR = os.path.join(os.path.dirname(PKG_DIR), "build", "obj")
+def _obj_dir():
+    """<checkout>/build/obj in a source tree; for an installed package (the parent is site-packages: shared, maybe read-only) a per-user cache."""
+    parent = os.path.dirname(PKG_DIR)
+    if os.path.isdir(os.path.join(parent, ".git")) or os.path.exists(os.path.join(parent, "bench.py")):
+        return os.path.join(parent, "build", "obj")
+    return os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache")), "sfft_amd", "obj")
+
+
+OBJ_DIR = _obj_dir()
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # csrc/sfft_amd.hip only: matrix instructions take their accumulators in ordinary registers.  chol_dataflow needs more than 256 registers, and the
@@ -35,6 +43,9 @@ def _stale(target, deps):
 
 def needs_build():
     units = _units()
+    every_source = sorted(set(d for _, _, deps, _ in units for d in deps))
+    if os.path.exists(LIB) and not _stale(LIB, every_source):
+        return False        # a library newer than every source is current even when only the .so was shipped (no objects beside it)
     return any(_stale(o, d) for _, o, d, _ in units) or _stale(LIB, [o for _, o, _, _ in units if os.path.exists(o)] or [SRC])
 
 

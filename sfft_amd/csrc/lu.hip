@@ -37,10 +37,10 @@ static void update(double* A, int ld, int n, int k0, int nb, const LuPerm* perm,
     }
 }
 
-static void apply_perm(double* A, int ld, const LuPerm* perm, int cbeg, int cend, hipStream_t s, lu_note_fn note)
+static void apply_perm(double* A, int ld, int n, const LuPerm* perm, int cbeg, int cend, hipStream_t s, lu_note_fn note)
 {
     if (cend <= cbeg) return;
-    hipLaunchKernelGGL(lu_apply_perm, dim3((cend - cbeg + LU_NB - 1) / LU_NB), dim3(256), 0, s, A, ld, perm, cbeg, cend);
+    hipLaunchKernelGGL(lu_apply_perm, dim3((cend - cbeg + LU_NB - 1) / LU_NB), dim3(256), 0, s, A, ld, n, perm, cbeg, cend);
     say(note, "lu_apply_perm");
 }
 
@@ -71,7 +71,7 @@ void lu_factor_launches(double* A, int ld, int n, LuPerm* perms, int* status, do
             if (Rw == 1) LU_MW(1); else if (Rw == 2) LU_MW(2); else if (Rw == 3) LU_MW(3); else if (Rw == 4) LU_MW(4); else LU_MW(6);
 #undef LU_MW
             say(note, "lu_panel_mw");
-            apply_perm(A, ld, pl, K0, K0 + NBo, s, note);                // the panel's own columns: rows into place
+            apply_perm(A, ld, n, pl, K0, K0 + NBo, s, note);                // the panel's own columns: rows into place
             update(A, ld, n, K0, NBo, pl, n + 1, s, note);
         }
     }

@@ -720,9 +720,11 @@ __global__ void __launch_bounds__(256) lu_swap_trsm(double* __restrict__ A, int 
     __shared__ int spos[LU_MAXTOUCH], ssrc[LU_MAXTOUCH], srcof[LU_NB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c16 = lane & 15, rq = lane >> 4;
     const int cs = k0 + nb + LU_NB * (int)blockIdx.x, wc = min(LU_NB, cend - cs);       // columns [k0 + nb, cend) in slabs of 64
-    const int cnt = perm ? perm->count : 0;
+    // (count and rows clamped: after a timed-out hand-off poll of lu_panel_mw -- status bit 4, the solve is then redone or refused -- a list may
+    //  hold stale entries; the later kernels of the chain still run on it and must stay inside the matrix)
+    const int cnt = perm ? min(perm->count, LU_MAXTOUCH) : 0;
     if (tid < LU_NB) srcof[tid] = k0 + min(tid, nb - 1);
-    if (tid < LU_MAXTOUCH) { spos[tid] = tid < cnt ? perm->pos[tid] : 0; ssrc[tid] = tid < cnt ? perm->src[tid] : 0; }
+    if (tid < LU_MAXTOUCH) { spos[tid] = tid < cnt ? min(max(perm->pos[tid], k0), n - 1) : 0; ssrc[tid] = tid < cnt ? min(max(perm->src[tid], 0), n - 1) : 0; }
     __syncthreads();
     if (tid < cnt && spos[tid] < k0 + nb) srcof[spos[tid] - k0] = ssrc[tid];
     __syncthreads();
@@ -777,13 +779,13 @@ __global__ void __launch_bounds__(256) lu_swap_trsm(double* __restrict__ A, int 
 // Rows into place on columns [cbeg, cend) (64-column slabs): row perm->pos[e] receives row perm->src[e].  Two-level panels
 // (lu.hip) apply the lists of their 16-column groups to the panel's earlier columns and, one list after the other, to everything
 // right of the panel.
-__global__ void __launch_bounds__(256) lu_apply_perm(double* __restrict__ A, int ld, const LuPerm* __restrict__ perm, int cbeg, int cend)
+__global__ void __launch_bounds__(256) lu_apply_perm(double* __restrict__ A, int ld, int n, const LuPerm* __restrict__ perm, int cbeg, int cend)
 {
     __shared__ double Gs[LU_MAXTOUCH][LU_NB];
     __shared__ int spos[LU_MAXTOUCH], ssrc[LU_MAXTOUCH];
     const int tid = threadIdx.x, cs = cbeg + LU_NB * (int)blockIdx.x, wc = min(LU_NB, cend - cs);
-    const int cnt = perm->count;
-    if (tid < LU_MAXTOUCH) { spos[tid] = tid < cnt ? perm->pos[tid] : 0; ssrc[tid] = tid < cnt ? perm->src[tid] : 0; }
+    const int cnt = min(perm->count, LU_MAXTOUCH);          // (clamped like lu_swap_trsm's: a list behind a timed-out poll may be stale)
+    if (tid < LU_MAXTOUCH) { spos[tid] = tid < cnt ? min(max(perm->pos[tid], 0), n - 1) : 0; ssrc[tid] = tid < cnt ? min(max(perm->src[tid], 0), n - 1) : 0; }
     __syncthreads();
     const int gc = tid & 63, gr0 = tid >> 6;
     for (int e0 = 0; e0 < cnt; e0 += 32) {

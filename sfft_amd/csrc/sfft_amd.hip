@@ -196,6 +196,7 @@ struct sfft_plan {
     cplx* d_spec = nullptr;             // [Fij+1][N0][Nhp]   (plane Fij: J in solve, FD in apply)
     cplx *d_big1 = nullptr, *d_big2 = nullptr, *d_colscr = nullptr;   // work arrays of the four-step path
     cplx *d_bb1 = nullptr, *d_bb2 = nullptr; int bb_lines = 0;        // work arrays [bb_lines][BM] of the Bluestein-through-four-step axes
+    size_t bb_elems = 0;                // complex elements of each of them: min(BIGBLUE_WORK_ELEMS, the most lines a pass of this plan transforms x BM)
     double* d_ones = nullptr;           // [max(N0, N1)] of 1.0: the weight table of unweighted planes on the fast row pass
     double *d_zero = nullptr, *d_zsol = nullptr;   // zero image / zero solution for the stand-alone inverse FFT (lazy)
     // mixed-domain apply (polynomial kernels on the staged fast path, KerHW <= 8): no column transforms in the apply pass
@@ -249,6 +250,7 @@ struct sfft_plan {
     int vconv_direct_launch = 0;        // env SFFT_VCONV_DIRECT=1: the leftover columns of the mixed-domain apply in a launch of their own (vconv_direct)
     int g1_dit = 1;                     // env SFFT_G1_DIT=0: grouped Omega launch without the radix-2 decimation step along the rows
     int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
+    long long n_solves = 0, n_lu_fallback = 0, n_chol_stall = 0;     // SFFT_Q_SOLVES / _LU_FALLBACKS / _CHOL_STALLS
     int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
     int colz = 1;                       // solve pass of the 4096^2 path: cols_fwd_weighted_4096_z (two workgroups per CU; pair-major stage lines in, 2-column
                                         // panels out).  env SFFT_COLZ=0: cols_fwd_weighted_4096_q.  Set to 0 by the plan when its conditions do not hold.
@@ -463,8 +465,15 @@ static int build_bigblue_axis(sfft_plan* p, AxisHost& ax, int N)
     HIPCHK(hipMemcpy(ax.root, r.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ax.chirp, c.data(), N * sizeof(cplx), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ax.bf, bf.data(), M * sizeof(cplx), hipMemcpyHostToDevice));
-    if (!p->d_bb1) {
-        if ((rc = dev_alloc(p, &p->d_bb1, BIGBLUE_WORK_ELEMS)) || (rc = dev_alloc(p, &p->d_bb2, BIGBLUE_WORK_ELEMS))) return rc;
+    // work arrays: a batch of lines x M elements, never more than the plan's longest pass needs (an FFT-only plan of a small prime-sided image
+    // used to hold 2 x 256 MB here); the two axes of a plan share them
+    const size_t max_lines = (size_t)std::max(std::max(p->N0, p->N1), 1);
+    const size_t need = std::min<size_t>(BIGBLUE_WORK_ELEMS, max_lines * (size_t)M);
+    if (need > p->bb_elems) {
+        if (p->d_bb1) { dev_free(p->d_bb1); p->d_bb1 = nullptr; }
+        if (p->d_bb2) { dev_free(p->d_bb2); p->d_bb2 = nullptr; }
+        if ((rc = dev_alloc(p, &p->d_bb1, need)) || (rc = dev_alloc(p, &p->d_bb2, need))) return rc;
+        p->bb_elems = need;
     }
     return SFFT_OK;
 }
@@ -1573,6 +1582,9 @@ extern "C" int sfft_plan_query(const sfft_plan* p, int field, long long* v)
         case SFFT_Q_WORKSPACE_BYTES: *v = (long long)p->ws_bytes; break;
         case SFFT_Q_LAST_SOLVER: *v = p->last_solver; break;
         case SFFT_Q_CHOL_STATUS: *v = p->chol_status; break;
+        case SFFT_Q_SOLVES: *v = p->n_solves; break;
+        case SFFT_Q_LU_FALLBACKS: *v = p->n_lu_fallback; break;
+        case SFFT_Q_CHOL_STALLS: *v = p->n_chol_stall; break;
         case SFFT_Q_NUM_GREEK_PAIRS: *v = (long long)(p->n_omg + p->n_dense_w); break;
         case SFFT_Q_SCAFIJ: *v = p->nsca; break;
         case SFFT_Q_SOLVE_GRAPH: *v = p->chol_exec ? 1 : 0; break;
@@ -1689,7 +1701,7 @@ static void big_axis_transform(sfft_plan* p, const AxisHost& ax, cplx* data, cpl
                                bool lines_fastest, int inverse, hipStream_t s, const cplx* src = nullptr, const double* wrow = nullptr)
 {
     if (ax.bigblue) {       // Bluestein through the BM-point four-step transform, a batch of lines at a time through the compact work arrays
-        const int M = ax.BM, per = (int)std::min<size_t>(BIGBLUE_WORK_ELEMS / (size_t)M, 16384);
+        const int M = ax.BM, per = (int)std::max<size_t>(1, std::min<size_t>(p->bb_elems / (size_t)M, 16384));
         for (int l0 = 0; l0 < nlines; l0 += per) {
             const int nl = std::min(per, nlines - l0);
             BlueDesc bd; bd.N = ax.N; bd.M = M; bd.nlines = nl; bd.line0 = l0; bd.conj = inverse; bd.transposed = (lst < st) ? 1 : 0;
@@ -2319,15 +2331,32 @@ static int solve_check(sfft_plan* p, double* d_solution, hipStream_t s, bool* re
         }
     }
     if (!p->attempt_lu) p->chol_status = *p->h_status;
+    ++p->n_solves;
+    if (!p->attempt_lu && (*p->h_status & 4)) ++p->n_chol_stall;
     if (*p->h_status == 0) return SFFT_OK;
-    if (p->attempt_lu) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+    int rc;
+    // What a nonzero status means after the pivoted LU: bit 2 = no nonzero pivot in some column (the reference's LinAlgError: "Singular matrix");
+    // bit 4 alone = a bounded hand-off poll of lu_panel_mw ran out -- its workgroups were not co-resident beside other streams' kernels --
+    // which says nothing about the system: the attempt is repeated once, then refused as a stall, never reported as singular.
+    auto lu_outcome = [&]() -> int {
+        if (*p->h_status == 0) return SFFT_OK;
+        if (*p->h_status & 2) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+        fprintf(stderr, "sfft_amd: the pivoted LU reported status %d (4: a hand-off poll between a panel's workgroups timed out); repeating the attempt\n", *p->h_status);
+        int rc2;
+        if ((rc2 = solve_attempt(p, true, d_solution, s))) return rc2;
+        HIPCHK(hipStreamSynchronize(s));
+        if (*p->h_status == 0) { if (redone) *redone = true; return SFFT_OK; }
+        if (*p->h_status & 2) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+        return set_err(SFFT_ERR_STALL, "pivoted LU: a hand-off poll between the workgroups of a panel timed out twice (a scheduling stall on a busy GPU, not a singular system); call again");
+    };
+    if (p->attempt_lu) return lu_outcome();
     if (*p->h_status & 12)      // not a property of the system: say so before the pivoted LU takes over
         fprintf(stderr, "sfft_amd: chol_dataflow reported status %d (4: hand-off poll timed out, 8: grid < 2 workgroups); solving by LU\n", *p->h_status);
-    int rc;
+    ++p->n_lu_fallback;
     if ((rc = solve_attempt(p, true, d_solution, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     p->last_solver = 2;
-    if (*p->h_status != 0) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
+    if ((rc = lu_outcome())) return rc;
     if (redone) *redone = true;
     return SFFT_OK;
 }
@@ -2759,7 +2788,9 @@ extern "C" int sfft_dbg_solve_dense(sfft_plan* p, const double* d_bordered, int 
     HIPCHK(hipStreamSynchronize(s));
     p->last_solver = use_lu ? 2 : 1;
     if (!use_lu) p->chol_status = *p->h_status;
-    if (*p->h_status != 0) return set_err(SFFT_ERR_SINGULAR, std::string("Singular matrix") + ((*p->h_status & 4) ? " (a hand-off of the solver timed out: status " + std::to_string(*p->h_status) + ")" : ""));
+    if (*p->h_status != 0 && !(*p->h_status & 3))       // bits 4 / 8 alone: a scheduling stall, not a property of the matrix
+        return set_err(SFFT_ERR_STALL, "dense solve: a hand-off poll between workgroups timed out (status " + std::to_string(*p->h_status) + "); not a singular system, call again");
+    if (*p->h_status != 0) return set_err(SFFT_ERR_SINGULAR, "Singular matrix");
     return SFFT_OK;
 }
 

@@ -30,13 +30,13 @@ def _clean_env():
     return env
 
 
-def _launch(extra, torchrun=True, gpus=2, tail=("--dist-backend", "gloo", "--all-ranks-on-device0")):
+def _launch(extra, torchrun=True, gpus=2, tail=("--dist-backend", "gloo", "--all-ranks-on-device0"), env_extra=None):
     """torchrun=True: the way the driver launches N > 1; False: plain `python bench.py --gpus N`, which must start its ranks itself."""
     head = [sys.executable]
     if torchrun:
         head += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
     cmd = head + [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + SMALL + list(tail) + extra
-    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(_clean_env(), **(env_extra or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     json_lines = [ln for ln in lines if ln.startswith("{")]
@@ -50,7 +50,21 @@ def test_bench_two_ranks_sharded_batch():
     d = _launch(["--pairs", "6"])                         # config-4 mode: 6 pairs dealt to 2 ranks, worker threads pull
     assert d["n_gpus"] == 2 and d["gathered_pairs"] == 6 and d["failed_pairs"] == 0 and d["value"] > 0
     assert d["scaling"] == "strong" and d["config"]["pairs_per_step"] == 6 and d["post_check"]["bitwise_equal"] is True
+    _check_per_rank(d, [3, 3])
     assert abs(d["value"] - 6 * d["steps"] / d["config"]["timed_region_s"]) <= 1e-3 * d["value"]
+
+
+def _check_per_rank(d, pairs_of_rank):
+    """The line carries one row per rank -- rank, device, pairs of the timed region, that rank's own pairs/s, the NUMA node of its GPU and
+    the CPUs its threads may run on -- and the timed region's solver accounting (sfft/MultiEasyCrowdedPacket.py:361-399, 646-669 prints
+    per-task outcomes per device; one aggregate number would hide an imbalanced or badly placed rank)."""
+    assert d["per_rank_keys"] == "rank,device,pairs,pairs_per_s,numa_node,cpus_allowed"
+    rows = d["per_rank"]
+    assert [r[0] for r in rows] == list(range(len(pairs_of_rank))) and [r[2] for r in rows] == [p * d["steps"] for p in pairs_of_rank]
+    assert all(r[3] > 0 and r[5] >= 1 for r in rows)
+    # every rank's own rate is at least the job's share of it (the job's clock is the slowest rank's, barrier included)
+    assert all(r[3] >= 0.999 * d["value"] * r[2] / (sum(pairs_of_rank) * d["steps"]) for r in rows)
+    assert d["solves_timed"] == sum(pairs_of_rank) * d["steps"]
 
 
 @pytest.mark.gpu
@@ -58,8 +72,20 @@ def test_bench_two_ranks_weak_scaling_headline_path():
     d = _launch(["--batch", "3", "--streams", "2"])      # the headline's mode: every rank holds its own batch
     assert d["n_gpus"] == 2 and d["gathered_pairs"] == 6 and d["failed_pairs"] == 0 and d["value"] > 0
     assert d["scaling"] == "weak" and d["config"]["pairs_per_step"] == 6 and d["post_check"]["bitwise_equal"] is True
+    _check_per_rank(d, [3, 3])
+    assert d["lu_fallback_pairs"] == 0 and d["chol_stall_events"] == 0 and d["config"]["solver"] == "cholesky"
     for k in ("roofline", "roofline_hbm", "roofline_greek", "roofline_solve"):
         assert set(("bound", "kernel", "achieved", "peak", "frac", "traffic", "avg_ms")) <= set(d[k]), k
+
+
+@pytest.mark.gpu
+def test_bench_line_counts_lu_fallbacks_of_the_timed_region():
+    """SFFT_TEST_FAIL_CHOL=1 reports every Cholesky attempt as failed, so every pair of the timed region is redone by the pivoted LU: the line
+    must say so (`lu_fallback_pairs` == the solves of the timed region, `config.solver` names the fallback) instead of "cholesky"."""
+    d = _launch(["--pairs", "5"], env_extra={"SFFT_TEST_FAIL_CHOL": "1"})
+    _check_per_rank(d, [3, 2])
+    assert d["lu_fallback_pairs"] == d["solves_timed"] == 5 * d["steps"] and d["failed_pairs"] == 0
+    assert "LU fallback on %d of %d" % (d["lu_fallback_pairs"], d["solves_timed"]) in d["config"]["solver"]
 
 
 @pytest.mark.gpu
