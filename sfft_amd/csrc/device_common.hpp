@@ -53,6 +53,27 @@ __device__ __forceinline__ void st_stream(double* p, double z)
     *p = z;
 #endif
 }
+// Stores that are ALWAYS non-temporal: the spectra of cols_fwd_weighted_4096_z and the DIFF rows of rows_c2r_diff_4096 (measured per kernel, round 6:
+// with every st_stream non-temporal the column pass, the Omega launch that reads its spectra and the inverse pass gain 0.014 / 0.03 / 0.006 ms,
+// the row passes lose 0.007 - 0.014 ms -- so the row passes keep plain stores; non-temporal LOADS cost the column pass 0.08 ms, its two
+// workgroups per panel share every line through the L2).  SFFT_NO_NT_STORES (build flag) restores plain stores for an A/B run.
+__device__ __forceinline__ void st_nt(cplx* p, cplx z)
+{
+#ifdef SFFT_NO_NT_STORES
+    *p = z;
+#else
+    v2d_t v = {z.x, z.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_t*>(p));
+#endif
+}
+__device__ __forceinline__ void st_nt(double* p, double z)
+{
+#ifdef SFFT_NO_NT_STORES
+    *p = z;
+#else
+    __builtin_nontemporal_store(z, p);
+#endif
+}
 __device__ __forceinline__ cplx ld_stream(const cplx* p)
 {
 #if SFFT_NT & 1

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(512, 4) cols_fwd_weighted_4096_z(const cplx* _
     // 2-column panels: element (row l, column c of pair cp) at cp * N0 * 2 + l * 2 + c;  row j + 256 sx of lane 2 j + c: tid + 512 sx
     cplx* __restrict__ dst = out + (size_t)g.out_plane[o] * plane_sz + (size_t)cpm * (size_t)(N0 * 2) + tid;
 #pragma unroll
-    for (int sx = 0; sx < 16; ++sx) st_stream(dst + 512 * sx, u[R16_OUT(sx)]);
+    for (int sx = 0; sx < 16; ++sx) st_nt(dst + 512 * sx, u[R16_OUT(sx)]);
 }
 
 // rows, half complex -> real (N1 = 4096), two rows per transform, DIFF epilogue (see rows_c2r_diff)
@@ -473,8 +473,8 @@ __global__ void __launch_bounds__(256) rows_c2r_diff_4096(const cplx* __restrict
                 B0 = fma(on ? c0[q] : 0.0, tb[e][q], B0);
                 B1 = fma(on ? c1[q] : 0.0, tb[e][q], B1);
             }
-            st_stream(d0 + n, jv0[e] - B0 - z.x);
-            if (has1) st_stream(d1 + n, jv1[e] - B1 + z.y);
+            st_nt(d0 + n, jv0[e] - B0 - z.x);
+            if (has1) st_nt(d1 + n, jv1[e] - B1 + z.y);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
