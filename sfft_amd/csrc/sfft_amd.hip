@@ -209,7 +209,7 @@ struct sfft_plan {
     cplx* d_stage = nullptr;            // fast path: row-pass output, one plane per distinct (image, column factor) (lazy)
     int n_stage_alloc = 0;
     cplx* d_spec2 = nullptr;            // [Fij][N0][Nhp] spectra of the full pair, filled on stream s2 during the solve (lazy)
-    hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr, ev_mom = nullptr, ev_gam = nullptr; int no_overlap = 0;
+    hipStream_t s2 = nullptr; hipEvent_t ev_in = nullptr, ev_pre = nullptr, ev_mom = nullptr, ev_gam = nullptr; 
     const double* overlap_I = nullptr;  // set by sfft_subtract for the duration of its sfft_solve call
     cplx* d_gp = nullptr;
     double* d_patches = nullptr; size_t n_patches = 0;
@@ -225,8 +225,8 @@ struct sfft_plan {
     unsigned int* d_tflags = nullptr;   // [nbc][nbc + 1] "tile factored" flags of chol_dataflow, [nbc * (nbc + 1)] = its task counter
     double* d_w16 = nullptr;            // [nbc][4][16][16] inverses of the 16 x 16 diagonal sub-blocks of the factor (chol_dataflow's MFMA triangular solves)
     unsigned long long* d_trace = nullptr;   // env SFFT_DF_TRACE=1: [nbc][16] wall-clock stamps of the critical path of chol_dataflow (development aid)
-    int dataflow = 1;                   // env SFFT_CHOL_DF=0: launch-per-step factorisation (A/B testing)
-    int df_groups = 64;                 // env SFFT_CHOL_DF_WG: persistent workgroups of chol_dataflow
+    int dataflow = 1;                   // 1: n < chol_outer_min factors in the single-launch dataflow kernel (fixed; the launch-per-step chain remains for the outer-blocked tail)
+    int df_groups = 64;                 // persistent workgroups of chol_dataflow (64: swept 24 .. 96 in rounds 4 and 5)
     hipGraphExec_t lu_exec = nullptr;   // the pivoted-LU chain (lu.hpp), captured the same way on its first use
     std::string lu_graph_kernels;
     LuPerm* d_luperm = nullptr;         // [panels] row permutation lists of the LU panels
@@ -236,9 +236,9 @@ struct sfft_plan {
     int* h_status = nullptr;            // pinned: status word of the most recent attempt
     int test_fail_chol = 0;             // env SFFT_TEST_FAIL_CHOL=1 (tests): report the Cholesky attempt as failed, to exercise the LU redo path
     bool attempt_lu = false;            // the most recent attempt used LU
-    int fused_step = 1;                 // env SFFT_FUSED_STEP=0: separate update / panel launches (A/B testing)
+    int fused_step = 1;                 // fused update + panel launches (fixed)
     int n_bflags = 0;
-    int back_variant = 1;               // env SFFT_BACK=0: one launch per block (A/B testing)
+    int back_variant = 1;               // back substitution as one launch (fixed)
     double* d_sol = nullptr;            // [NEQ] internal solution copy
     cplx* d_rtab = nullptr; int wpad = 4;   // [Fij][N0][1 + 2 wpad] per-row kernel transfer table of the apply pass
     double* d_rowmom = nullptr; double* d_delta = nullptr;
@@ -248,37 +248,36 @@ struct sfft_plan {
     int vconv_rp = 2;                   // mixed-domain apply: 2 = two source rows per LDS table read (vconv_mixed2); env SFFT_VCONV_RP=1: one row (vconv_mixed)
     int num_cu = 256;
     int vconv_direct_launch = 0;        // env SFFT_VCONV_DIRECT=1: the leftover columns of the mixed-domain apply in a launch of their own (vconv_direct)
-    int g1_dit = 1;                     // env SFFT_G1_DIT=0: grouped Omega launch without the radix-2 decimation step along the rows
+    int g1_dit = 1;                     // grouped Omega launch with the radix-2 decimation step along the rows wherever the shape allows (fixed)
     int vconv_r = -1;                   // env SFFT_VCONV_R: output rows per stream of vconv_mixed2 (-1: balanced against the CU count, 0: KS * L - 2 W as before)
     long long n_solves = 0, n_lu_fallback = 0, n_chol_stall = 0;     // SFFT_Q_SOLVES / _LU_FALLBACKS / _CHOL_STALLS
-    int colq = 1;                       // env SFFT_COLQ=0: forward column pass of the 4096^2 path with two columns per workgroup
+    int colq = 1;                       // four columns per workgroup on 4-column panels (cols_fwd_weighted_4096_q); other panel widths take the two-column kernel
     int colz = 1;                       // solve pass of the 4096^2 path: cols_fwd_weighted_4096_z (two workgroups per CU; pair-major stage lines in, 2-column
                                         // panels out).  env SFFT_COLZ=0: cols_fwd_weighted_4096_q.  Set to 0 by the plan when its conditions do not hold.
     SpecLayout lay_spec;                // layout of the solve pass's spectra in d_spec (= lay unless colz)
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 3;                    // Omega passes on the matrix cores: 3 = greek_g1_mfma4g (pass groups that share plane loads, v_mfma_f64_4x4x4_4b_f64),
-                                        // env SFFT_G1_MFMA=2: greek_g1_mfma4 (one pass per wave), 0: vector kernel (A/B testing)
+                                        // (fixed 3: the grouped launch; 2 = greek_g1_mfma4, one pass per wave, where no groups are built)
     unsigned long long* d_g1trace = nullptr;   // env SFFT_G1_TRACE=file: per-wave start / end stamps of the grouped Omega launch (development aid)
     G1Group* d_groups = nullptr;        // pass groups of the Omega launch
     int n_groups = 0;
-    int panel4 = 1, ncu = 0;            // env SFFT_PANEL4=0: the panel steps of the outer-blocked factorisation as four launches (chol_panel + 3 chol_step)
+    int panel4 = 1, ncu = 0;            // the four panel steps of an outer block as one launch (chol_panel4; fixed)
     unsigned int* d_pq = nullptr;       // [PANEL4_MAX_OUTER] role counters of chol_panel4 + [16] its hand-off flags
-    int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (env SFFT_ROWMOM_FUSED=0: separate row_moments launches)
+    int rowmom_fused = 0;               // 1: the row moments of the masked pair come out of rows_r2c_4096 (else separate row_moments launches)
     int n_the_fused = 0;                // leading Theta passes that ride in the groups (all Fij of them when Fij is even)
-    int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (env SFFT_THETA_FUSED=0: separate vector launch)
+    int theta_in_groups = 0;            // 1: the Fij Theta passes ride in the edge groups of the Omega launch (else a vector launch of their own)
     int theta_slots = 0;                // 1: half width 9 .. 16 (KerHW 9 .. 16): the Theta passes as ordinary slots in groups of their own behind the Omega groups
     int n_groups_omg = 0;               //    (first launch only: n_groups counts them, n_groups_omg does not; env SFFT_THETA_SLOTS=0: a launch of their own)
     int rows_r24 = 0;                   // 16 / 24: 6144- / 9216-point row axis on the register-resident kernels of fft_r24.hpp (env SFFT_NO_ROWS_R24=1: the generic pass, A/B)
     bool cols_r24_pair = true;          // 6144-point columns: two panel neighbours per workgroup in neighbouring lanes (env SFFT_COLS_R24_PAIR=0: one column)
     int cols_r24 = 0;                   // the same for the column axis (env SFFT_NO_COLS_R24=1)
-    int no_wx_support = 0;              // env SFFT_NO_WX_SUPPORT=1: the generic weighted column pass reads rows whose row factor is zero too (A/B)
     std::vector<int> kbx_lo, kbx_hi;    // [nkx] first row / one past the last row where the kernel row factor is nonzero
     int no_staged = 0;                  // env SFFT_NO_STAGED=1: one row transform per plane instead of one per column factor (A/B testing)
-    int no_fast_fft = 0;                // env SFFT_NO_FAST_FFT=1: use the generic LDS FFT for 4096-point axes too (A/B testing)
+    int no_fast_fft = 0;                // (fixed 0; SFFT_NO_R16 / SFFT_NO_MIXED_RADIX select the generic transforms for tests)
     // A/B switches of the launch paths, read ONCE at plan creation (never getenv on a hot path)
     bool want_mom_event = false, mom_event_recorded = false;   // solve pass: ev_mom right behind the row pass (the Gamma block then runs beside the COLUMN pass)
-    int colscr_planes = 1, no_dft16_multi = 0;      // scratch planes of the four-step column path; SFFT_NO_DFT16_MULTI=1: one first pass per output (A/B)
-    int no_dft16_regs = 0, no_rader_r24 = 0, no_gamma_aside = 0, vconv2_w12 = 1, inv_r24 = -1;
+    int colscr_planes = 1;              // scratch planes of the four-step column path
+    int no_dft16_regs = 0, no_rader_r24 = 0, vconv2_w12 = 1, inv_r24 = -1;
     // Omega products of basis terms with (nearly) disjoint supports: computed in real space by omega_sparse, no transform pass
     std::vector<SparseProd> sprods; SparseProd* d_sprods = nullptr; SparseLine* d_slines = nullptr; int* d_scols = nullptr;
     double* d_strip = nullptr; int n_scols = 0; int2* d_sitems = nullptr; int n_sitems = 0;      // (items: eight runs of n_sitems / 8, one per XCD)
@@ -298,7 +297,12 @@ static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // Debug allocator (env SFFT_GUARD=1 | 2): every plan buffer is mapped on its own with unmapped address space on both sides
 // (HIP virtual-memory API), its END (1) or START (2) flush with the mapping, so that a kernel reading or writing out of
 // bounds faults instead of silently touching a neighbour.  Such buffers are never freed (debug runs only).
-static int guard_mode() { static int v = getenv("SFFT_GUARD") ? atoi(getenv("SFFT_GUARD")) : 0; return v; }
+static int guard_mode() { static int v = [] { const char* e = getenv("SFFT_GUARD"); return e ? atoi(e) : 0; }(); return v; }
+// switches that several places of the plan builder consult (read at every plan creation, never cached: tests flip them between plans)
+static bool env_no_r16() { return getenv("SFFT_NO_R16") != nullptr; }
+static bool env_no_mixed_radix() { return getenv("SFFT_NO_MIXED_RADIX") != nullptr; }
+static bool env_no_vconv() { return getenv("SFFT_NO_VCONV") != nullptr; }
+static int env_theta_slots() { const char* e = getenv("SFFT_THETA_SLOTS"); return e ? atoi(e) : 1; }
 static hipError_t guarded_malloc(void** out, size_t bytes, int dev)
 {
     hipMemAllocationProp prop = {};
@@ -363,7 +367,7 @@ static void host_fft_pow2(std::vector<long double>& re, std::vector<long double>
 
 static const size_t LDS_MAX_ELEMS = 8192;   // longest on-chip transform: 128 KiB of complex128 (160 KiB LDS per CU on gfx950)
 static const size_t LDS_MIXED_ELEMS = 9216; // longest 2^a*3^b transform: 144 KiB (+16 B of column padding)
-static size_t lds_col_elems() { static size_t v = getenv("SFFT_COL_ELEMS") ? (size_t)atol(getenv("SFFT_COL_ELEMS")) : 9216; return v; }
+static size_t lds_col_elems() { return 9216; }
 #define LDS_COL_ELEMS lds_col_elems()      // column tile budget (144 KiB): two padded 4096-point columns fit
 
 // N = 2^a * 3^b with b >= 1: writes a, b
@@ -414,7 +418,7 @@ static int bluestein_len(int N)
     const int need = 2 * N - 1;
     int p2 = 1; while (p2 < need) p2 <<= 1;
     if ((size_t)p2 <= LDS_MAX_ELEMS) return p2;
-    if (need <= 9216 && !getenv("SFFT_NO_MIXED_RADIX") && !getenv("SFFT_NO_R16")) return 9216;
+    if (need <= 9216 && !env_no_mixed_radix() && !env_no_r16()) return 9216;
     return 0;
 }
 
@@ -422,13 +426,13 @@ static bool fits_on_chip(int N)
 {
     if (is_pow2(N)) return (size_t)N <= LDS_MAX_ELEMS;
     int a, b;
-    if (is_2a3b(N, &a, &b) && (size_t)N <= LDS_MIXED_ELEMS && !getenv("SFFT_NO_MIXED_RADIX")) return true;
+    if (is_2a3b(N, &a, &b) && (size_t)N <= LDS_MIXED_ELEMS && !env_no_mixed_radix()) return true;
     return bluestein_len(N) != 0;
 }
 
 // rader: this axis may use Rader sub-transforms (the COLUMN axis only: strided_rader577 is the lines-fastest pass of a column transform)
 static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis = false, bool rader = false);
-static bool rader_ok(int N) { return N == RADER_M + 1 && !getenv("SFFT_NO_RADER") && !getenv("SFFT_NO_R16"); }
+static bool rader_ok(int N) { return N == RADER_M + 1 && !getenv("SFFT_NO_RADER") && !env_no_r16(); }
 
 #define BIGBLUE_MAX_N 16384
 #define BIGBLUE_WORK_ELEMS ((size_t)1 << 24)         // complex elements per work array (256 MB): lines are taken in batches of this many / BM
@@ -572,13 +576,13 @@ static int build_axis(sfft_plan* p, AxisHost& ax, int N, bool sub_axis, bool rad
     ax.N = N;
     int e2 = 0, e3 = 0;
     if (is_pow2(N)) { ax.M = N; ax.blue = 0; }
-    else if (is_2a3b(N, &e2, &e3) && !getenv("SFFT_NO_MIXED_RADIX")) { ax.M = N; ax.blue = 0; ax.n3 = e3; }
+    else if (is_2a3b(N, &e2, &e3) && !env_no_mixed_radix()) { ax.M = N; ax.blue = 0; ax.n3 = e3; }
     else {
         ax.M = bluestein_len(N); ax.blue = 1;
         if (!is_pow2(ax.M)) { is_2a3b(ax.M, &e2, &e3); ax.n3 = e3; }
     }
     ax.logM = ax.n3 ? e2 : ilog2(ax.M);
-    ax.r16 = ((ax.n3 || ax.M >= 16) && !getenv("SFFT_NO_R16")) ? 1 : 0;
+    ax.r16 = ((ax.n3 || ax.M >= 16) && !env_no_r16()) ? 1 : 0;
     int rc;
     std::vector<cplx> h(ax.M);
     for (int k = 0; k < ax.M; ++k) {
@@ -688,24 +692,16 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     ON_DEVICE(device);
     sfft_plan* p = new sfft_plan();
     p->dev = device;
-    if (const char* ev = getenv("SFFT_NO_FAST_FFT")) p->no_fast_fft = atoi(ev);
     if (const char* ev = getenv("SFFT_NO_STAGED")) p->no_staged = atoi(ev);
-    if (const char* ev = getenv("SFFT_NO_WX_SUPPORT")) p->no_wx_support = atoi(ev);
     if (const char* ev = getenv("SFFT_CHOL_OUTER_MIN")) p->chol_outer_min = atoi(ev);
-    if (const char* ev = getenv("SFFT_COLQ")) p->colq = atoi(ev);
     if (const char* ev = getenv("SFFT_COLZ")) p->colz = atoi(ev);
     if (getenv("SFFT_NO_GRAPH")) p->use_graph = 0;
     if (getenv("SFFT_TEST_FAIL_CHOL")) p->test_fail_chol = 1;
     if (const char* ev = getenv("SFFT_VCONV_RP")) p->vconv_rp = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_R")) p->vconv_r = atoi(ev);
-    if (const char* ev = getenv("SFFT_G1_DIT")) p->g1_dit = atoi(ev);
     if (const char* ev = getenv("SFFT_VCONV_DIRECT")) p->vconv_direct_launch = atoi(ev);
-    if (const char* ev = getenv("SFFT_G1_MFMA")) { p->g1_mfma = atoi(ev); if (p->g1_mfma == 1) p->g1_mfma = 2; }
-    if (const char* ev = getenv("SFFT_NO_OVERLAP")) p->no_overlap = atoi(ev);
     if (getenv("SFFT_NO_DFT16_REGS")) p->no_dft16_regs = 1;
-    if (getenv("SFFT_NO_DFT16_MULTI")) p->no_dft16_multi = 1;
     if (getenv("SFFT_NO_RADER_R24")) p->no_rader_r24 = 1;
-    if (getenv("SFFT_NO_GAMMA_ASIDE")) p->no_gamma_aside = 1;
     if (const char* ev = getenv("SFFT_VCONV2_W12")) p->vconv2_w12 = atoi(ev);
     if (const char* ev = getenv("SFFT_INV_R24")) p->inv_r24 = atoi(ev);
     p->N0 = N0; p->N1 = N1; p->w = KerHW; p->DK = DK; p->DB = DB; p->mode = BS.mode; p->cpr = (BS.mode == 1 || BS.mode == 2);
@@ -739,7 +735,6 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         // subset of the CUs when SFFT_S2_CUMASK is set (bit pattern per 32 CUs) so that the solver's small,
         // latency-bound launches always find free CUs; fall back to a low-priority stream if masking fails
         uint32_t pat = 0u;      // CU masking measured slower than a plain low-priority stream on MI355X; off by default
-        if (const char* ev = getenv("SFFT_S2_CUMASK")) pat = (uint32_t)strtoul(ev, nullptr, 0);
         hipDeviceProp_t prop;
         PLAN_HIP(hipGetDeviceProperties(&prop, device));
         p->num_cu = prop.multiProcessorCount;
@@ -798,7 +793,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                         // consumer (32 lines per wave load); 4 keeps them at speed and still gives 0.60 -> 0.47 ms; 8 gains nothing
         if (const char* ev = getenv("SFFT_PANEL")) pw = atoi(ev);
         const bool both_fast = !p->no_fast_fft && !p->ax0.big && !p->ax0.blue && p->ax0.M == 4096 && !p->ax1.big && !p->ax1.blue && p->ax1.M == 4096;
-        const bool both_onchip = !p->ax0.big && !p->ax1.big && !getenv("SFFT_PANEL_FAST_ONLY");
+        const bool both_onchip = !p->ax0.big && !p->ax1.big;
         if ((both_fast || both_onchip) && pw > 1 && is_pow2(pw) && p->Nhp % pw == 0) {
             p->lay.shift = ilog2(pw); p->lay.mask = pw - 1; p->lay.rstride = pw; p->lay.pstride = (long long)N0 * pw;
         }
@@ -808,7 +803,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         // (the pair-per-workgroup column pass: the staged 4096^2 solve pass on 4-column panels; its 2-column spectra are read by the Greek launches only --
         //  plans whose apply pass reads d_spec keep the four-column kernel, see below)
         if (!(both_fast && !p->no_staged && p->colq && p->lay.mask == 3 && p->lay.rstride == 4)) p->colz = 0;
-        if (DK >= 0 && DK <= 3 && p->mode != 3 && KerHW >= 1 && KerHW <= 12 && !getenv("SFFT_NO_VCONV")) {
+        if (DK >= 0 && DK <= 3 && p->mode != 3 && KerHW >= 1 && KerHW <= 12 && !env_no_vconv()) {
             p->use_vconv = 1;
             p->vncf = DK + 1;
             p->vw = KerHW <= 4 ? 4 : KerHW <= 8 ? 8 : 12;
@@ -818,7 +813,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         // basis plans whose terms are the full tensor product of nkx row factors and nky column factors in (ii, jj) order -- the B-spline
         // kernels of BSplineSFFT -- take the same route through vconv_tensor (4 x 4 .. 6 x 6 terms, KerHW <= 8)
         if (DK < 0 && p->mode != 3 && KerHW >= 1 && KerHW <= 8 && BS.nkx == BS.nky && BS.nkx >= 4 && BS.nkx <= 6 && p->Fij == BS.nkx * BS.nky &&
-            !getenv("SFFT_NO_VCONV")) {
+            !env_no_vconv()) {
             bool tensor = true;
             for (int t = 0; t < p->Fij; ++t) tensor = tensor && BS.kpair[2 * t] == t / BS.nky && BS.kpair[2 * t + 1] == t % BS.nky;
             if (tensor) {
@@ -836,7 +831,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                     span = std::max(span, hi - lo + 1);
                     ibase[l] = std::min(lo, BS.nkx - 3);
                 }
-                if (span <= 3 && BS.nkx > 3 && !getenv("SFFT_NO_VT_SPARSE")) {
+                if (span <= 3 && BS.nkx > 3) {
                     p->vt_na = 3;
                     PLAN_TRY(dev_alloc(p, &p->d_ibase, ibase.size()));
                     PLAN_HIP(hipMemcpy(p->d_ibase, ibase.data(), ibase.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -876,7 +871,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     }
     if (p->ax0.big) {
         // 16 x B column axes: the outputs of a stage plane share the first pass, each through a scratch plane of its own (up to DFT16_MAX_OUT)
-        const bool multi = !p->ax0.bigblue && p->ax0.A == 16 && p->ax0.subA && p->ax0.subA->M == 16 && !p->ax0.subA->blue && !p->no_dft16_regs && !p->no_dft16_multi;
+        const bool multi = !p->ax0.bigblue && p->ax0.A == 16 && p->ax0.subA && p->ax0.subA->M == 16 && !p->ax0.subA->blue && !p->no_dft16_regs;
         p->colscr_planes = multi ? std::min(DFT16_MAX_OUT, std::max(1, p->nkx)) : 1;
         PLAN_TRY(dev_alloc(p, &p->d_colscr, (size_t)p->colscr_planes * N0 * p->Nhp));
     }
@@ -941,8 +936,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         if (poly) bkg_deg = BS.nby - 1;
     }
     const int gam_nmu = (DK >= 0) ? DK + bkg_deg + 1 : BS.nky * (bkg_deg + 1);
-    p->gamma_analytic = (bkg_deg >= 0 && p->mode != 3 && KerHW <= GAMMA_MAXW && gam_nmu <= (DK >= 0 ? 7 : GAMMA_ND) && p->Fij <= 64 &&
-                         !getenv("SFFT_NO_ANALYTIC_GAMMA")) ? 1 : 0;
+    p->gamma_analytic = (bkg_deg >= 0 && p->mode != 3 && KerHW <= GAMMA_MAXW && gam_nmu <= (DK >= 0 ? 7 : GAMMA_ND) && p->Fij <= 64) ? 1 : 0;
     p->gam_tab = (DK >= 0) ? 0 : 1; p->gam_nmu = gam_nmu; p->gam_db = bkg_deg;
     std::vector<char> const_x(BS.nbx, 0);
     {
@@ -1004,7 +998,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
         std::vector<int> sk_pass, ss_pass, st_pass, sg_pass((size_t)nsca * BS.nbx);
         // Omega passes.  On the matrix-core path the diagonal passes (a, a) go in pairs: one "dual" pass carries |A_a|^2 and |A_b|^2
         // (greek_g1_mfma, DG) and the partner's record only owns its partial buffer; partner records sit behind the launched ones.
-        const bool dual_diag = p->g1_mfma && hO >= 9 && (hO <= 16 || (hO <= 32 && p->g1_mfma >= 3)) && p->Fij >= 2 && !getenv("SFFT_NO_DUAL_DIAG");
+        const bool dual_diag = p->g1_mfma && hO >= 9 && (hO <= 16 || (hO <= 32 && p->g1_mfma >= 3)) && p->Fij >= 2;
         omg_pass.assign((size_t)p->Fij * (p->Fij + 1) / 2, -1);
         auto okey = [&](int a, int b) { return a * p->Fij - (a * (a - 1)) / 2 + (b - a); };      // (a <= b) -> k, the job / patch order
         std::vector<std::pair<int, int>> partners;     // (leader pass, partner plane)
@@ -1259,7 +1253,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             // plane, and the separate vector launch (which re-reads all Fij + 1 planes) disappears -- when every kernel plane has such a
             // group (Fij even) and the short-pass launch holds nothing but the Theta passes
             {
-                bool ok = p->gamma_analytic && p->n_dense_w == p->n_the && hG <= 8 && !(getenv("SFFT_THETA_FUSED") && atoi(getenv("SFFT_THETA_FUSED")) == 0);
+                bool ok = p->gamma_analytic && p->n_dense_w == p->n_the && hG <= 8;
                 std::vector<int> owner((size_t)p->Fij, -1);
                 if (ok) for (size_t gi = 0; gi < groups.size(); ++gi) {
                     const G1Group& g = groups[gi];
@@ -1283,7 +1277,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
                     // odd Fij: the last plane's Theta pass (x, J) as an ordinary slot beside its lone diagonal pass (x, x): planes (x, x, J),
                     // slot 0 = (v0, v1) = the diagonal, slot 2 = (v0, v2) = the Theta pass with its own lag half width -- instead of a
                     // vector launch of its own that re-reads two planes (config 3: 0.32 ms)
-                    if (nf == p->Fij - 1 && !(getenv("SFFT_THETA_SLOTS") && atoi(getenv("SFFT_THETA_SLOTS")) == 0))
+                    if (nf == p->Fij - 1 && (env_theta_slots() != 0))
                         for (G1Group& g : groups) {
                             const G1Pass& q0 = p->passes[g.pass[0]];
                             if (g.mask == 1 && !q0.dual && q0.a_plane == nf && q0.b_plane == nf && g.tpass[0] < 0) {
@@ -1301,7 +1295,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             // behind the Omega groups, which is where the later launches (lags 17 ..) stop.
             p->n_groups_omg = (int)groups.size();
             if (!p->theta_in_groups && p->gamma_analytic && p->n_dense_w == p->n_the && hG >= 9 && hG <= 16 && hO <= 32 &&
-                !(getenv("SFFT_THETA_FUSED") && atoi(getenv("SFFT_THETA_FUSED")) == 0) && !(getenv("SFFT_THETA_SLOTS") && atoi(getenv("SFFT_THETA_SLOTS")) == 0)) {
+                (env_theta_slots() != 0)) {
                 for (int a = 0; a + 1 < p->Fij; a += 2) {
                     G1Group g = blank(a, a + 1, JP);
                     g.mask = 6; g.pass[1] = the_pass[a + 1]; g.pass[2] = the_pass[a];          // slot 1 = (v1, v2), slot 2 = (v0, v2)
@@ -1336,8 +1330,7 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             for (int d = 0; d < nd; ++d) for (int x1 = 0; x1 < N1; ++x1)
                 cyp[(size_t)d * N1 + x1] = p->gam_tab ? BS.kby[(size_t)(d / NQB) * N1 + x1] * ipow_host((x1 + 1.0) / N1, d % NQB) : ipow_host((x1 + 1.0) / N1, d);
             // the 4096^2 fast path with a polynomial kernel basis: the moments come out of the row pass of the forward transforms
-            p->rowmom_fused = (!p->gam_tab && !p->no_fast_fft && !p->no_staged && N0 == 4096 && N1 == 4096 && nd <= ROWMOM_FUSED_MAX && p->nby <= ROWMOM_FUSED_MAX &&
-                               !(getenv("SFFT_ROWMOM_FUSED") && atoi(getenv("SFFT_ROWMOM_FUSED")) == 0)) ? 1 : 0;
+            p->rowmom_fused = (!p->gam_tab && !p->no_fast_fft && !p->no_staged && N0 == 4096 && N1 == 4096 && nd <= ROWMOM_FUSED_MAX && p->nby <= ROWMOM_FUSED_MAX) ? 1 : 0;
             PLAN_TRY(dev_alloc(p, &p->d_cyp, cyp.size()));
             PLAN_HIP(hipMemcpy(p->d_cyp, cyp.data(), cyp.size() * sizeof(double), hipMemcpyHostToDevice));
             PLAN_TRY(dev_alloc(p, &p->d_rowmomI, (size_t)N0 * GAMMA_ND));
@@ -1377,13 +1370,8 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
             PLAN_HIP(hipMemset(p->d_luxchg, 0, lu_xchg_bytes()));
         }
         if (getenv("SFFT_DF_TRACE")) { PLAN_TRY(dev_alloc(p, &p->d_trace, (size_t)nblk_b * 16)); PLAN_HIP(hipMemset(p->d_trace, 0, (size_t)nblk_b * 16 * 8)); }
-        if (const char* ev = getenv("SFFT_CHOL_DF")) p->dataflow = atoi(ev);
-        if (const char* ev = getenv("SFFT_PANEL4")) p->panel4 = atoi(ev);
         PLAN_TRY(dev_alloc(p, &p->d_pq, (size_t)PANEL4_MAX_OUTER + 16));
         PLAN_HIP(hipMemset(p->d_pq, 0, ((size_t)PANEL4_MAX_OUTER + 16) * sizeof(unsigned int)));
-        if (const char* ev = getenv("SFFT_CHOL_DF_WG")) p->df_groups = std::max(1, atoi(ev));
-        if (const char* ev = getenv("SFFT_FUSED_STEP")) p->fused_step = atoi(ev);
-        if (const char* ev = getenv("SFFT_BACK")) p->back_variant = atoi(ev);
         int ncu = 0;
         PLAN_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
         p->ncu = ncu;
@@ -1727,7 +1715,7 @@ static void big_axis_transform(sfft_plan* p, const AxisHost& ax, cplx* data, cpl
 static bool staged_cols_shared_first_pass(sfft_plan* p, const AxisHost& ax, const cplx* stage, int nout, cplx* const* dsts, const double* const* wx,
                                           long long st, long long lst, int nlines, hipStream_t s)
 {
-    if (ax.bigblue || !ax.subA || ax.A != 16 || ax.subA->M != 16 || ax.subA->blue || p->no_dft16_regs || p->colscr_planes < 2 || p->no_dft16_multi) return false;
+    if (ax.bigblue || !ax.subA || ax.A != 16 || ax.subA->M != 16 || ax.subA->blue || p->no_dft16_regs || p->colscr_planes < 2) return false;
     PassDesc d1, d2;
     four_step_passes(ax, st, lst, nlines, true, 0, p->d_ones, &d1, &d2);        // (d1.w only says "weighted": the kernel takes the weights per output)
     const size_t plane_sz = (size_t)p->N0 * p->Nhp;
@@ -1884,7 +1872,7 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                     g.stage_plane[g.nout] = k; g.out_plane[g.nout] = o.plane; g.wx[g.nout] = o.wx;
                     g.lo[g.nout] = 0; g.hi[g.nout] = p->N0;
                     const ptrdiff_t off = o.wx - p->d_kbx;
-                    if (!p->no_wx_support && off >= 0 && off < (ptrdiff_t)p->kbx_lo.size() * p->N0) {
+                    if (off >= 0 && off < (ptrdiff_t)p->kbx_lo.size() * p->N0) {
                         g.lo[g.nout] = p->kbx_lo[off / p->N0]; g.hi[g.nout] = p->kbx_hi[off / p->N0];
                     }
                     ++g.nout;
@@ -2372,11 +2360,11 @@ static int solve_impl(sfft_plan* p, const double* d_I, const double* d_J, double
     // group, so only one of the two moment sets would be written: such a call takes the separate row_moments launches.
     struct ScopedInt { int& r; int old; ScopedInt(int& ref, int v) : r(ref), old(ref) { r = v; } ~ScopedInt() { r = old; } }
         rowmom_scope(p->rowmom_fused, d_I == d_J ? 0 : p->rowmom_fused);
-    const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !p->no_gamma_aside;
+    const bool gamma_aside = p->gamma_analytic && p->rowmom_fused && p->s2 && s != nullptr;
     // Without the fused row moments (every shape but 4096^2, and solve(I, I)) the Gamma block needs nothing but the image itself: its three
     // kernels (row moments of I, gamma_rows, gamma_patches: 0.42 ms at config 3, 0.60 ms at config 5, a few workgroups each) go to the second
     // stream right at the start of the solve, beside the forward transforms, instead of sitting on the main stream behind the Omega launch
-    const bool gamma_early = p->gamma_analytic && !p->rowmom_fused && p->s2 && !p->no_overlap && s != nullptr && !p->no_gamma_aside;
+    const bool gamma_early = p->gamma_analytic && !p->rowmom_fused && p->s2 && s != nullptr;
     if (gamma_early) {
         const int nd = p->gam_nmu, NQB = p->gam_db + 1, NJ = p->gam_tab ? p->nky : p->DK + 1;
         HIPCHK(hipEventRecord(p->ev_mom, s));                      // (behind the previous pair's fill_system, which reads the patches)
@@ -2680,12 +2668,6 @@ extern "C" int sfft_subtract(sfft_plan* p, const double* d_I, const double* d_J,
     hipStream_t s = (hipStream_t)stream;
     ON_DEVICE(p->dev);
     int rc;
-    if (p->no_overlap) {
-        if ((rc = sfft_solve(p, d_mI, d_mJ, d_solution, stream))) return rc;
-        if ((rc = sfft_apply(p, d_I, d_J, d_solution, d_diff, stream))) return rc;
-        HIPCHK(hipStreamSynchronize(s));
-        return SFFT_OK;
-    }
     // One host sync per pair: the solve is enqueued without waiting for its status word, the apply pass follows on the stream, and
     // the status is looked at after the final sync.  Only if the Cholesky attempt failed (LU fallback) is the apply pass redone.
     bool redone = false;
