@@ -1301,6 +1301,39 @@ def test_pair_column_pass_equals_quad_column_pass_4096(dev, w, DK, DB, same):
     assert rms(a[1] - b[1]) <= 1e-8 * rms(b[1])
 
 
+def test_pair_column_pass_with_a_bspline_basis_4096(dev):
+    """The pair-per-workgroup column pass under a tabulated (B-spline, 5 x 5 terms) kernel basis at 4096^2: 26 output planes from 6 stage planes in
+    one launch, Omega products summed in real space beside it (omega_sparse), the tensor form of the mixed-domain apply -- against the four-column
+    kernel (SFFT_COLZ=0), itself held to the oracle on the 768^2 / 1536^2 / 6144 x 96 B-spline cases.  A self-comparison: regression guard."""
+    from sfft_amd.plan import Plan
+    from sfft_amd.BSplineSFFT import _axis_tables
+    N, w = 4096, 4
+    REF, SCI, mREF, mSCI = _blob_pair(N, N, 9)
+    kx, ky = [N / 3 + 0.5, 2 * N / 3 + 0.5], [N / 3 + 0.5, 2 * N / 3 + 0.5]
+    kbx, kby, kpairs = _axis_tables(N, N, "B-Spline", 2, kx, ky)
+    tbx, tby, bpairs = _axis_tables(N, N, "Polynomial", 2, [], [])
+    bdict = dict(kbx=kbx, kby=kby, ker_pairs=kpairs, tbx=tbx, tby=tby, bkg_pairs=bpairs, scaling_mode=2)
+    I, J, mI, mJ = _to(dev, REF), _to(dev, SCI), _to(dev, mREF), _to(dev, mSCI)
+    outs = []
+    for env in ({}, {"SFFT_COLZ": "0"}):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            plan = Plan(N, N, w, device=dev.index, basis=bdict)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        plan.set_timing(True)
+        sol, diff = plan.subtract(I, J, mI, mJ)
+        LH, rhs = plan.get_system()
+        outs.append((sol.cpu().numpy(), diff.cpu().numpy(), LH.cpu().numpy(), rhs.cpu().numpy(), plan.stage_kernels()["fwd_cols"]))
+        plan.close()
+    a, b = outs
+    assert a[4] == ["cols_fwd_weighted_4096_z"] and b[4] == ["cols_fwd_weighted_4096_q"], (a[4], b[4])
+    assert np.abs(a[2] - b[2]).max() <= 1e-12 * np.abs(b[2]).max() and np.abs(a[3] - b[3]).max() <= 1e-12 * np.abs(b[3]).max()
+    assert rms(a[1] - b[1]) <= 1e-8 * rms(b[1])
+
+
 def test_outer_blocked_cholesky_equals_plain_blocked(dev):
     """Systems of 3000+ unknowns factor in 256-column outer blocks with a rank-256 matrix-core update (chol_syrk); forced on
     at n = 1735 it must give the solution of the rank-64 path on the same matrix (and the matrix itself is untouched)."""
