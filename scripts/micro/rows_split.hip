@@ -18,6 +18,9 @@ typedef double2 cplx;
 #include "../../sfft_amd/csrc/fft_generic.hpp"
 #include "../../sfft_amd/csrc/fft_r16_4096.hpp"
 
+#ifndef RS_LWPS
+#define RS_LWPS 3
+#endif
 #ifndef RS_WPS
 #define RS_WPS 3
 #endif
@@ -88,6 +91,90 @@ __global__ void __launch_bounds__(256, RS_WPS) rows_r2c_4096_s(RowsArgs a, RowGr
     }
 }
 
+
+// Lean form for three workgroups per CU (<= 168 registers): the rows are NOT held across planes (planes after the first read them again, from the
+// L2), the exchanges overwrite real / imaginary parts in place, and the partner exchange keeps 18 partial outputs instead of 36 partner values.
+template <class T> __device__ __forceinline__ T* at_b(T* base, unsigned off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off); }
+template <class T> __device__ __forceinline__ const T* at_b(const T* base, unsigned off) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off); }
+template <int AB>
+__global__ void __launch_bounds__(256, RS_LWPS) rows_r2c_4096_l(RowsArgs a, RowGroups grp, cplx* __restrict__ out, int N0, int Nhp, SpecLayout lay,
+                                                          const cplx* __restrict__ tw, double scale, int pairs_per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    const int N1 = 4096;
+    const int j = threadIdx.x;
+    const int pfirst = grp.first[blockIdx.y], pcount = grp.count[blockIdx.y];
+    const int rp = (int)(blockIdx.x & 7) * pairs_per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= pairs_per_xcd || 2 * rp >= N0) return;
+    const int l0 = 2 * rp, l1 = l0 + 1;
+    // addresses = (workgroup-uniform pointer) + (32-bit byte offset of the lane): see fft_r24.hpp
+    const double* __restrict__ src = a.src[pfirst];
+    const double* r0u = src + (size_t)l0 * N1;
+    const double* r1u = src + (size_t)l1 * N1;
+    const unsigned jo8 = (unsigned)j * 8u;
+    const unsigned so = (unsigned)(((size_t)(j >> 2) * (size_t)lay.pstride + (size_t)(j & 3)) * sizeof(cplx));     // 4-column panels: column j + 256 sx sits 64 sx panels further
+    const size_t sstep = (size_t)64 * (size_t)lay.pstride;
+    const double hs = 0.5 * scale;
+    for (int pp = 0; pp < pcount; ++pp) {
+        const int plane = pfirst + pp;
+        const double* __restrict__ wyu = a.wy[plane];
+        const double cx0 = a.wx[plane][l0], cx1 = a.wx[plane][l1];
+        cplx u[16];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            double f[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = 8 * hb + r;
+                u[rr] = make_double2(*at_b(r0u + 256 * rr, jo8), *at_b(r1u + 256 * rr, jo8));
+                f[r] = *at_b(wyu + 256 * rr, jo8);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { u[8 * hb + r].x *= cx0 * f[r]; u[8 * hb + r].y *= cx1 * f[r]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (pp > 0) __syncthreads();
+        int zoff;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+        double p0x[9], p1y[9];          // X0.x = hs (z.x + zp.x), X1.y = -hs (z.x - zp.x): need the partner's real part only
+        if (!(AB & 1)) {
+            fft4096_core_split2(u, j, lds, tw + zoff, 0);
+            __syncthreads();
+#pragma unroll
+            for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)].x;
+            __syncthreads();
+            const double* pr = lds + ((N1 - j) & (N1 - 1));      // partner of element j + 256 sx: (N1 - j) - 256 sx (j = 0: element (16 - sx) 256 mod N1)
+#pragma unroll
+            for (int sx = 0; sx <= 8; ++sx) {
+                const double zr = (j == 0) ? lds[(256 * (16 - sx)) & (N1 - 1)] : pr[-256 * sx];
+                const double zx = u[R16_OUT(sx)].x; p0x[sx] = hs * (zx + zr); p1y[sx] = -hs * (zx - zr);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int sx = 0; sx < 16; ++sx) lds[j + 256 * sx] = u[R16_OUT(sx)].y;
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int sx = 0; sx <= 8; ++sx) { p0x[sx] = u[sx].x; p1y[sx] = u[sx].y; }
+        }
+        cplx* o0u = out + (size_t)plane * N0 * Nhp + (size_t)l0 * lay.rstride;
+        cplx* o1u = out + (size_t)plane * N0 * Nhp + (size_t)l1 * lay.rstride;
+        const double* pr = lds + ((N1 - j) & (N1 - 1));
+#pragma unroll
+        for (int sx = 0; sx <= 8; ++sx) {
+            if (sx < 8 || j == 0) {
+                const double zy = u[R16_OUT(sx)].y;
+                const double zi = (AB & 1) ? zy : ((j == 0) ? lds[(256 * (16 - sx)) & (N1 - 1)] : pr[-256 * sx]);
+                const cplx v0 = make_double2(p0x[sx], hs * (zy - zi)), v1 = make_double2(hs * (zy + zi), p1y[sx]);
+                cplx* q0 = at_b(o0u + sstep * sx, so); cplx* q1 = at_b(o1u + sstep * sx, so);
+                if (AB & 2) { if (v0.x == 1.2345e300) st_stream(q0, v0); if (v1.x == 1.2345e300) st_stream(q1, v1); }
+                else { st_stream(q0, v0); st_stream(q1, v1); }
+            }
+        }
+    }
+}
+
 template <typename F> static float time_ms(F f, int reps)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -143,6 +230,22 @@ int main(int argc, char** argv)
             }
             printf("max |product - split| / max |product| = %.3e\n", d / m);
         }
+        auto f_lean = [&] { hipLaunchKernelGGL(rows_r2c_4096_l<0>, dim3(8 * rp_per, grp.ngroups), dim3(256), Z4K_LDS * sizeof(double), 0, ra, grp, dout2, N0, Nhp, lay, dtw, 0.25, rp_per); };
+        auto f_lean_ns = [&] { hipLaunchKernelGGL(rows_r2c_4096_l<2>, dim3(8 * rp_per, grp.ngroups), dim3(256), Z4K_LDS * sizeof(double), 0, ra, grp, dout2, N0, Nhp, lay, dtw, 0.25, rp_per); };
+        const float t_lean = time_ms(f_lean, reps);
+        HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+        if (rep == 0) {
+            std::vector<cplx> h1(4 * plane_sz), h2(4 * plane_sz);
+            HIPCHK(hipMemcpy(h1.data(), dout1, 4 * plane_sz * 16, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(h2.data(), dout2, 4 * plane_sz * 16, hipMemcpyDeviceToHost));
+            double d = 0, m = 0;
+            for (int pl = 0; pl < 4; ++pl) for (int l = 0; l < N0; ++l) for (int k = 0; k < Nh; ++k) {
+                const size_t i = (size_t)pl * plane_sz + lay.at(l, k);
+                d = std::max(d, std::max(fabs(h1[i].x - h2[i].x), fabs(h1[i].y - h2[i].y))); m = std::max(m, std::max(fabs(h1[i].x), fabs(h1[i].y)));
+            }
+            printf("max |product - lean| / max |product| = %.3e\n", d / m);
+        }
+        const float t_lean_ns = time_ms(f_lean_ns, reps);
+        printf("  lean form, three workgroups per CU: %.4f ms (%.2f TB/s), without stores %.4f\n", t_lean, bytes / t_lean * 1e-9, t_lean_ns);
         const float t_mov = time_ms(f_mov, reps), t_nst = time_ms(f_nst, reps);
         printf("rows r2c (solve launch, 4 planes): product %.4f ms (%.2f TB/s)  split exchanges, %d waves per SIMD %.4f ms (%.2f TB/s)  mover %.4f  no stores %.4f\n",
                t_old, bytes / t_old * 1e-9, RS_WPS, t_new, bytes / t_new * 1e-9, t_mov, t_nst);

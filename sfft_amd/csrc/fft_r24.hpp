@@ -29,6 +29,26 @@ template <class T> __device__ __forceinline__ const T* at_byte(const T* base, un
 }
 
 
+// R24_NT (tuning macro, A/B): bit 0 the spectra of cols_fwd_weighted_r24, bit 1 the DIFF rows of rows_c2r_diff_r24, bit 2 the outputs of strided_rader577_r24
+// leave with non-temporal stores
+#ifndef R24_NT
+#define R24_NT 0
+#endif
+#if R24_NT & 1
+#define R24_ST1(p, v) st_nt(p, v)
+#else
+#define R24_ST1(p, v) (*(p) = (v))
+#endif
+#if R24_NT & 2
+#define R24_ST2(p, v) st_nt(p, v)
+#else
+#define R24_ST2(p, v) (*(p) = (v))
+#endif
+#if R24_NT & 4
+#define R24_ST4(p, v) st_nt(p, v)
+#else
+#define R24_ST4(p, v) (*(p) = (v))
+#endif
 template <int Q> struct R24 {
     static constexpr int N = 384 * Q;                // 6144, 9216
     static constexpr int NT = 24 * Q;                // threads: 384, 576
@@ -244,7 +264,7 @@ __global__ void __launch_bounds__(24 * Q * NC) cols_fwd_weighted_r24(const cplx*
 #pragma unroll
     for (int d = 0; d < 8; ++d)
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) { cplx* __restrict__ dr = dst + (size_t)(F::NQ * (d + 8 * cc)) * rs; *at_byte(dr, jo) = dft24_x(G, d, cc); }
+        for (int cc = 0; cc < 3; ++cc) { cplx* __restrict__ dr = dst + (size_t)(F::NQ * (d + 8 * cc)) * rs; R24_ST1(at_byte(dr, jo), dft24_x(G, d, cc)); }
 }
 
 // rows, real -> half complex (N1 = 384 Q), two image rows per transform, spatial factors fused (see rows_r2c_4096 for the arguments).
@@ -424,8 +444,8 @@ __global__ void __launch_bounds__(24 * Q) rows_c2r_diff_r24(const cplx* __restri
                 B0 = fma(c0[q], tb[e][q], B0);
                 B1 = fma(c1[q], tb[e][q], B1);
             }
-            *at_byte(d0 + n0, jb) = jv0[e] - B0 - z.x;
-            if (has1) *at_byte(d1 + n0, jb) = jv1[e] - B1 + z.y;
+            R24_ST2(at_byte(d0 + n0, jb), jv0[e] - B0 - z.x);
+            if (has1) R24_ST2(at_byte(d1 + n0, jb), jv1[e] - B1 + z.y);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -516,7 +536,7 @@ __global__ void __launch_bounds__(RDR_NT, 3) strided_rader577_r24(const cplx* __
     const unsigned lout = (unsigned)(seq * (int)d.lst_out) * (unsigned)sizeof(cplx), eout = (unsigned)d.es_out * (unsigned)sizeof(cplx);
     const double sy = d.conj_out ? d.scale : -d.scale;          // (the conjugation of the second transform, and the caller's)
 #pragma unroll
-    for (int k = 0; k < 24; ++k) *at_byte(pout, lout + (unsigned)gout[i + 24 * k] * eout) = make_double2(F[k].x * d.scale, F[k].y * sy);
+    for (int k = 0; k < 24; ++k) R24_ST4(at_byte(pout, lout + (unsigned)gout[i + 24 * k] * eout), make_double2(F[k].x * d.scale, F[k].y * sy));
     if (i == 0) {
         const cplx X0 = cadd(x0, A0);
         *at_byte(pout, lout) = make_double2(X0.x * d.scale, d.conj_out ? -X0.y * d.scale : X0.y * d.scale);

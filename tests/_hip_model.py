@@ -313,3 +313,77 @@ def construct_fd(specI, sol, p, ax0, ax1):
             K += ax0.root[(l * (aa - w)) % N0][:, None] * C[aa][None, :]
         FD += specI[ij] * (scale * (K - soff))
     return FD
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 6: index arithmetic of the pair-per-workgroup column pass (cols_fwd_weighted_4096_z) and of the 2048-point
+# network of scripts/micro/fft_h2048.hpp
+# ------------------------------------------------------------------------------------------------
+def pair_major_offset(l, m, pstride):
+    """Element (row l, spectrum column m) of a stage plane with pair-major lines: 4-column panels, every 128-byte line (rows 2p, 2p + 1 x
+    columns 0..3) stored [column pair h][row parity][column c]."""
+    return (m >> 2) * pstride + (l >> 1) * 8 + ((m >> 1) & 1) * 4 + (l & 1) * 2 + (m & 1)
+
+
+def rows_pm_store_offsets(l0, pstride):
+    """What rows_r2c_4096 (pm = 1) stores where for the row pair (l0, l0 + 1): {offset: (row, column)}.  Thread j, step sx holds X0[m], X1[m]
+    (rows l0, l0 + 1) of column m = j + 256 sx; lanes 0, 1 of a quad send X1 and receive X0 from lanes 2, 3; instruction A stores at
+    line + (j & 3), instruction B at line + 4 + (j & 3)."""
+    out = {}
+    for sx in range(9):
+        for j in range(256 if sx < 8 else 4):
+            m = j + 256 * sx
+            t = j & 3
+            even = t < 2
+            partner_m = m ^ 2                       # lane ^ 2 holds column m ^ 2
+            base = (l0 >> 1) * 8 + t + (m >> 2) * pstride
+            # A: even ? X0[m] : got = X1 of the partner (the partner is even and sent X1);  B: even ? got = X0 of the partner : X1[m]
+            a_val = (l0, m) if even else (l0 + 1, partner_m)
+            b_val = (l0, partner_m) if even else (l0 + 1, m)
+            assert base not in out and base + 4 not in out
+            out[base] = a_val
+            out[base + 4] = b_val
+    return out
+
+
+def cols_z_load_offset(tid, r, cp, pstride):
+    """Element offset of the r-th load of lane tid = 2 j + c in cols_fwd_weighted_4096_z for column pair cp, and the (row, column) it must be."""
+    off = (cp >> 1) * pstride + (cp & 1) * 4 + (tid >> 2) * 8 + (tid & 3) + 1024 * r
+    return off, ((tid >> 1) + 256 * r, 2 * cp + (tid & 1))
+
+
+def h2048_forward(z):
+    """The 2048-point network of fft_h2048.hpp (fft2048_fwd), thread by thread: returns (A, B, C, Cp) with A[s4][j] = Z[C + 512 s4], B = Z[Cp + 512 s4]."""
+    tw = np.exp(-2j * np.pi * np.arange(4096) / 4096)
+    j = np.arange(256)
+    u = np.fft.fft(np.stack([z[j + 256 * r] for r in range(8)]), axis=0)
+    for s in range(8):
+        u[s] = u[s] * tw[2 * j * s]
+    lds = np.zeros(2304, complex)
+    for s in range(8):
+        lds[256 * s + j] = u[s]
+    a, s1 = j & 31, j >> 5
+    u = np.fft.fft(np.stack([lds[256 * s1 + a + 32 * b] for b in range(8)]), axis=0)
+    for s in range(8):
+        u[s] = u[s] * tw[16 * a * s]
+    lds[:] = 0
+    for s2 in range(8):
+        lds[a + 36 * (s1 + 8 * s2)] = u[s2]
+    c, Q = j & 3, j >> 2
+    u = np.fft.fft(np.stack([lds[c + 4 * d + 36 * Q] for d in range(8)]), axis=0)
+    for s in range(8):
+        u[s] = u[s] * tw[128 * c * s]
+    lds[:] = 0
+    for s3 in range(8):
+        lds[514 * c + Q + 64 * s3] = u[s3]
+    C, Cp = j, np.where(j > 0, 512 - j, 256)
+    A = np.fft.fft(np.stack([lds[514 * cc + C] for cc in range(4)]), axis=0)
+    B = np.fft.fft(np.stack([lds[514 * cc + Cp] for cc in range(4)]), axis=0)
+    return A, B, C, Cp
+
+
+def h2048_untangle(Zk, Zp, wk, h=0.5):
+    """untangle2 of fft_h2048.hpp: (X[k], X[2048 - k]) from Z[k], Z[2048 - k], w = exp(-2 pi i k / 4096)."""
+    S, D = Zk + np.conj(Zp), Zk - np.conj(Zp)
+    wd = wk * D
+    return h * ((S.real + wd.imag) + 1j * (S.imag - wd.real)), h * ((S.real - wd.imag) + 1j * (-S.imag - wd.real))
