@@ -29,10 +29,11 @@ template <class T> __device__ __forceinline__ const T* at_byte(const T* base, un
 }
 
 
-// R24_NT (tuning macro, A/B): bit 0 the spectra of cols_fwd_weighted_r24, bit 1 the DIFF rows of rows_c2r_diff_r24, bit 2 the outputs of strided_rader577_r24
-// leave with non-temporal stores
+// R24_NT (tuning macro): bit 0 the spectra of cols_fwd_weighted_r24, bit 1 the DIFF rows of rows_c2r_diff_r24, bit 2 the outputs of strided_rader577_r24
+// leave with non-temporal stores.  Measured per bit (round 6, profiles/r06_f_ab_r24_nontemporal.txt): bit 0 costs config 3's column pass 3.1 -> 4.7 ms (its
+// 32-byte pieces need the L2 to meet their neighbours), bit 1 nothing either way, bit 2 gains config 5 1.7 % (42.9 - 43.0 against 42.1 - 42.3 pairs/s): 4 is the default.
 #ifndef R24_NT
-#define R24_NT 0
+#define R24_NT 4
 #endif
 #if R24_NT & 1
 #define R24_ST1(p, v) st_nt(p, v)
