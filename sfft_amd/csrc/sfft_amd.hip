@@ -254,7 +254,8 @@ struct sfft_plan {
     int colq = 1;                       // four columns per workgroup on 4-column panels (cols_fwd_weighted_4096_q); other panel widths take the two-column kernel
     int colz = 1;                       // solve pass of the 4096^2 path: cols_fwd_weighted_4096_z (two workgroups per CU; pair-major stage lines in, 2-column
                                         // panels out).  env SFFT_COLZ=0: cols_fwd_weighted_4096_q.  Set to 0 by the plan when its conditions do not hold.
-    SpecLayout lay_spec;                // layout of the solve pass's spectra in d_spec (= lay unless colz)
+    SpecLayout lay_spec;                // layout of the solve pass's spectra in d_spec (= lay unless colz / spec2)
+    int spec2 = 1;                      // 6144-point column axis on the paired kernel (cols_fwd_weighted_r24<16, 2>): spectra in 2-column panels.  env SFFT_SPEC2=0: the plan's layout
     int chol_outer_min = 3000;          // env SFFT_CHOL_OUTER_MIN: systems at least this large factor in 256-column outer blocks
     int g1_mfma = 3;                    // Omega passes on the matrix cores: 3 = greek_g1_mfma4g (pass groups that share plane loads, v_mfma_f64_4x4x4_4b_f64),
                                         // (fixed 3: the grouped launch; 2 = greek_g1_mfma4, one pass per wave, where no groups are built)
@@ -854,6 +855,9 @@ static int plan_create_impl(sfft_plan** out, int N0, int N1, int KerHW, const Ba
     p->cols_r24 = (p->no_fast_fft || getenv("SFFT_NO_COLS_R24")) ? 0 : r24_q(p->ax0);
     if (const char* e = getenv("SFFT_COLS_R24_PAIR")) p->cols_r24_pair = atoi(e) != 0;
     if (p->lay.mask < 1) p->cols_r24_pair = false;          // (row-major planes: neighbouring columns are not neighbours in memory)
+    if (const char* ev = getenv("SFFT_SPEC2")) p->spec2 = atoi(ev);
+    if (!(p->use_vconv && !p->no_staged && p->cols_r24 == 16 && p->cols_r24_pair && p->lay.mask == 3 && p->lay.rstride == 4)) p->spec2 = 0;
+    if (p->spec2) { p->lay_spec.shift = 1; p->lay_spec.mask = 1; p->lay_spec.rstride = 2; p->lay_spec.pstride = (long long)N0 * 2; }
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_r2c_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)rows_c2r_diff_r24<24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PLAN_HIP(hipFuncSetAttribute((const void*)cols_fwd_weighted_r24<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1861,6 +1865,8 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
             if (p->timing && st_cols >= 0) { hipEventRecord(p->ev[st_cols][1], s); p->ev_valid[st_cols] = true; tl_klog = klog_outer; }
             return SFFT_OK;
         }
+        // the solve pass's spectra of a plan with the paired 6144-point column kernel go out in 2-column panels (lay_spec; the Greek launches read them)
+        const SpecLayout lay_cols_out = (p->spec2 && d_J != nullptr && dst == p->d_spec) ? p->lay_spec : p->lay;
         const int G = p->TC >= 8 ? 1 : 8 / p->TC;
         const int ntiles = (p->Nh + p->TC - 1) / p->TC;
         const int ntg = (ntiles + 8 * G - 1) / (8 * G);           // tile groups per XCD
@@ -1884,13 +1890,13 @@ static int forward_basis_planes_staged(sfft_plan* p, const double* d_I, const do
                 const dim3 grid(64 * g.nout * ((p->Nh + 63) / 64));
                 if (p->cols_r24 == 16 && p->cols_r24_pair)        // two panel neighbours per workgroup, in neighbouring lanes
                     SFFT_LAUNCH((cols_fwd_weighted_r24<16, 2>), dim3(grid.x / 2), dim3(2 * R24<16>::NT), (2 * R24<16>::LDS + 16) * sizeof(double), s,
-                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
+                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, lay_cols_out, p->ax0.tw);
                 else if (p->cols_r24 == 16)
                     SFFT_LAUNCH(cols_fwd_weighted_r24<16>, grid, dim3(R24<16>::NT), R24<16>::LDS * sizeof(double), s,
-                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
+                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, lay_cols_out, p->ax0.tw);
                 else
                     SFFT_LAUNCH(cols_fwd_weighted_r24<24>, grid, dim3(R24<24>::NT), R24<24>::LDS * sizeof(double), s,
-                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, p->ax0.tw);
+                                       p->d_stage, dst, g, p->Nh, p->Nhp, p->lay, lay_cols_out, p->ax0.tw);
                 continue;
             }
             SFFT_LAUNCH(cols_fwd_weighted, dim3(8 * G * g.nout * ntg), dim3(p->nt_cols), p->lds_cols, s, p->d_stage, dst, g, p->N0, p->Nh,
