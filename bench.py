@@ -295,6 +295,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline with the full protocol (3 warm-ups, median of 10) instead of the bounded one")
     ap.add_argument("--no-host-arrays", action="store_true", help="skip the host-array (PCIe-inclusive) variant")
+    ap.add_argument("--no-lu-leg", action="store_true", help="skip the forced-LU leg and the vendor getrf + getrs yardstick behind the timed region "
+                    "(profiling runs: thousands of tiny vendor launches under rocprofv3 --pmc crashed the tool at configs 3 / 5)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of configs 3, 4 and 5 after the headline run")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the N > 1 run: nccl (= RCCL over "
                     "xGMI, the default) or gloo (records and timing cross the ranks as host tensors; tests)")
@@ -502,6 +504,8 @@ def run_config(args, rank, world, local_rank, headline_extras=True):
         # stage's duration beside the Cholesky path's, and the DIFF it leads to against the Cholesky run's
         solve_lu = None
         try:
+            if args.no_lu_leg:
+                raise RuntimeError("skipped (--no-lu-leg)")
             plans[0].set_force_lu(True)
             g = pairs[check_ids[0]]
             lu_ms = []

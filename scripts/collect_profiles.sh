@@ -4,7 +4,7 @@ set -x
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles; mkdir -p $OUT
 EXTRA="$@"
 cd /tmp && export TMPDIR=/tmp
-ONE="--streams 1 --batch 4 --no-cpu --no-host-arrays --no-other-configs $EXTRA"
+ONE="--streams 1 --batch 4 --no-cpu --no-host-arrays --no-other-configs --no-lu-leg $EXTRA"
 # (1) kernel trace + stats, one pair in flight (kernel durations not interleaved with other streams)
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks -- python $GRAFT_REPO_ROOT/bench.py $ONE --steps 5 --warmup 2 > $OUT/bench_streams1.json 2> /dev/null
 cp $GRAFT_REPO_ROOT/profiles/bench_last_full.json $OUT/bench_streams1_full.json      # (carries stage_kernels: which kernels each stage launched)
