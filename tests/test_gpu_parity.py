@@ -1260,12 +1260,13 @@ def _subtract_with_env(dev, env, shape, w, DK, DB, pair):
     return out
 
 
-@pytest.mark.parametrize("w,DK,DB,same", [(8, 2, 2, False), (4, 1, 0, False), (8, 2, 2, True)])
+@pytest.mark.parametrize("w,DK,DB,same", [(8, 2, 2, False), (4, 1, 0, False), (8, 2, 2, True), (12, 3, 2, False), (5, 2, 1, False), (2, 0, 0, False)])
 def test_pair_column_pass_equals_quad_column_pass_4096(dev, w, DK, DB, same):
     """Round 6: the solve pass of the 4096^2 path transforms one column PAIR per workgroup (cols_fwd_weighted_4096_z: two workgroups per CU,
     stage planes with pair-major lines, spectra in 2-column panels read by the Greek launches) -- against the four-column kernel
     (SFFT_COLZ=0, the round-1..5 path, itself held to the oracle by test_config2_full_size_matches_oracle): the same linear system block by
-    block to 1e-12, the same difference image.  `same`: I passed as its own mask (the apply pass then must NOT reuse the solve pass's
+    block to 1e-12, the same difference image.  KerHW 12: the Omega launch in two lag bands; KerHW 5 / 2: the vector Greek kernels -- every reader of the
+    2-column spectra.  `same`: I passed as its own mask (the apply pass then must NOT reuse the solve pass's
     pair-major stage planes).  A self-comparison of two HIP paths: a regression guard, not parity evidence."""
     from sfft_amd.utils.synthetic import make_pair
     shape = (4096, 4096)
